@@ -1,0 +1,83 @@
+"""ctypes binding of liblcr_hip.so (C ABI: include/lcr_hip.h).  Loud failure if the library is absent."""
+import ctypes
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "liblcr_hip.so")
+
+_lib = None
+
+c_f32p = ctypes.c_void_p
+c_vp = ctypes.c_void_p
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_size_p = ctypes.POINTER(ctypes.c_size_t)
+
+_SIGS = {
+    "lcr_last_error": (ctypes.c_char_p, []),
+    "lcr_version": (c_int, []),
+    "lcr_support_grid_ws_bytes": (c_int, [c_i64, c_int, c_size_p]),
+    "lcr_support_grid_build": (c_int, [c_vp, c_vp, c_int, c_i64, c_float, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "lcr_radius_query": (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_i64, c_float, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "lcr_radius_search_ws_bytes": (c_int, [c_i64, c_i64, c_int, c_size_p]),
+    "lcr_radius_search": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_float, c_int, c_vp, c_vp, c_vp, c_vp,
+                                  c_vp, ctypes.c_size_t, c_vp]),
+    "lcr_grid_subsample_ws_bytes": (c_int, [c_i64, c_int, c_size_p]),
+    "lcr_grid_subsample": (c_int, [c_vp, c_vp, c_int, c_i64, c_float, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+}
+
+
+def build():
+    """Compile the library in-tree (hipcc, gfx950)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_lcr_build", os.path.join(_PKG, "csrc", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build()
+
+
+def lib():
+    """The loaded library.  Raises RuntimeError (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "liblcr_hip.so not found at %s — build it with `python lcr-net_amd/csrc/build.py` "
+                "(there is no CPU fallback for the lcr-net_amd hot path)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            if not hasattr(L, name):
+                continue  # symbol presence is enforced by tests/test_cabi_symbols.py against include/lcr_hip.h
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().lcr_last_error()
+        raise RuntimeError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+
+def ptr(t):
+    """Device pointer of a tensor (or NULL for None)."""
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("lcr-net_amd ops run on the GPU only: got a %s tensor (no CPU fallback)" % t.device)
+
+
+def workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

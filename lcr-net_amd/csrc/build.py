@@ -1,0 +1,64 @@
+"""Build liblcr_hip.so (all HIP kernels + the C ABI) for gfx950, in-tree.
+
+    python lcr-net_amd/csrc/build.py [--force]
+
+hipcc cross-compiles without a GPU.  Objects go to csrc/_obj/, the library to lcr-net_amd/liblcr_hip.so
+(git-ignored, but it travels to the GPU box with the working tree).  -ffp-contract=off everywhere: the
+subsample / radius-search kernels must reproduce the reference's un-fused fp32 arithmetic bit for bit
+(SURVEY §7 "hard parts"); kernels that want FMA call fmaf / MFMA explicitly.
+"""
+import concurrent.futures as cf
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+OBJ = os.path.join(HERE, "_obj")
+LIB = os.path.join(PKG, "liblcr_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+         "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def _newer(src, dst, deps):
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    return any(os.path.getmtime(p) > t for p in [src] + deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(HERE, "*.hip")))
+    deps = sorted(glob.glob(os.path.join(HERE, "*.h"))) + [os.path.join(PKG, "..", "include", "lcr_hip.h")]
+    jobs = []
+    for s in srcs:
+        o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
+        if force or _newer(s, o, deps):
+            jobs.append((s, o))
+
+    def cc(job):
+        s, o = job
+        cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), r.stderr))
+        if verbose and r.stderr:
+            sys.stderr.write(r.stderr)
+        return o
+
+    with cf.ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(cc, jobs))
+    objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + ".o") for s in srcs]
+    if force or jobs or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stderr))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

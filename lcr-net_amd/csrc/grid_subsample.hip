@@ -1,0 +1,511 @@
+// grid_subsample.hip — a-1: stack-mode voxel-barycentre subsampling for gfx950, bit-exact with the reference.
+//
+// Replaces utils.ext.grid_subsampling (utils/extensions/cpu/grid_subsampling/grid_subsampling_cpu.cpp:3-75,
+// grid_subsampling_cpu.h:7-21).  The reference walks the points once, accumulating fp32 sums per voxel in a
+// std::unordered_map<size_t, SampledData> and emits the map in ITERATION order.  Three things must match exactly:
+//   (1) the voxel key arithmetic  — origin = floor(min * float(1/v)) * v; i = floor((p - origin) / v) with a true
+//       fp32 division; key = iX + NX*iY + NX*NY*iZ  (:11-35);
+//   (2) the fp32 summation order  — input order within a voxel (.h:17-20), then sum * float(1.0 / count) (:46);
+//   (3) the emission order        — libstdc++'s hash-table iteration order for keys inserted in first-occurrence order.
+//
+// MI355X design.  (1)+(2): keys are radix-sorted together with the row index (stable, so each voxel's run is in input
+// order), one lane walks each run and adds in order.  (3): the unordered_map is never built; its iteration order is
+// reproduced by a closed-form replay of libstdc++'s _Hashtable behaviour, phase by phase of its bucket-count schedule
+// (13, 29, 59, ... — a property of libstdc++, measured with g++ 11.4): within a phase with nb buckets, give every
+// element a timestamp t (its position in the previous phase's list, or its insertion rank if new); the list after the
+// phase is the elements sorted by (min t of their bucket, descending; then t descending).  Each phase is therefore two
+// block-wide scans plus bucket atomics — O(n) parallel work instead of a serial pointer chase.
+// (Verified against std::unordered_map in tests/test_hashmap_order.py through the host mirror lcr_hashmap_order_host.)
+#include <vector>
+
+#include "common.h"
+#include "radix_sort.h"
+
+namespace lcr {
+
+constexpr int GS_MAX_B = 64;
+constexpr int HM_T = 1024;   // threads of the hash-order workgroup (one workgroup per cloud)
+
+__constant__ const int64_t c_sched[] = {13,        29,        59,         127,        257,      541,      1109,     2357,
+                                        5087,      10273,     20753,      42043,      85229,    172933,   351061,   712697,
+                                        1447153,   2938679,   5967347,    12117689,   24607243, 49969847, 101473717,
+                                        206062531, 418453099, 849745171, 1725584621, 3504127453};
+constexpr int N_SCHED = 28;
+static const int64_t h_sched[] = {13,        29,        59,         127,        257,      541,      1109,     2357,
+                                  5087,      10273,     20753,      42043,      85229,    172933,   351061,   712697,
+                                  1447153,   2938679,   5967347,    12117689,   24607243, 49969847, 101473717,
+                                  206062531, 418453099, 849745171, 1725584621, 3504127453};
+
+struct GsHeader {
+  RadixCtl rx;                       // n, num_passes (must be first: radix kernels read it)
+  int      B;
+  int      kbits;                    // bits of the voxel key inside the composite sort key
+  int64_t  n_cap;
+  int64_t  in_off[GS_MAX_B + 1];
+  int64_t  out_off[GS_MAX_B + 1];
+  uint32_t bb_min[GS_MAX_B][3], bb_max[GS_MAX_B][3];
+  float    org[GS_MAX_B][3];
+  uint64_t NX[GS_MAX_B], NY[GS_MAX_B];
+  int32_t  M[GS_MAX_B];              // distinct voxels per cloud
+  int64_t  n_seg;                    // total distinct voxels
+};
+
+struct GsLayout {
+  GsHeader* hdr;
+  uint64_t *keyA, *keyB;
+  uint32_t *valA, *valB;
+  int32_t*  hist;
+  void*     scan_ws;
+  int32_t*  head;        // [n]   head flags -> segment index (scan)
+  int32_t*  first;       // [n]   is-first-occurrence flags by input row -> rank (scan)
+  float*    bary;        // [n,3] barycentre per segment
+  uint64_t* seg_key;     // [n]
+  uint32_t* seg_first;   // [n]
+  uint64_t* ins_key;     // [n]   keys in insertion (first-occurrence) order, per cloud at out_off[b]
+  int32_t*  ins_seg;     // [n]
+  int32_t*  hm_t;        // [n]   timestamps / positions
+  int32_t*  hm_bk;       // [n]   bucket of each element
+  int32_t*  hm_mem;      // [n]   bucket member lists
+  int32_t*  hm_at;       // [n]
+  int32_t*  hm_gmin;     // [bucket_cap]
+  int32_t*  hm_cnt;      // [bucket_cap]
+  int32_t*  hm_start;    // [bucket_cap]
+  size_t    bytes;
+};
+
+static inline int64_t bucket_cap_of(int64_t n, int b) { return (n * 9) / 4 + 64 * (b + 1); }
+
+static GsLayout gs_layout(void* ws, int64_t n_cap, int B) {
+  GsLayout L;
+  Carver c(ws, ~size_t(0));
+  const size_t n = static_cast<size_t>(n_cap > 0 ? n_cap : 1);
+  L.hdr = c.take<GsHeader>(1);
+  L.keyA = c.take<uint64_t>(n);
+  L.keyB = c.take<uint64_t>(n);
+  L.valA = c.take<uint32_t>(n);
+  L.valB = c.take<uint32_t>(n);
+  L.hist = c.take<int32_t>(radix_hist_elems(n_cap));
+  L.scan_ws = c.take<char>(scan_ws_bytes(static_cast<int64_t>(radix_hist_elems(n_cap)) > n_cap ? radix_hist_elems(n_cap) : n_cap + 1));
+  L.head = c.take<int32_t>(n + 1);
+  L.first = c.take<int32_t>(n + 1);
+  L.bary = c.take<float>(3 * n);
+  L.seg_key = c.take<uint64_t>(n);
+  L.seg_first = c.take<uint32_t>(n);
+  L.ins_key = c.take<uint64_t>(n);
+  L.ins_seg = c.take<int32_t>(n);
+  L.hm_t = c.take<int32_t>(n);
+  L.hm_bk = c.take<int32_t>(n);
+  L.hm_mem = c.take<int32_t>(n);
+  L.hm_at = c.take<int32_t>(n + 1);
+  const size_t bc = static_cast<size_t>(bucket_cap_of(n_cap, B));
+  L.hm_gmin = c.take<int32_t>(bc);
+  L.hm_cnt = c.take<int32_t>(bc);
+  L.hm_start = c.take<int32_t>(bc + 1);
+  L.bytes = c.off;
+  return L;
+}
+
+// float -> uint64 exactly as x86-64 gcc does for in-range values (negatives wrap through int64)
+__device__ __forceinline__ uint64_t f2u64(float v) { return static_cast<uint64_t>(static_cast<int64_t>(v)); }
+
+__global__ void k_gs_init(GsHeader* h, const int64_t* __restrict__ len, int B, int64_t n_cap, uint32_t* status) {
+  if (threadIdx.x == 0) {
+    int64_t o = 0;
+    for (int b = 0; b < B; ++b) {
+      h->in_off[b] = o;
+      o += len[b];
+    }
+    h->in_off[B] = o;
+    if (o > n_cap) {
+      atomicOr(status, LCR_STATUS_LEN_MISMATCH);
+      o = n_cap;
+    }
+    h->rx.n = o;
+    h->B = B;
+    h->n_cap = n_cap;
+    h->n_seg = 0;
+  }
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    h->M[b] = 0;
+    for (int d = 0; d < 3; ++d) {
+      h->bb_min[b][d] = 0xffffffffu;
+      h->bb_max[b][d] = 0u;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gs_bbox(GsHeader* h, const float* __restrict__ xyz) {
+  const int B = h->B;
+  const int64_t n = h->rx.n;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int b = cloud_of(h->in_off, B, i);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const uint32_t u = f2ord(xyz[3 * i + d]);
+      if (u < h->bb_min[b][d]) atomicMin(&h->bb_min[b][d], u);
+      if (u > h->bb_max[b][d]) atomicMax(&h->bb_max[b][d], u);
+    }
+  }
+}
+
+__device__ __forceinline__ int bits_of(uint64_t v) { return v ? 64 - __clzll(static_cast<long long>(v)) : 0; }
+
+__global__ void k_gs_params(GsHeader* h, float voxel, float inv_voxel, int key_bits_hint, uint32_t* status) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int B = h->B;
+  int kbits = 1;
+  for (int b = 0; b < B; ++b) {
+    if (h->in_off[b + 1] <= h->in_off[b]) {
+      h->NX[b] = h->NY[b] = 1;
+      continue;
+    }
+    float mn[3], mx[3];
+    for (int d = 0; d < 3; ++d) {
+      mn[d] = ord2f(h->bb_min[b][d]);
+      mx[d] = ord2f(h->bb_max[b][d]);
+      h->org[b][d] = fmul(floorf(fmul(mn[d], inv_voxel)), voxel);                 // grid_subsampling_cpu.cpp:11
+    }
+    const uint64_t NX = f2u64(fadd(floorf(fdiv(fsub(mx[0], h->org[b][0]), voxel)), 1.f));   // :13-16
+    const uint64_t NY = f2u64(fadd(floorf(fdiv(fsub(mx[1], h->org[b][1]), voxel)), 1.f));   // :17-20
+    const uint64_t NZ = f2u64(fadd(floorf(fdiv(fsub(mx[2], h->org[b][2]), voxel)), 1.f));
+    h->NX[b] = NX;
+    h->NY[b] = NY;
+    // largest key of this cloud (if the product overflows 64 bits the key is not sortable together with a cloud id)
+    const unsigned __int128 top = static_cast<unsigned __int128>(NX) * NY * NZ;
+    int kb = 64;
+    if ((top >> 64) == 0) kb = bits_of(static_cast<uint64_t>(top));
+    else kb = 65;
+    kbits = max(kbits, kb);
+  }
+  const int cbits = bits_of(static_cast<uint64_t>(B - 1));
+  int total = kbits + cbits;
+  if (total > 64 || (key_bits_hint > 0 && total > key_bits_hint)) {
+    atomicOr(status, LCR_STATUS_KEY_OVERFLOW);
+    total = min(total, 64);
+    if (key_bits_hint > 0) total = min(total, key_bits_hint);
+    kbits = max(total - cbits, 1);
+  }
+  h->kbits = kbits;
+  h->rx.num_passes = (total + 7) / 8;
+}
+
+__global__ __launch_bounds__(256) void k_gs_keys(GsHeader* h, const float* __restrict__ xyz, float voxel, uint64_t* __restrict__ keyA,
+                                                 uint32_t* __restrict__ valA, uint32_t* status) {
+  const int B = h->B;
+  const int64_t n = h->rx.n;
+  const int kbits = h->kbits;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int b = cloud_of(h->in_off, B, i);
+    const uint64_t ix = f2u64(floorf(fdiv(fsub(xyz[3 * i + 0], h->org[b][0]), voxel)));   // :32
+    const uint64_t iy = f2u64(floorf(fdiv(fsub(xyz[3 * i + 1], h->org[b][1]), voxel)));   // :33
+    const uint64_t iz = f2u64(floorf(fdiv(fsub(xyz[3 * i + 2], h->org[b][2]), voxel)));   // :34
+    const uint64_t key = ix + h->NX[b] * iy + h->NX[b] * h->NY[b] * iz;                    // :35 (wraps mod 2^64 like size_t)
+    if (kbits < 64 && (key >> kbits) != 0) atomicOr(status, LCR_STATUS_KEY_OVERFLOW);
+    keyA[i] = (kbits < 64 ? (static_cast<uint64_t>(b) << kbits) : 0ull) | key;
+    valA[i] = static_cast<uint32_t>(i);
+  }
+}
+
+__device__ __forceinline__ const uint64_t* sorted_keys(const GsHeader* h, const uint64_t* a, const uint64_t* b) {
+  return (h->rx.num_passes & 1) ? b : a;
+}
+__device__ __forceinline__ const uint32_t* sorted_vals(const GsHeader* h, const uint32_t* a, const uint32_t* b) {
+  return (h->rx.num_passes & 1) ? b : a;
+}
+
+__global__ __launch_bounds__(256) void k_gs_heads(const GsHeader* __restrict__ h, const uint64_t* __restrict__ kA,
+                                                  const uint64_t* __restrict__ kB, int32_t* __restrict__ head, int64_t n_cap) {
+  const int64_t n = h->rx.n;
+  const uint64_t* k = sorted_keys(h, kA, kB);
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i <= n_cap; i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    head[i] = (i < n && (i == 0 || k[i] != k[i - 1])) ? 1 : 0;
+}
+
+// one lane per voxel run: in-order fp32 sums (.h:17-20), barycentre = sum * float(1.0 / count) (:46)
+__global__ __launch_bounds__(256) void k_gs_reduce(GsHeader* h, const float* __restrict__ xyz, const uint64_t* __restrict__ kA,
+                                                   const uint64_t* __restrict__ kB, const uint32_t* __restrict__ vA,
+                                                   const uint32_t* __restrict__ vB, const int32_t* __restrict__ head_scan,
+                                                   float* __restrict__ bary, uint64_t* __restrict__ seg_key,
+                                                   uint32_t* __restrict__ seg_first, int32_t* __restrict__ first_flag) {
+  const int64_t n = h->rx.n;
+  const uint64_t* k = sorted_keys(h, kA, kB);
+  const uint32_t* v = sorted_vals(h, vA, vB);
+  const int kbits = h->kbits;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int seg = head_scan[i];
+    if (head_scan[i + 1] == seg) continue;   // not a run head (exclusive scan of the flags: head <=> next value differs)
+    const uint64_t key = k[i];
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    int cnt = 0;
+    int64_t j = i;
+    do {
+      const uint32_t r = v[j];
+      sx = fadd(sx, xyz[3 * r + 0]);
+      sy = fadd(sy, xyz[3 * r + 1]);
+      sz = fadd(sz, xyz[3 * r + 2]);
+      ++cnt;
+      ++j;
+    } while (j < n && k[j] == key);
+    const float rc = static_cast<float>(1.0 / static_cast<double>(cnt));
+    bary[3 * seg + 0] = fmul(sx, rc);
+    bary[3 * seg + 1] = fmul(sy, rc);
+    bary[3 * seg + 2] = fmul(sz, rc);
+    const int b = kbits < 64 ? static_cast<int>(key >> kbits) : 0;
+    seg_key[seg] = kbits < 64 ? (key & ((1ull << kbits) - 1ull)) : key;
+    const uint32_t f = v[i];   // stable sort => first element of the run is the first occurrence
+    seg_first[seg] = f;
+    first_flag[f] = 1;
+    atomicAdd(&h->M[b], 1);
+  }
+}
+
+__global__ void k_gs_offsets(GsHeader* h, int64_t* __restrict__ out_len) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int64_t o = 0;
+  for (int b = 0; b < h->B; ++b) {
+    h->out_off[b] = o;
+    out_len[b] = h->M[b];
+    o += h->M[b];
+  }
+  h->out_off[h->B] = o;
+  h->n_seg = o;
+}
+
+__global__ __launch_bounds__(256) void k_gs_insertion(const GsHeader* __restrict__ h, const int32_t* __restrict__ first_scan,
+                                                      const uint64_t* __restrict__ seg_key, const uint32_t* __restrict__ seg_first,
+                                                      uint64_t* __restrict__ ins_key, int32_t* __restrict__ ins_seg) {
+  const int64_t m = h->n_seg;
+  const int B = h->B;
+  for (int64_t s = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; s < m; s += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const uint32_t f = seg_first[s];
+    const int b = cloud_of(h->in_off, B, static_cast<int64_t>(f));
+    const int rank = first_scan[f] - first_scan[h->in_off[b]];   // insertion rank inside the cloud
+    const int64_t o = h->out_off[b] + rank;
+    ins_key[o] = seg_key[s];
+    ins_seg[o] = static_cast<int32_t>(s);
+  }
+}
+
+// ---- libstdc++ unordered_map iteration order, one workgroup per cloud -----------------------------------------------
+__device__ __forceinline__ int hm_block_excl_scan(int v, int* total, int* lds) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int inc = wave_incl_scan(v);
+  if (lane == 63) lds[w] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int k = 0; k < HM_T / 64; ++k) {
+    const int s = lds[k];
+    if (k < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+// exclusive scan of a[0..n) in place (block-wide, arbitrary n); reversed => scan from the top index downwards
+template <bool REVERSED>
+__device__ void hm_scan_inplace(int32_t* a, int n, int* lds) {
+  const int chunk = (n + HM_T - 1) / HM_T;
+  const int lo = threadIdx.x * chunk, hi = min(lo + chunk, n);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += a[REVERSED ? n - 1 - i : i];
+  int tot;
+  int run = hm_block_excl_scan(s, &tot, lds);
+  for (int i = lo; i < hi; ++i) {
+    const int idx = REVERSED ? n - 1 - i : i;
+    const int v = a[idx];
+    a[idx] = run;
+    run += v;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(HM_T) void k_gs_hashorder(const GsHeader* __restrict__ h, const uint64_t* __restrict__ ins_key,
+                                                       const int32_t* __restrict__ ins_seg, const float* __restrict__ bary,
+                                                       int32_t* __restrict__ hm_t, int32_t* __restrict__ hm_bk,
+                                                       int32_t* __restrict__ hm_mem, int32_t* __restrict__ hm_at,
+                                                       int32_t* __restrict__ hm_gmin, int32_t* __restrict__ hm_cnt,
+                                                       int32_t* __restrict__ hm_start, float* __restrict__ out_xyz) {
+  __shared__ int lds[HM_T / 64];
+  const int b = blockIdx.x;
+  const int n = h->M[b];
+  if (n <= 0) return;
+  const int64_t o = h->out_off[b];
+  const uint64_t* key = ins_key + o;
+  int32_t* t = hm_t + o;
+  int32_t* bk = hm_bk + o;
+  int32_t* mem = hm_mem + o;
+  int32_t* at = hm_at + o;
+  const int64_t bo = (h->in_off[b] * 9) / 4 + 64 * b;   // this cloud's slice of the bucket arrays
+  int32_t* gmin = hm_gmin + bo;
+  int32_t* cnt = hm_cnt + bo;
+  int32_t* start = hm_start + bo;
+  const int tid = threadIdx.x;
+
+  int lo = 0;
+  for (int p = 0; p < N_SCHED; ++p) {
+    const int64_t nb64 = c_sched[p];
+    const int hi = static_cast<int>(min(static_cast<int64_t>(n), nb64));
+    const int nb = static_cast<int>(min(nb64, static_cast<int64_t>(2147483647)));
+    // only buckets that can be hit matter, but all nb are scanned for the member offsets; nb <= 2.25 n + 64
+    for (int i = tid; i < nb; i += HM_T) {
+      gmin[i] = 0x7fffffff;
+      cnt[i] = 0;
+    }
+    for (int e = lo + tid; e < hi; e += HM_T) t[e] = e;   // new elements: timestamp = insertion rank
+    __syncthreads();
+    for (int e = tid; e < hi; e += HM_T) {
+      const int bb = static_cast<int>(key[e] % static_cast<uint64_t>(nb64));
+      bk[e] = bb;
+      atomicMin(&gmin[bb], t[e]);
+      atomicAdd(&cnt[bb], 1);
+      at[e] = 0;
+    }
+    __syncthreads();
+    // group sizes keyed by the group's creation time
+    for (int i = tid; i < nb; i += HM_T) {
+      const int c = cnt[i];
+      if (c > 0) at[gmin[i]] = c;
+      start[i] = c;
+    }
+    __syncthreads();
+    hm_scan_inplace<true>(at, hi, lds);     // at[tt] = number of elements in groups created AFTER time tt
+    hm_scan_inplace<false>(start, nb, lds);  // member-list offsets per bucket
+    for (int e = tid; e < hi; e += HM_T) {
+      const int bb = bk[e];
+      const int slot = start[bb] + atomicSub(&cnt[bb], 1) - 1;
+      mem[slot] = e;
+    }
+    __syncthreads();
+    for (int e = tid; e < hi; e += HM_T) {
+      const int bb = bk[e];
+      const int te = t[e];
+      const int s0 = start[bb];
+      const int s1 = (bb + 1 < nb) ? start[bb + 1] : hi;
+      int r = 0;
+      for (int s = s0; s < s1; ++s) r += t[mem[s]] > te;   // newer members of the bucket come first
+      bk[e] = at[gmin[bb]] + r;                              // position in the list after this phase
+    }
+    __syncthreads();
+    for (int e = tid; e < hi; e += HM_T) t[e] = bk[e];
+    __syncthreads();
+    lo = hi;
+    if (hi >= n) break;
+  }
+  // t[rank] = position in iteration order
+  for (int e = tid; e < n; e += HM_T) {
+    const int seg = ins_seg[o + e];
+    const int64_t dst = o + t[e];
+    out_xyz[3 * dst + 0] = bary[3 * seg + 0];
+    out_xyz[3 * dst + 1] = bary[3 * seg + 1];
+    out_xyz[3 * dst + 2] = bary[3 * seg + 2];
+  }
+}
+
+}  // namespace lcr
+
+using namespace lcr;
+
+extern "C" int lcr_grid_subsample_ws_bytes(int64_t n_cap, int B, size_t* bytes) {
+  if (!bytes || n_cap < 0 || B < 1 || B > GS_MAX_B) return LCR_EARG;
+  *bytes = gs_layout(nullptr, n_cap, B).bytes;
+  return LCR_OK;
+}
+
+extern "C" int lcr_grid_subsample_ex(const float* xyz, const int64_t* len, int B, int64_t n_cap, float voxel, int key_bits_hint,
+                                     float* out_xyz, int64_t* out_len, uint32_t* status, void* ws, size_t ws_bytes, void* stream) {
+  if (!len || !out_len || !status || !ws || B < 1 || B > GS_MAX_B || n_cap < 0 || !(voxel > 0.f) || key_bits_hint < 0 ||
+      key_bits_hint > 64) {
+    set_error("lcr_grid_subsample: bad argument");
+    return LCR_EARG;
+  }
+  if (n_cap > (int64_t(1) << 31) - 2) {
+    set_error("lcr_grid_subsample: more than 2^31-2 points");
+    return LCR_EARG;
+  }
+  GsLayout L = gs_layout(ws, n_cap, B);
+  if (L.bytes > ws_bytes) {
+    set_error("lcr_grid_subsample: workspace too small (%zu < %zu)", ws_bytes, L.bytes);
+    return LCR_ESPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const float inv_voxel = static_cast<float>(1.0 / static_cast<double>(voxel));   // `1. / voxel_size` narrowed by operator*(PointXYZ,float)
+  const int nblk = n_cap > 0 ? min(div_up(n_cap, 256), 2048) : 1;
+  hipLaunchKernelGGL(k_gs_init, dim3(1), dim3(64), 0, st, L.hdr, len, B, n_cap, status);
+  if (n_cap == 0) {
+    hipLaunchKernelGGL(k_gs_offsets, dim3(1), dim3(64), 0, st, L.hdr, out_len);
+    return check_launch("lcr_grid_subsample");
+  }
+  hipLaunchKernelGGL(k_gs_bbox, dim3(nblk), dim3(256), 0, st, L.hdr, xyz);
+  hipLaunchKernelGGL(k_gs_params, dim3(1), dim3(64), 0, st, L.hdr, voxel, inv_voxel, key_bits_hint, status);
+  hipLaunchKernelGGL(k_gs_keys, dim3(nblk), dim3(256), 0, st, L.hdr, xyz, voxel, L.keyA, L.valA, status);
+  const int max_passes = key_bits_hint > 0 ? (key_bits_hint + 7) / 8 : 8;
+  int rc = radix_sort_pairs(&L.hdr->rx, L.keyA, L.keyB, L.valA, L.valB, n_cap, max_passes, L.hist, L.scan_ws, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_gs_heads, dim3(nblk), dim3(256), 0, st, L.hdr, L.keyA, L.keyB, L.head, n_cap);
+  rc = exclusive_scan_i32(L.head, L.head, n_cap + 1, nullptr, L.scan_ws, st);
+  if (rc) return rc;
+  hipMemsetAsync(L.first, 0, sizeof(int32_t) * (n_cap + 1), st);
+  hipLaunchKernelGGL(k_gs_reduce, dim3(nblk), dim3(256), 0, st, L.hdr, xyz, L.keyA, L.keyB, L.valA, L.valB, L.head, L.bary, L.seg_key,
+                     L.seg_first, L.first);
+  rc = exclusive_scan_i32(L.first, L.first, n_cap + 1, nullptr, L.scan_ws, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_gs_offsets, dim3(1), dim3(64), 0, st, L.hdr, out_len);
+  hipLaunchKernelGGL(k_gs_insertion, dim3(nblk), dim3(256), 0, st, L.hdr, L.first, L.seg_key, L.seg_first, L.ins_key, L.ins_seg);
+  hipLaunchKernelGGL(k_gs_hashorder, dim3(B), dim3(HM_T), 0, st, L.hdr, L.ins_key, L.ins_seg, L.bary, L.hm_t, L.hm_bk, L.hm_mem, L.hm_at,
+                     L.hm_gmin, L.hm_cnt, L.hm_start, out_xyz);
+  return check_launch("lcr_grid_subsample");
+}
+
+extern "C" int lcr_grid_subsample(const float* xyz, const int64_t* len, int B, int64_t n_cap, float voxel, float* out_xyz,
+                                  int64_t* out_len, uint32_t* status, void* ws, size_t ws_bytes, void* stream) {
+  return lcr_grid_subsample_ex(xyz, len, B, n_cap, voxel, 0, out_xyz, out_len, status, ws, ws_bytes, stream);
+}
+
+// Host mirror of the phase algorithm of k_gs_hashorder (same steps, serial): order[j] = insertion rank of the j-th
+// element in std::unordered_map iteration order.  Lets the CPU-only test suite pin the algorithm against the real
+// container without a GPU; it is not used by the device path.
+extern "C" int lcr_hashmap_order_host(const uint64_t* keys, int64_t n, int64_t* order) {
+  if (n < 0 || (n > 0 && (!keys || !order))) return LCR_EARG;
+  if (n == 0) return LCR_OK;
+  std::vector<int64_t> t(n), pos(n), bk(n), mem(n);
+  int64_t lo = 0;
+  for (int p = 0; p < N_SCHED; ++p) {
+    const int64_t nb = h_sched[p];
+    const int64_t hi = n < nb ? n : nb;
+    for (int64_t e = lo; e < hi; ++e) t[e] = e;                       // new elements: timestamp = insertion rank
+    std::vector<int64_t> gmin(nb, INT64_MAX), cnt(nb, 0), start(nb + 1, 0), at(hi + 1, 0);
+    for (int64_t e = 0; e < hi; ++e) {
+      bk[e] = static_cast<int64_t>(keys[e] % static_cast<uint64_t>(nb));
+      if (t[e] < gmin[bk[e]]) gmin[bk[e]] = t[e];
+      cnt[bk[e]]++;
+    }
+    for (int64_t i = 0; i < nb; ++i)
+      if (cnt[i] > 0) at[gmin[i]] = cnt[i];
+    int64_t run = 0;
+    for (int64_t i = hi - 1; i >= 0; --i) {                            // reversed exclusive scan
+      const int64_t v = at[i];
+      at[i] = run;
+      run += v;
+    }
+    run = 0;
+    for (int64_t i = 0; i < nb; ++i) {                                 // member-list offsets
+      start[i] = run;
+      run += cnt[i];
+    }
+    start[nb] = run;
+    std::vector<int64_t> cur(start.begin(), start.end() - 1);
+    for (int64_t e = 0; e < hi; ++e) mem[cur[bk[e]]++] = e;
+    for (int64_t e = 0; e < hi; ++e) {
+      int64_t r = 0;
+      for (int64_t s0 = start[bk[e]]; s0 < start[bk[e] + 1]; ++s0) r += t[mem[s0]] > t[e];
+      pos[e] = at[gmin[bk[e]]] + r;
+    }
+    for (int64_t e = 0; e < hi; ++e) t[e] = pos[e];
+    lo = hi;
+    if (hi >= n) break;
+  }
+  for (int64_t e = 0; e < n; ++e) order[t[e]] = e;
+  return LCR_OK;
+}

@@ -1,0 +1,416 @@
+// radius_search.hip — a-2: stack-mode radius neighbour search for gfx950.
+//
+// Replaces utils.ext.radius_neighbors (utils/extensions/cpu/radius_neighbors/radius_neighbors_cpu.cpp:3-91; nanoflann
+// kd-tree, extra/nanoflann/nanoflann.hpp:1280-1289) and the [:, :limit] slice of modules/ops/radius_search.py:25-26.
+// Contract: same-cloud supports with d2 < r*r strictly, d2 = ((dx*dx)+dy*dy)+dz*dz in fp32 without FMA,
+// ascending by (d2, index) — the canonical order of cpp_wrappers/cpp_neighbors/neighbors/neighbors.cpp:125-208 —
+// global support index, rows padded with sum(slen).
+//
+// MI355X design (not a kd-tree): per call a uniform grid over every support cloud (cell >= radius, so the 27-cell
+// neighbourhood covers the ball), built with atomics + a device-wide scan into a cell-sorted float4 array (x,y,z,idx)
+// so that candidate loads are coalesced 16-B reads.  One 64-lane wavefront owns one query: the nine x-runs of the
+// neighbourhood are concatenated, lanes stride over the candidates, survivors are compacted into LDS with a
+// ballot/popcount wavefront scan, and the row is ordered by an all-pairs rank over the LDS keys
+// (key = d2 bits << 32 | index; n ~ 50 so n^2/64 work per lane beats a padded bitonic network).  Rows whose
+// in-radius count exceeds the LDS capacity fall back to a storage-free rank by re-enumeration (exact, slow, rare).
+// HBM-bound by its output rows (limit * 4 or 8 bytes per query); everything else stays in L2.
+#include "common.h"
+
+namespace lcr {
+
+constexpr int RS_CAP = 512;      // LDS keys per wavefront (8 B each)
+constexpr int RS_WAVES = 4;      // wavefronts (= queries in flight) per workgroup
+constexpr int GRID_MAX_B = 64;   // clouds per call
+constexpr int CELL_PER_PT = 32;  // cell budget = CELL_PER_PT * ns_cap + CELL_MIN * B
+constexpr int CELL_MIN = 4096;
+
+struct GridCloud {
+  double  org[3];
+  double  inv_cell;
+  int     dim[3];
+  int     cell_base;   // first cell of this cloud in the global cell arrays
+  int64_t s_start;     // first support row of this cloud
+};
+
+struct GridHeader {
+  int       B;
+  int       n_cells;     // cells in use (<= cell_cap)
+  int64_t   ns_total;    // sum(slen)
+  int64_t   ns_cap;
+  int64_t   cell_cap;
+  GridCloud cloud[GRID_MAX_B];
+  uint32_t  bb_min[GRID_MAX_B][3];   // order-preserving encodings
+  uint32_t  bb_max[GRID_MAX_B][3];
+  int64_t   s_off[GRID_MAX_B + 1];
+};
+
+struct GridLayout {
+  GridHeader* hdr;
+  int32_t*    cell_cnt;     // [cell_cap]   (zero before and after build)
+  int32_t*    cell_start;   // [cell_cap+1]
+  int32_t*    pt_cell;      // [ns_cap]
+  float4*     sorted;       // [ns_cap]  x,y,z,bits(idx global)
+  void*       scan_ws;
+  size_t      bytes;
+};
+
+static GridLayout grid_layout(void* ws, int64_t ns_cap, int B) {
+  GridLayout L;
+  Carver c(ws, ~size_t(0));
+  const int64_t cell_cap = CELL_PER_PT * ns_cap + static_cast<int64_t>(CELL_MIN) * B;
+  L.hdr = c.take<GridHeader>(1);
+  L.cell_cnt = c.take<int32_t>(cell_cap);
+  L.cell_start = c.take<int32_t>(cell_cap + 1);
+  L.pt_cell = c.take<int32_t>(ns_cap > 0 ? ns_cap : 1);
+  L.sorted = c.take<float4>(ns_cap > 0 ? ns_cap : 1);
+  L.scan_ws = c.take<char>(scan_ws_bytes(cell_cap + 1));
+  L.bytes = c.off;
+  return L;
+}
+
+// ---- build ---------------------------------------------------------------------------------------------------------
+__global__ void k_grid_init(GridHeader* h, const int64_t* __restrict__ slen, int B, int64_t ns_cap, int64_t cell_cap,
+                            uint32_t* status) {
+  if (threadIdx.x == 0) {
+    int64_t o = 0;
+    for (int b = 0; b < B; ++b) {
+      h->s_off[b] = o;
+      o += slen[b];
+    }
+    h->s_off[B] = o;
+    h->ns_total = o;
+    h->B = B;
+    h->ns_cap = ns_cap;
+    h->cell_cap = cell_cap;
+    if (o > ns_cap && status) atomicOr(status, LCR_STATUS_LEN_MISMATCH);
+  }
+  for (int b = threadIdx.x; b < B; b += blockDim.x)
+    for (int d = 0; d < 3; ++d) {
+      h->bb_min[b][d] = 0xffffffffu;
+      h->bb_max[b][d] = 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_grid_bbox(GridHeader* h, const float* __restrict__ s) {
+  const int B = h->B;
+  const int64_t n = min(h->ns_total, h->ns_cap);
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int b = cloud_of(h->s_off, B, i);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const uint32_t u = f2ord(s[3 * i + d]);
+      // cheap filter before the atomic: most points are not on the hull
+      if (u < h->bb_min[b][d]) atomicMin(&h->bb_min[b][d], u);
+      if (u > h->bb_max[b][d]) atomicMax(&h->bb_max[b][d], u);
+    }
+  }
+}
+
+__global__ void k_grid_params(GridHeader* h, float radius) {
+  // one thread: B is small; cell bases are a serial prefix anyway
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int B = h->B;
+  int base = 0;
+  for (int b = 0; b < B; ++b) {
+    GridCloud& c = h->cloud[b];
+    const int64_t nb = h->s_off[b + 1] - h->s_off[b];
+    c.s_start = h->s_off[b];
+    c.cell_base = base;
+    if (nb <= 0) {
+      c.dim[0] = c.dim[1] = c.dim[2] = 0;
+      c.inv_cell = 0.0;
+      c.org[0] = c.org[1] = c.org[2] = 0.0;
+      continue;
+    }
+    double lo[3], ext[3];
+    for (int d = 0; d < 3; ++d) {
+      lo[d] = static_cast<double>(ord2f(h->bb_min[b][d]));
+      ext[d] = static_cast<double>(ord2f(h->bb_max[b][d])) - lo[d];
+      c.org[d] = lo[d];
+    }
+    // cell >= radius * (1 + 1e-6): cell indices are computed in fp64, so |dx| < r implies |cell delta| <= 1
+    double cell = fmax(static_cast<double>(radius) * 1.000001, 1e-12);
+    const double budget = static_cast<double>(CELL_PER_PT) * static_cast<double>(nb) + CELL_MIN;
+    int dim[3];
+    for (int it = 0; it < 64; ++it) {
+      double tot = 1.0;
+      for (int d = 0; d < 3; ++d) {
+        double n = floor(ext[d] / cell) + 1.0;
+        dim[d] = n > 2.0e9 ? 2000000000 : static_cast<int>(n);
+        tot *= n;
+      }
+      if (tot <= budget) break;
+      cell *= fmax(cbrt(tot / budget), 1.0) * 1.02;
+    }
+    for (int d = 0; d < 3; ++d) c.dim[d] = dim[d];
+    c.inv_cell = 1.0 / cell;
+    base += dim[0] * dim[1] * dim[2];
+  }
+  h->n_cells = base;
+}
+
+__device__ __forceinline__ int cell_coord(double p, double org, double inv_cell, int dim) {
+  // clamp in floating point first: queries may lie far outside the support box
+  double c = floor((p - org) * inv_cell);
+  c = fmin(fmax(c, -2.0), static_cast<double>(dim) + 1.0);
+  return static_cast<int>(c);
+}
+
+__global__ __launch_bounds__(256) void k_grid_count(GridHeader* h, const float* __restrict__ s, int32_t* __restrict__ cell_cnt,
+                                                    int32_t* __restrict__ pt_cell) {
+  const int B = h->B;
+  const int64_t n = min(h->ns_total, h->ns_cap);
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int b = cloud_of(h->s_off, B, i);
+    const GridCloud& c = h->cloud[b];
+    int cx = cell_coord(s[3 * i + 0], c.org[0], c.inv_cell, c.dim[0]);
+    int cy = cell_coord(s[3 * i + 1], c.org[1], c.inv_cell, c.dim[1]);
+    int cz = cell_coord(s[3 * i + 2], c.org[2], c.inv_cell, c.dim[2]);
+    cx = min(max(cx, 0), c.dim[0] - 1);   // supports are inside the box by construction; guard rounding at the max face
+    cy = min(max(cy, 0), c.dim[1] - 1);
+    cz = min(max(cz, 0), c.dim[2] - 1);
+    const int cell = c.cell_base + (cz * c.dim[1] + cy) * c.dim[0] + cx;
+    pt_cell[i] = cell;
+    atomicAdd(&cell_cnt[cell], 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_grid_scatter(GridHeader* h, const float* __restrict__ s, int32_t* __restrict__ cell_cnt,
+                                                      const int32_t* __restrict__ cell_start, const int32_t* __restrict__ pt_cell,
+                                                      float4* __restrict__ sorted) {
+  const int64_t n = min(h->ns_total, h->ns_cap);
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int cell = pt_cell[i];
+    const int slot = cell_start[cell] + atomicSub(&cell_cnt[cell], 1) - 1;   // counts return to zero
+    sorted[slot] = make_float4(s[3 * i + 0], s[3 * i + 1], s[3 * i + 2], __uint_as_float(static_cast<uint32_t>(i)));
+  }
+}
+
+// ---- query ---------------------------------------------------------------------------------------------------------
+template <bool HAS64, bool HAS32>
+__global__ __launch_bounds__(RS_WAVES * 64) void k_radius_query(const float* __restrict__ q, const int64_t* __restrict__ qlen, int B,
+                                                                 int64_t nq_cap, const GridHeader* __restrict__ h,
+                                                                 const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
+                                                                 float r2, int limit, int64_t* __restrict__ out64,
+                                                                 int32_t* __restrict__ out32, int32_t* __restrict__ out_cnt) {
+  __shared__ uint64_t s_keys[RS_WAVES][RS_CAP];
+  __shared__ int s_run_a[RS_WAVES][12];     // first sorted slot of each x-run
+  __shared__ int s_run_p[RS_WAVES][12];     // exclusive prefix of run lengths
+  __shared__ int64_t s_qoff[GRID_MAX_B + 1];
+
+  if (threadIdx.x == 0) {
+    int64_t o = 0;
+    for (int b = 0; b < B; ++b) {
+      s_qoff[b] = o;
+      o += qlen[b];
+    }
+    s_qoff[B] = o;
+  }
+  __syncthreads();
+  const int64_t nq = min(s_qoff[B], nq_cap);
+  const int64_t ns_total = h->ns_total;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint64_t* keys = s_keys[w];
+
+  for (int64_t qi = static_cast<int64_t>(blockIdx.x) * RS_WAVES + w; qi < nq; qi += static_cast<int64_t>(gridDim.x) * RS_WAVES) {
+    const int b = cloud_of(s_qoff, B, qi);
+    const GridCloud& c = h->cloud[b];
+    const float qx = q[3 * qi + 0], qy = q[3 * qi + 1], qz = q[3 * qi + 2];
+
+    // nine x-runs (dy, dz in {-1,0,1}); lanes 0..8 own one run each
+    int len = 0, a = 0;
+    if (lane < 9 && c.dim[0] > 0) {
+      const int cx = cell_coord(qx, c.org[0], c.inv_cell, c.dim[0]);
+      const int cy = cell_coord(qy, c.org[1], c.inv_cell, c.dim[1]) + (lane % 3) - 1;
+      const int cz = cell_coord(qz, c.org[2], c.inv_cell, c.dim[2]) + (lane / 3) - 1;
+      const int x0 = max(cx - 1, 0), x1 = min(cx + 1, c.dim[0] - 1);
+      if (x0 <= x1 && cy >= 0 && cy < c.dim[1] && cz >= 0 && cz < c.dim[2]) {
+        const int row = c.cell_base + (cz * c.dim[1] + cy) * c.dim[0];
+        a = cell_start[row + x0];
+        len = cell_start[row + x1 + 1] - a;
+      }
+    }
+    const int incl = wave_incl_scan(len);
+    const int total = __shfl(incl, 8);
+    if (lane < 9) {
+      s_run_a[w][lane] = a;
+      s_run_p[w][lane] = incl - len;
+    }
+    // wave-private LDS: same-wave program order is enough, but keep the compiler honest
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    int p1 = s_run_p[w][1], p2 = s_run_p[w][2], p3 = s_run_p[w][3], p4 = s_run_p[w][4], p5 = s_run_p[w][5],
+        p6 = s_run_p[w][6], p7 = s_run_p[w][7], p8 = s_run_p[w][8];
+
+    auto candidate = [&](int t, float& d2, uint32_t& idx) {
+      const int r = (t >= p1) + (t >= p2) + (t >= p3) + (t >= p4) + (t >= p5) + (t >= p6) + (t >= p7) + (t >= p8);
+      const int slot = s_run_a[w][r] + (t - s_run_p[w][r]);
+      const float4 P = sorted[slot];
+      const float dx = fsub(qx, P.x), dy = fsub(qy, P.y), dz = fsub(qz, P.z);
+      d2 = fadd(fadd(fmul(dx, dx), fmul(dy, dy)), fmul(dz, dz));
+      idx = __float_as_uint(P.w);
+    };
+
+    int n = 0;
+    for (int t0 = 0; t0 < total; t0 += 64) {
+      const int t = t0 + lane;
+      float d2 = 0.f;
+      uint32_t idx = 0;
+      bool pass = false;
+      if (t < total) {
+        candidate(t, d2, idx);
+        pass = d2 < r2;
+      }
+      const uint64_t m = __ballot(pass);
+      const int off = n + __popcll(m & lanemask_lt());
+      if (pass && off < RS_CAP) keys[off] = (static_cast<uint64_t>(__float_as_uint(d2)) << 32) | idx;
+      n += __popcll(m);
+    }
+    if (out_cnt) {
+      if (lane == 0) out_cnt[qi] = n;
+    }
+    if (limit <= 0) continue;
+
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    int64_t* row64 = HAS64 ? out64 + qi * static_cast<int64_t>(limit) : nullptr;
+    int32_t* row32 = HAS32 ? out32 + qi * static_cast<int64_t>(limit) : nullptr;
+
+    if (n <= RS_CAP) {
+      // all-pairs rank over the LDS keys (keys are unique: the index is part of the key)
+      for (int e = lane; e < n; e += 64) {
+        const uint64_t k = keys[e];
+        int rank = 0;
+        int j = 0;
+        for (; j + 4 <= n; j += 4) {
+          rank += (keys[j] < k) + (keys[j + 1] < k) + (keys[j + 2] < k) + (keys[j + 3] < k);
+        }
+        for (; j < n; ++j) rank += keys[j] < k;
+        if (rank < limit) {
+          const int64_t v = static_cast<int64_t>(static_cast<uint32_t>(k));
+          if (HAS64) row64[rank] = v;
+          if (HAS32) row32[rank] = static_cast<int32_t>(v);
+        }
+      }
+    } else {
+      // exact fallback without storage: rank every in-radius candidate by re-enumerating the runs
+      for (int t0 = 0; t0 < total; t0 += 64) {
+        const int t = t0 + lane;
+        float d2 = 0.f;
+        uint32_t idx = 0;
+        bool pass = false;
+        if (t < total) {
+          candidate(t, d2, idx);
+          pass = d2 < r2;
+        }
+        const uint64_t k = (static_cast<uint64_t>(__float_as_uint(d2)) << 32) | idx;
+        int rank = 0;
+        for (int u = 0; u < total; ++u) {   // u is wave-uniform: one broadcast load per step
+          float e2;
+          uint32_t eidx;
+          candidate(u, e2, eidx);
+          const uint64_t ek = (static_cast<uint64_t>(__float_as_uint(e2)) << 32) | eidx;
+          rank += (e2 < r2) && (ek < k);
+        }
+        if (pass && rank < limit) {
+          if (HAS64) row64[rank] = static_cast<int64_t>(idx);
+          if (HAS32) row32[rank] = static_cast<int32_t>(idx);
+        }
+      }
+    }
+    for (int col = n + lane; col < limit; col += 64) {
+      if (HAS64) row64[col] = ns_total;
+      if (HAS32) row32[col] = static_cast<int32_t>(ns_total);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+}  // namespace lcr
+
+using namespace lcr;
+
+extern "C" int lcr_support_grid_ws_bytes(int64_t ns_cap, int B, size_t* bytes) {
+  if (!bytes || ns_cap < 0 || B < 1 || B > GRID_MAX_B) return LCR_EARG;
+  *bytes = grid_layout(nullptr, ns_cap, B).bytes;
+  return LCR_OK;
+}
+
+extern "C" int lcr_support_grid_build(const float* s, const int64_t* slen, int B, int64_t ns_cap, float radius, uint32_t* status,
+                                      void* grid_ws, size_t grid_ws_bytes, void* stream) {
+  if (!slen || !grid_ws || B < 1 || B > GRID_MAX_B || ns_cap < 0 || !(radius > 0.f)) {
+    set_error("lcr_support_grid_build: bad argument");
+    return LCR_EARG;
+  }
+  if (ns_cap > (int64_t(1) << 31) - 1) {
+    set_error("lcr_support_grid_build: more than 2^31-1 support points");
+    return LCR_EARG;
+  }
+  GridLayout L = grid_layout(grid_ws, ns_cap, B);
+  if (L.bytes > grid_ws_bytes) {
+    set_error("lcr_support_grid_build: workspace too small (%zu < %zu)", grid_ws_bytes, L.bytes);
+    return LCR_ESPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t cell_cap = CELL_PER_PT * ns_cap + static_cast<int64_t>(CELL_MIN) * B;
+  hipMemsetAsync(L.cell_cnt, 0, sizeof(int32_t) * cell_cap, st);
+  hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, st, L.hdr, slen, B, ns_cap, cell_cap, status);
+  const int nblk = ns_cap > 0 ? min(div_up(ns_cap, 256), 2048) : 1;
+  hipLaunchKernelGGL(k_grid_bbox, dim3(nblk), dim3(256), 0, st, L.hdr, s);
+  hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(64), 0, st, L.hdr, radius);
+  hipLaunchKernelGGL(k_grid_count, dim3(nblk), dim3(256), 0, st, L.hdr, s, L.cell_cnt, L.pt_cell);
+  int rc = exclusive_scan_i32(L.cell_cnt, L.cell_start, cell_cap + 1, nullptr, L.scan_ws, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_grid_scatter, dim3(nblk), dim3(256), 0, st, L.hdr, s, L.cell_cnt, L.cell_start, L.pt_cell, L.sorted);
+  return check_launch("lcr_support_grid_build");
+}
+
+extern "C" int lcr_radius_query(const float* q, const int64_t* qlen, int B, int64_t nq_cap, const void* grid_ws, int64_t ns_cap,
+                                float radius, int limit, int64_t* out_idx64, int32_t* out_idx32, int32_t* out_cnt, void* stream) {
+  if (!qlen || !grid_ws || B < 1 || B > GRID_MAX_B || nq_cap < 0 || ns_cap < 0 || limit < 0 || !(radius > 0.f)) {
+    set_error("lcr_radius_query: bad argument");
+    return LCR_EARG;
+  }
+  if (limit == 0 && !out_cnt) {
+    set_error("lcr_radius_query: limit == 0 needs out_cnt");
+    return LCR_EARG;
+  }
+  if (limit > 0 && !out_idx64 && !out_idx32) {
+    set_error("lcr_radius_query: limit > 0 needs an index output");
+    return LCR_EARG;
+  }
+  if (nq_cap == 0) return LCR_OK;
+  GridLayout L = grid_layout(const_cast<void*>(grid_ws), ns_cap, B);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const float r2 = radius * radius;   // fp32 product, as radius_neighbors_cpu.cpp:12
+  const int nblk = min(div_up(nq_cap, RS_WAVES), 256 * 8 * 4);
+  const dim3 grid(nblk), block(RS_WAVES * 64);
+  if (out_idx64 && out_idx32)
+    hipLaunchKernelGGL((k_radius_query<true, true>), grid, block, 0, st, q, qlen, B, nq_cap, L.hdr, L.cell_start, L.sorted, r2, limit,
+                       out_idx64, out_idx32, out_cnt);
+  else if (out_idx64)
+    hipLaunchKernelGGL((k_radius_query<true, false>), grid, block, 0, st, q, qlen, B, nq_cap, L.hdr, L.cell_start, L.sorted, r2, limit,
+                       out_idx64, out_idx32, out_cnt);
+  else
+    hipLaunchKernelGGL((k_radius_query<false, true>), grid, block, 0, st, q, qlen, B, nq_cap, L.hdr, L.cell_start, L.sorted, r2, limit,
+                       out_idx64, out_idx32, out_cnt);
+  return check_launch("lcr_radius_query");
+}
+
+extern "C" int lcr_radius_search_ws_bytes(int64_t nq_cap, int64_t ns_cap, int B, size_t* bytes) {
+  (void)nq_cap;
+  return lcr_support_grid_ws_bytes(ns_cap, B, bytes);
+}
+
+extern "C" int lcr_radius_search(const float* q, const float* s, const int64_t* qlen, const int64_t* slen, int B, int64_t nq_cap,
+                                 int64_t ns_cap, float radius, int limit, int64_t* out_idx64, int32_t* out_idx32, int32_t* out_cnt,
+                                 uint32_t* status, void* ws, size_t ws_bytes, void* stream) {
+  int rc = lcr_support_grid_build(s, slen, B, ns_cap, radius, status, ws, ws_bytes, stream);
+  if (rc) return rc;
+  return lcr_radius_query(q, qlen, B, nq_cap, ws, ns_cap, radius, limit, out_idx64, out_idx32, out_cnt, stream);
+}

@@ -1,0 +1,47 @@
+"""grid_subsample — drop-in for experiments/lcrnet/modules/ops/grid_subsample.py:7-22 on the GPU.
+
+Reference: ``ext.grid_subsampling(points, lengths, voxel_size) -> (s_points, s_lengths)``
+(utils/extensions/cpu/grid_subsampling/grid_subsampling.cpp:5-62).  Bit-exact, including the output order.
+"""
+import ctypes
+
+import torch
+
+from ... import _lib
+
+
+def grid_subsample_device(points, lengths, voxel_size):
+    """Sync-free form: returns (out_xyz [N,3] capacity buffer, out_len i64[B] on device, status)."""
+    _lib.require_cuda(points)
+    if points.dtype != torch.float32:
+        raise RuntimeError("points must be a float tensor")
+    if lengths.dtype != torch.int64:
+        raise RuntimeError("lengths must be an long tensor")
+    if not points.is_contiguous():
+        raise RuntimeError("points must be contiguous")
+    if not lengths.is_contiguous():
+        raise RuntimeError("lengths must be contiguous")
+    dev = points.device
+    lengths = lengths.to(dev, non_blocking=True)
+    B, n = lengths.numel(), points.shape[0]
+    L = _lib.lib()
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(L.lcr_grid_subsample_ws_bytes(n, B, ctypes.byref(nbytes)), "lcr_grid_subsample_ws_bytes")
+    ws = _lib.workspace(nbytes.value, dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    out = torch.empty((max(n, 1), 3), dtype=torch.float32, device=dev)
+    out_len = torch.empty((B,), dtype=torch.int64, device=dev)
+    _lib.check(L.lcr_grid_subsample(_lib.ptr(points), _lib.ptr(lengths), B, n, float(voxel_size), _lib.ptr(out),
+                                    _lib.ptr(out_len), _lib.ptr(status), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
+               "lcr_grid_subsample")
+    return out, out_len, status
+
+
+def grid_subsample(points, lengths, voxel_size):
+    """Grid subsampling in stack mode (GPU).  Returns (s_points (M,3), s_lengths (B,)) like the reference."""
+    out, out_len, status = grid_subsample_device(points, lengths, voxel_size)
+    m = int(out_len.sum().item())   # host sync: the output shape is data dependent
+    st = int(status.item())
+    if st:
+        raise RuntimeError("lcr_grid_subsample: device status 0x%x (voxel key overflow / length mismatch)" % st)
+    return out[:m], out_len

@@ -1,0 +1,71 @@
+"""radius_search — drop-in for experiments/lcrnet/modules/ops/radius_search.py:7-27 on the GPU.
+
+Reference: ``ext.radius_neighbors(q, s, q_lengths, s_lengths, radius)`` then ``[:, :neighbor_limit]`` (a
+non-contiguous view; here the result is always contiguous).  Checks mirror the TORCH_CHECKs of
+utils/extensions/cpu/radius_neighbors/radius_neighbors.cpp:12-23 (dtype / contiguity), with "CUDA" for "CPU".
+"""
+import ctypes
+
+import torch
+
+from ... import _lib
+
+
+def _check(q_points, s_points, q_lengths, s_lengths):
+    _lib.require_cuda(q_points, s_points)
+    for name, t in (("q_points", q_points), ("s_points", s_points)):
+        if t.dtype != torch.float32:
+            raise RuntimeError("%s must be a float tensor" % name)
+        if not t.is_contiguous():
+            raise RuntimeError("%s must be contiguous" % name)
+    for name, t in (("q_lengths", q_lengths), ("s_lengths", s_lengths)):
+        if t.dtype != torch.int64:
+            raise RuntimeError("%s must be an long tensor" % name)
+        if not t.is_contiguous():
+            raise RuntimeError("%s must be contiguous" % name)
+    if q_lengths.numel() != s_lengths.numel():
+        raise RuntimeError("q_lengths and s_lengths must have the same batch size")
+
+
+def _call(q_points, s_points, q_lengths, s_lengths, radius, limit, want64, want32, want_cnt):
+    dev = q_points.device
+    q_lengths = q_lengths.to(dev, non_blocking=True)
+    s_lengths = s_lengths.to(dev, non_blocking=True)
+    B = q_lengths.numel()
+    nq, ns = q_points.shape[0], s_points.shape[0]
+    L = _lib.lib()
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(L.lcr_radius_search_ws_bytes(nq, ns, B, ctypes.byref(nbytes)), "lcr_radius_search_ws_bytes")
+    ws = _lib.workspace(nbytes.value, dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    out64 = torch.empty((nq, limit), dtype=torch.int64, device=dev) if (want64 and limit > 0) else None
+    out32 = torch.empty((nq, limit), dtype=torch.int32, device=dev) if (want32 and limit > 0) else None
+    cnt = torch.empty((nq,), dtype=torch.int32, device=dev) if want_cnt else None
+    _lib.check(L.lcr_radius_search(_lib.ptr(q_points), _lib.ptr(s_points), _lib.ptr(q_lengths), _lib.ptr(s_lengths), B,
+                                   nq, ns, float(radius), int(limit), _lib.ptr(out64), _lib.ptr(out32), _lib.ptr(cnt),
+                                   _lib.ptr(status), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "lcr_radius_search")
+    return out64, out32, cnt, status
+
+
+def radius_count(q_points, s_points, q_lengths, s_lengths, radius):
+    """int32 [Nq] uncapped in-radius counts (all that calibrate_neighbors_stack_mode needs, data.py:423)."""
+    _check(q_points, s_points, q_lengths, s_lengths)
+    return _call(q_points, s_points, q_lengths, s_lengths, radius, 0, False, False, True)[2]
+
+
+def radius_search(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, dtype=torch.int64):
+    r"""Neighbours of ``q_points`` in ``s_points`` within ``radius`` (stack mode), on the GPU.
+
+    Returns LongTensor (N, k): k = neighbor_limit if > 0, else the maximum in-radius count (reference width).
+    Rows are ascending in (d², index) and padded with M = s_points.shape[0].
+    """
+    _check(q_points, s_points, q_lengths, s_lengths)
+    limit = int(neighbor_limit)
+    if limit <= 0:
+        cnt = radius_count(q_points, s_points, q_lengths, s_lengths, radius)
+        limit = int(cnt.max().item()) if cnt.numel() else 0   # host sync: output width is data dependent
+        if limit == 0:
+            return torch.empty((q_points.shape[0], 0), dtype=dtype, device=q_points.device)
+    want64 = dtype == torch.int64
+    out64, out32, _, _ = _call(q_points, s_points, q_lengths, s_lengths, radius, limit, want64, not want64, False)
+    return out64 if want64 else out32

@@ -97,6 +97,18 @@ int64_t oracle_grid_subsample(const float* xyz, const int64_t* len, int B, float
   return out_off;
 }
 
+// Iteration order of std::unordered_map<size_t,...> after inserting n DISTINCT keys in the given order:
+// order[j] = insertion rank (0-based) of the j-th element visited.  This is the libstdc++ behaviour the
+// reference's output order depends on (grid_subsampling_cpu.cpp:26,45-47); used to unit-test the product's
+// explicit emulation of it.
+int64_t oracle_hashmap_order(const uint64_t* keys, int64_t n, int64_t* order) {
+  std::unordered_map<size_t, int64_t> m;
+  for (int64_t i = 0; i < n; ++i) m.emplace(static_cast<size_t>(keys[i]), i);
+  int64_t j = 0;
+  for (auto& kv : m) order[j++] = kv.second;
+  return j;
+}
+
 // Per-row in-radius counts (uncapped).  Returns the maximum count (= the reference's output width).
 // d2 = ((0 + dx*dx) + dy*dy) + dz*dz in fp32, strict d2 < r*r, same-cloud supports only.
 int64_t oracle_radius_count(const float* q, const float* s, const int64_t* qlen, const int64_t* slen,

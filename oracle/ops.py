@@ -46,6 +46,8 @@ def lib():
         L.oracle_radius_search.restype = ctypes.c_int
         L.oracle_radius_search.argtypes = [_f32p, _f32p, _i64p, _i64p, ctypes.c_int, ctypes.c_float,
                                            ctypes.c_int64, _i64p, _i32p]
+        L.oracle_hashmap_order.restype = ctypes.c_int64
+        L.oracle_hashmap_order.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int64, _i64p]
         _lib = L
     return _lib
 
@@ -85,6 +87,16 @@ def grid_subsample(points, lengths, voxel_size, impl="oracle"):
     fn = lib().oracle_grid_subsample if impl == "oracle" else ref().ref_grid_subsample
     m = fn(pp, lp, len(lengths), ctypes.c_float(voxel_size), out.ctypes.data_as(_f32p), out_len.ctypes.data_as(_i64p))
     return out[:m].copy(), out_len
+
+
+def hashmap_order(keys):
+    """order[j] = insertion rank of the j-th element in std::unordered_map iteration order (distinct keys)."""
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    order = np.empty(keys.shape[0], dtype=np.int64)
+    n = lib().oracle_hashmap_order(keys.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), keys.shape[0],
+                                   order.ctypes.data_as(_i64p))
+    assert n == keys.shape[0], "keys must be distinct"
+    return order
 
 
 def radius_count(q_points, s_points, q_lengths, s_lengths, radius):

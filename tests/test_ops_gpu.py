@@ -1,0 +1,126 @@
+"""GPU parity tests for the native ops, through the C ABI (ctypes): HIP path vs the oracle and vs the golden digests
+generated from the compiled reference.  Bit-exact: stage points (fp32 bit patterns, order included), neighbour indices."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import DEMO_SCANS, LIMITS, NUM_STAGES, RADIUS, VOXEL, load_scan, search_specs, sha
+from oracle import ops as oracle_ops
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def test_fp32_div_floor_exact():
+    """The voxel index arithmetic relies on IEEE fp32 subtract/divide on the device."""
+    from lcrnet_amd.modules.ops import grid_subsample
+    rng = np.random.default_rng(0)
+    xyz = (rng.standard_normal((200000, 3)) * 40).astype(np.float32)
+    lens = np.array([len(xyz)], dtype=np.int64)
+    for v in (0.3, 0.123, 1.7):
+        want, wl = oracle_ops.grid_subsample(xyz, lens, v)
+        got, gl = grid_subsample(dev(xyz), dev(lens), v)
+        assert np.array_equal(gl.cpu().numpy(), wl)
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("name", DEMO_SCANS + ["syn0", "syn1"])
+def test_precompute_stages_bit_exact(name, ops_golden):
+    from lcrnet_amd.modules.ops import grid_subsample, radius_search, radius_count
+    xyz = load_scan(name)
+    lens = np.array([len(xyz)], dtype=np.int64)
+    pts, ls = [dev(xyz)], [dev(lens)]
+    v = VOXEL
+    for i in range(1, NUM_STAGES):
+        v *= 2
+        p, l = grid_subsample(pts[-1], ls[-1], v)
+        pts.append(p.contiguous())
+        ls.append(l)
+    for i in range(NUM_STAGES):
+        assert sha(pts[i].cpu().numpy()) == str(ops_golden[f"{name}/points{i}_sha"]), f"stage {i}"
+        assert np.array_equal(ls[i].cpu().numpy(), ops_golden[f"{name}/lengths{i}"])
+    for sname, q, s, ql, sl, r, lim in search_specs(pts, ls):
+        k = f"{name}/{sname}"
+        out = radius_search(q, s, ql, sl, r, lim)
+        assert out.dtype == torch.int64 and out.is_contiguous()
+        assert sha(out.cpu().numpy()) == str(ops_golden[k + "_sha_canon"]), k
+        cnt = radius_count(q, s, ql, sl, r)
+        assert sha(cnt.cpu().numpy()) == str(ops_golden[k + "_counts_sha"]), k
+        o32 = radius_search(q, s, ql, sl, r, lim, dtype=torch.int32)
+        assert torch.equal(o32.long(), out)
+
+
+def test_pair_stack_and_uncapped_width(ops_golden):
+    from lcrnet_amd.modules.ops import grid_subsample, radius_search
+    a, b = load_scan("003854"), load_scan("000958")
+    xyz = np.concatenate([a, b])
+    lens = np.array([len(a), len(b)], dtype=np.int64)
+    p1, l1 = grid_subsample(dev(xyz), dev(lens), 0.6)
+    assert sha(p1.cpu().numpy()) == str(ops_golden["pair_003854_000958/points1_sha"])
+    out = radius_search(dev(xyz), dev(xyz), dev(lens), dev(lens), RADIUS, LIMITS[0])
+    assert sha(out.cpu().numpy()) == str(ops_golden["pair_003854_000958/neighbors0_sha_canon"])
+    full = radius_search(p1.contiguous(), dev(xyz), l1, dev(lens), RADIUS, -1)        # reference semantics: width = max count
+    assert full.shape[1] == int(ops_golden["pair_003854_000958/subsampling0_max_count"])
+    want = oracle_ops.radius_search(p1.cpu().numpy(), xyz, l1.cpu().numpy(), lens, RADIUS, -1)
+    assert np.array_equal(full.cpu().numpy(), want)
+
+
+def test_ragged_and_empty_clouds():
+    from lcrnet_amd.modules.ops import grid_subsample, radius_search
+    rng = np.random.default_rng(5)
+    xyz = (rng.random((5000, 3)) * np.array([30, 30, 4])).astype(np.float32)
+    lens = np.array([1, 0, 2999, 2000], dtype=np.int64)              # single-point cloud, empty cloud
+    want_p, want_l = oracle_ops.grid_subsample(xyz, lens, 0.8)
+    got_p, got_l = grid_subsample(dev(xyz), dev(lens), 0.8)
+    assert np.array_equal(got_l.cpu().numpy(), want_l)
+    assert np.array_equal(got_p.cpu().numpy().view(np.uint32), want_p.view(np.uint32))
+    want = oracle_ops.radius_search(want_p, xyz, want_l, lens, 2.0, 30)
+    got = radius_search(got_p.contiguous(), dev(xyz), got_l, dev(lens), 2.0, 30)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_dense_ball_exceeds_lds_capacity():
+    """More than 512 in-radius supports per query: exercises the storage-free fallback ranking."""
+    from lcrnet_amd.modules.ops import radius_search
+    rng = np.random.default_rng(9)
+    s = (rng.standard_normal((3000, 3)) * 0.4).astype(np.float32)
+    q = s[:200].copy()
+    ql, sl = np.array([200]), np.array([3000])
+    want, cnt = oracle_ops.radius_search(q, s, ql, sl, 1.0, 100, return_counts=True)
+    assert cnt.max() > 512
+    got = radius_search(dev(q), dev(s), dev(ql), dev(sl), 1.0, 100)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_exact_ties_order_by_index():
+    from lcrnet_amd.modules.ops import radius_search
+    # lattice points: many exactly equal distances -> order must be (d2, idx)
+    g = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(6), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    rng = np.random.default_rng(2)
+    g = g[rng.permutation(len(g))]
+    n = np.array([len(g)])
+    want = oracle_ops.radius_search(g, g, n, n, 2.5, 40)
+    got = radius_search(dev(g), dev(g), dev(n), dev(n), 2.5, 40)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_raw_scan_voxel03(ops_golden):
+    """BASELINE configs[1] front end: raw ~120k-pt synthetic scans -> 0.3 m voxels, batch of 2 stacked."""
+    import lcrnet_amd.synthetic as synthetic
+    from lcrnet_amd.modules.ops import grid_subsample
+    raws = [synthetic.synthetic_scan(s) for s in (0, 1)]
+    assert sha(raws[0]) == str(ops_golden["syn0/raw_sha"])
+    xyz = np.concatenate(raws)
+    lens = np.array([len(r) for r in raws], dtype=np.int64)
+    got, gl = grid_subsample(dev(xyz), dev(lens), VOXEL)
+    got = got.cpu().numpy()
+    n0 = int(ops_golden["syn0/voxel03_n"])
+    assert gl.cpu().tolist() == [n0, int(ops_golden["syn1/voxel03_n"])]
+    assert sha(got[:n0]) == str(ops_golden["syn0/voxel03_sha"])
+    assert sha(got[n0:]) == str(ops_golden["syn1/voxel03_sha"])
