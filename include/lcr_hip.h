@@ -82,6 +82,56 @@ int lcr_radius_search(const float* q, const float* s, const int64_t* qlen, const
                       int64_t* out_idx64, int32_t* out_idx32, int32_t* out_cnt, uint32_t* status,
                       void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * a-4 / a-5 / a-6  KPConv encoder building blocks (fp32).  Index tensors are [M,H] int32 or int64 (idx_is_64),
+ * padded with Ns like the reference's neighbour lists; feature tensors are row-major [N,C].
+ * ------------------------------------------------------------------------------------------------ */
+/* C = A·B on the fp32 matrix cores with fused epilogue: C[m][:] = (A·B)[m][:] / rowdiv[m] + bias, and per-(segment,group)
+ * sum / sum-of-squares of C accumulated into stats[S,groups,2] (fp64) for the GroupNorm that follows.
+ * transA: A is stored [K,M]; transB: B is stored [N,K] (nn.Linear weight).  Replaces F.linear + the (15,C,Cout)
+ * contraction of KPConv.forward (modules/kpconv/kpconv.py:108-116) and torch.matmul in NetVlad.py:56,68. */
+int lcr_gemm_f32(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB,
+                 const float* bias, const float* rowdiv, const int64_t* seg_len, int S, int groups, double* stats,
+                 void* stream);
+/* Gather + kernel-point influences + weighted aggregation of KPConv.forward (kpconv.py:91-105): A[m][k*C+c] =
+ * sum_h max(0, 1-|s[idx[m,h]]-q[m]-kp[k]|/sigma) * s_feats[idx[m,h]][c];  nn[m] = max(1, #neighbours with s_pos != 0)
+ * (kpconv.py:113-116).  kernel_points_host: 15x3 floats in HOST memory.  C in {32,64,128,256}, H <= 128. */
+int lcr_kpconv_aggregate(const float* s_feats, const uint8_t* s_pos, const float* q_pts, const float* s_pts,
+                         const void* idx, int idx_is_64, int64_t M, int64_t Ns, int H, int C,
+                         const float* kernel_points_host, float sigma, float* A, float* nn, void* stream);
+/* Whole KPConv for C_in = 1 (encoder1_1, backbone4.py:15): out[M,Cout] incl. count normalisation and bias. W: [15,Cout]. */
+int lcr_kpconv_cin1(const float* s_feats, const float* q_pts, const float* s_pts, const void* idx, int idx_is_64,
+                    int64_t M, int64_t Ns, int H, const float* kernel_points_host, float sigma, const float* W,
+                    const float* bias, int Cout, float* out, void* stream);
+/* maxpool over neighbours, zero shadow row (modules/kpconv/functional.py:54-67). */
+int lcr_maxpool(const float* x, const void* idx, int idx_is_64, int64_t M, int64_t Ns, int H, int C, float* out, void* stream);
+/* pos[n] = (sum_c x[n][c] > 0) — the flag behind KPConv's neighbour count. */
+int lcr_row_positive(const float* x, int64_t N, int C, uint8_t* pos, void* stream);
+/* Segmented GroupNorm statistics (sum, sumsq per segment and group, fp64) of x[N,C]; seg_len i64[S] on the device. */
+int lcr_groupnorm_stats(const float* x, int64_t N, int C, int groups, const int64_t* seg_len, int S, double* stats, void* stream);
+/* y = act( GN(x; stats,gamma,beta) [+ res | + GN(res; res_stats,res_gamma,res_beta)] ), act = LeakyReLU(slope) if act != 0
+ * (modules/kpconv/modules.py:33-50, 78-84, 207-225).  Optional pos[n] = (sum_c y[n][c] > 0). */
+int lcr_groupnorm_apply(const float* x, const double* stats, const float* gamma, const float* beta, const float* res,
+                        const double* res_stats, const float* res_gamma, const float* res_beta, float* y, int64_t N, int C,
+                        int groups, const int64_t* seg_len, int S, float eps, float slope, int act, uint8_t* pos, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a-7  global descriptor head: F.normalize -> NetVLADLoupe2 -> GatingContext -> F.normalize
+ *      (model_family/LCRNet_GlobalDescrition.py:34-38, modules/netvlad/NetVlad.py:49-87, 165-201), S scans per call.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct LcrNetvladWeights {   /* device pointers; reference parameter names `netvlad.*` */
+  const float* cluster_weights;      /* (1024, 64) */
+  const float* cluster_weights2;     /* (1, 1024, 64) */
+  const float* hidden1_weights;      /* (65536, 256) */
+  const float *bn1_w, *bn1_b, *bn1_mean, *bn1_var;
+  const float *bn2_w, *bn2_b, *bn2_mean, *bn2_var;
+  const float* gating_weights;       /* (256, 256) */
+  const float *gbn_w, *gbn_b, *gbn_mean, *gbn_var;
+} LcrNetvladWeights;
+int lcr_netvlad_ws_bytes(int64_t n_rows, int S, size_t* bytes);
+int lcr_netvlad_forward(const float* feats /*[sum(seg_len),1024]*/, const int64_t* seg_len_host, int S,
+                        const LcrNetvladWeights* weights_host, float* out /*[S,256]*/, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,40 @@
+"""KPEncoder — experiments/lcrnet/backbone4.py:11-89 (4 stages / 11 blocks), same attribute names => same checkpoint keys."""
+import torch.nn as nn
+
+from .modules.kpconv import ConvBlock, ResidualBlock, StageContext
+
+
+class KPEncoder(nn.Module):
+    def __init__(self, input_dim, init_dim, kernel_size, init_radius, init_sigma, group_norm):
+        super().__init__()
+        d, k, r, s, g = init_dim, kernel_size, init_radius, init_sigma, group_norm
+        self.encoder1_1 = ConvBlock(input_dim, d, k, r, s, g)
+        self.encoder1_2 = ResidualBlock(d, d * 2, k, r, s, g)
+        self.encoder2_1 = ResidualBlock(d * 2, d * 2, k, r, s, g, strided=True)
+        self.encoder2_2 = ResidualBlock(d * 2, d * 4, k, r * 2, s * 2, g)
+        self.encoder2_3 = ResidualBlock(d * 4, d * 4, k, r * 2, s * 2, g)
+        self.encoder3_1 = ResidualBlock(d * 4, d * 4, k, r * 2, s * 2, g, strided=True)
+        self.encoder3_2 = ResidualBlock(d * 4, d * 8, k, r * 4, s * 4, g)
+        self.encoder3_3 = ResidualBlock(d * 8, d * 8, k, r * 4, s * 4, g)
+        self.encoder4_1 = ResidualBlock(d * 8, d * 8, k, r * 4, s * 4, g, strided=True)
+        self.encoder4_2 = ResidualBlock(d * 8, d * 16, k, r * 8, s * 8, g)
+        self.encoder4_3 = ResidualBlock(d * 16, d * 16, k, r * 8, s * 8, g)
+
+    def forward(self, feats, data_dict):
+        """data_dict: 'points'[4], 'neighbors'[4], 'subsampling'[3] (+ optional 'segment_lengths'[4]: per-stage device
+        int64 GroupNorm segment lengths; absent => one segment = whole stack, the reference's semantics)."""
+        P, N, S = data_dict["points"], data_dict["neighbors"], data_dict["subsampling"]
+        seg = data_dict.get("segment_lengths")
+        ctx = [StageContext(None if seg is None else seg[i]) for i in range(4)]
+        f1 = self.encoder1_1(feats, P[0], P[0], N[0], ctx[0], ctx[0])
+        f1 = self.encoder1_2(f1, P[0], P[0], N[0], ctx[0], ctx[0])
+        f2 = self.encoder2_1(f1, P[1], P[0], S[0], ctx[1], ctx[0])
+        f2 = self.encoder2_2(f2, P[1], P[1], N[1], ctx[1], ctx[1])
+        f2 = self.encoder2_3(f2, P[1], P[1], N[1], ctx[1], ctx[1])
+        f3 = self.encoder3_1(f2, P[2], P[1], S[1], ctx[2], ctx[1])
+        f3 = self.encoder3_2(f3, P[2], P[2], N[2], ctx[2], ctx[2])
+        f3 = self.encoder3_3(f3, P[2], P[2], N[2], ctx[2], ctx[2])
+        f4 = self.encoder4_1(f3, P[3], P[2], S[2], ctx[3], ctx[2])
+        f4 = self.encoder4_2(f4, P[3], P[3], N[3], ctx[3], ctx[3])
+        f4 = self.encoder4_3(f4, P[3], P[3], N[3], ctx[3], ctx[3])
+        return [f1, f2, f3, f4]

@@ -1,0 +1,313 @@
+// kpconv.hip — a-4: the gather / kernel-point-influence / aggregation half of rigid KPConv, plus the small ops around it.
+//
+// Reference: KPConv.forward, experiments/lcrnet/modules/kpconv/kpconv.py:79-122 — gathers (M,H,3) and (M,H,C), builds
+// (M,H,15,3) differences, (M,15,H) influences, bmm -> (M,15,C), then the (15,C,Cout) contraction, every intermediate
+// materialised in HBM (~2.6 GB per scan).  Here one wavefront owns one query point:
+//   1. lanes = neighbours: each lane gathers its support point (shadow rows skipped instead of a +1e6 pad, kpconv.py:91),
+//      evaluates the 15 linear influences max(0, 1 - |y - k|/sigma) (:96-99) and parks them in LDS;
+//   2. lanes = channels: the wavefront streams the valid neighbours' feature rows (coalesced 128-256 B segments),
+//      accumulating the 15 x C weighted sums (:104) in registers (for C = 32 the two half-waves take alternate neighbours
+//      and are folded with one cross-lane add);
+//   3. writes the (15*C) row that lcr_gemm_f32 contracts with the (15*C, Cout) weights (:108-110) and the neighbour
+//      count used by its epilogue (:113-116: neighbours whose feature row sums to > 0).
+// Only the (M, 15*C) aggregate goes through HBM/Infinity-Cache between the two halves (fusing it away is the next step).
+// encoder1_1 (C_in = 1, backbone4.py:15) is fully fused in k_kpconv_cin1.
+#include <algorithm>
+
+#include "common.h"
+
+namespace lcr {
+
+constexpr int KP_K = 15;       // kernel points (cfg.backbone.kernel_size)
+constexpr int KP_HMAX = 128;   // neighbour columns supported per query
+constexpr int KP_WAVES = 4;
+
+struct KPoints {
+  float p[KP_K][3];
+};
+
+// Compacts the valid (non-shadow) neighbours of one query into LDS, in order, together with their 15 influences.
+template <typename IdxT>
+__device__ __forceinline__ int gather_neighbours(const IdxT* __restrict__ row, int H, int64_t Ns, const float* __restrict__ s_pts,
+                                                 const float* __restrict__ q, const KPoints& kp, float sigma,
+                                                 int32_t* __restrict__ l_idx, float* __restrict__ l_w /*[KP_HMAX][16]*/) {
+  const int lane = threadIdx.x & 63;
+  int n = 0;
+  for (int h0 = 0; h0 < H; h0 += 64) {
+    const int h = h0 + lane;
+    int64_t j = Ns;
+    if (h < H) j = static_cast<int64_t>(row[h]);
+    const bool ok = j >= 0 && j < Ns;
+    const uint64_t m = __ballot(ok);
+    const int slot = n + __popcll(m & lanemask_lt());
+    if (ok) {
+      const float dx = s_pts[3 * j + 0] - q[0], dy = s_pts[3 * j + 1] - q[1], dz = s_pts[3 * j + 2] - q[2];
+      l_idx[slot] = static_cast<int32_t>(j);
+#pragma unroll
+      for (int k = 0; k < KP_K; ++k) {
+        const float ex = dx - kp.p[k][0], ey = dy - kp.p[k][1], ez = dz - kp.p[k][2];
+        const float d2 = ex * ex + ey * ey + ez * ez;
+        l_w[slot * 16 + k] = fmaxf(1.f - sqrtf(d2) / sigma, 0.f);
+      }
+    }
+    n += __popcll(m);
+  }
+  return n;
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// CPL = channels per lane (C = 64*CPL) or, for HALF, C = 32 with the two half-waves splitting the neighbours
+template <typename IdxT, int CPL, bool HALF>
+__global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate(const float* __restrict__ s_feats, const uint8_t* __restrict__ s_pos,
+                                                                    const float* __restrict__ q_pts, const float* __restrict__ s_pts,
+                                                                    const IdxT* __restrict__ idx, int64_t M, int64_t Ns, int H, KPoints kp,
+                                                                    float sigma, float* __restrict__ A, float* __restrict__ nn) {
+  constexpr int C = HALF ? 32 : 64 * CPL;
+  __shared__ int32_t s_idx[KP_WAVES][KP_HMAX];
+  __shared__ float   s_w[KP_WAVES][KP_HMAX * 16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int64_t m = static_cast<int64_t>(blockIdx.x) * KP_WAVES + w; m < M; m += static_cast<int64_t>(gridDim.x) * KP_WAVES) {
+    const float q[3] = {q_pts[3 * m], q_pts[3 * m + 1], q_pts[3 * m + 2]};
+    const int n = gather_neighbours(idx + m * H, H, Ns, s_pts, q, kp, sigma, s_idx[w], s_w[w]);
+    wave_lds_sync();
+    // neighbour count of kpconv.py:113-116
+    int cnt = 0;
+    for (int h = lane; h < n; h += 64) cnt += s_pos[s_idx[w][h]] ? 1 : 0;
+    cnt = wave_sum(cnt);
+
+    float acc[CPL][KP_K];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j)
+#pragma unroll
+      for (int k = 0; k < KP_K; ++k) acc[j][k] = 0.f;
+
+    if (HALF) {
+      const int g = lane >> 5, c = lane & 31;
+      for (int h = g; h < n; h += 2) {
+        const float f = s_feats[static_cast<int64_t>(s_idx[w][h]) * C + c];
+        const float* wp = &s_w[w][h * 16];
+#pragma unroll
+        for (int k = 0; k < KP_K; ++k) acc[0][k] = fmaf(wp[k], f, acc[0][k]);
+      }
+#pragma unroll
+      for (int k = 0; k < KP_K; ++k) acc[0][k] += __shfl_xor(acc[0][k], 32);
+      if (lane < 32) {
+        float* out = A + m * (KP_K * C);
+#pragma unroll
+        for (int k = 0; k < KP_K; ++k) out[k * C + c] = acc[0][k];
+      }
+    } else {
+      int h = 0;
+      for (; h + 2 <= n; h += 2) {   // two neighbours in flight
+        const float* r0 = s_feats + static_cast<int64_t>(s_idx[w][h]) * C;
+        const float* r1 = s_feats + static_cast<int64_t>(s_idx[w][h + 1]) * C;
+        float f0[CPL], f1[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          f0[j] = r0[lane + 64 * j];
+          f1[j] = r1[lane + 64 * j];
+        }
+        const float* w0 = &s_w[w][h * 16];
+        const float* w1 = w0 + 16;
+#pragma unroll
+        for (int k = 0; k < KP_K; ++k) {
+          const float a = w0[k], b = w1[k];
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) acc[j][k] = fmaf(b, f1[j], fmaf(a, f0[j], acc[j][k]));
+        }
+      }
+      if (h < n) {
+        const float* r0 = s_feats + static_cast<int64_t>(s_idx[w][h]) * C;
+        const float* w0 = &s_w[w][h * 16];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          const float f = r0[lane + 64 * j];
+#pragma unroll
+          for (int k = 0; k < KP_K; ++k) acc[j][k] = fmaf(w0[k], f, acc[j][k]);
+        }
+      }
+      float* out = A + m * (KP_K * C);
+#pragma unroll
+      for (int k = 0; k < KP_K; ++k)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) out[k * C + lane + 64 * j] = acc[j][k];
+    }
+    if (lane == 0) nn[m] = static_cast<float>(cnt > 1 ? cnt : 1);
+    wave_lds_sync();
+  }
+}
+
+// encoder1_1: scalar input feature per point; out[m][o] = (sum_k (sum_h w[k][h] f[h]) W[k][o]) / count + bias[o]
+template <typename IdxT>
+__global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_cin1(const float* __restrict__ s_feats, const float* __restrict__ q_pts,
+                                                               const float* __restrict__ s_pts, const IdxT* __restrict__ idx, int64_t M,
+                                                               int64_t Ns, int H, KPoints kp, float sigma, const float* __restrict__ W,
+                                                               const float* __restrict__ bias, int Cout, float* __restrict__ out) {
+  __shared__ float s_a[KP_WAVES][16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int64_t m = static_cast<int64_t>(blockIdx.x) * KP_WAVES + w; m < M; m += static_cast<int64_t>(gridDim.x) * KP_WAVES) {
+    const float qx = q_pts[3 * m], qy = q_pts[3 * m + 1], qz = q_pts[3 * m + 2];
+    float a[KP_K];
+#pragma unroll
+    for (int k = 0; k < KP_K; ++k) a[k] = 0.f;
+    int cnt = 0;
+    for (int h = lane; h < H; h += 64) {
+      const int64_t j = static_cast<int64_t>(idx[m * H + h]);
+      if (j >= 0 && j < Ns) {
+        const float f = s_feats[j];
+        cnt += f > 0.f ? 1 : 0;
+        const float dx = s_pts[3 * j + 0] - qx, dy = s_pts[3 * j + 1] - qy, dz = s_pts[3 * j + 2] - qz;
+#pragma unroll
+        for (int k = 0; k < KP_K; ++k) {
+          const float ex = dx - kp.p[k][0], ey = dy - kp.p[k][1], ez = dz - kp.p[k][2];
+          a[k] = fmaf(fmaxf(1.f - sqrtf(ex * ex + ey * ey + ez * ez) / sigma, 0.f), f, a[k]);
+        }
+      }
+    }
+    cnt = wave_sum(cnt);
+#pragma unroll
+    for (int k = 0; k < KP_K; ++k) {
+      const float s = wave_sum(a[k]);
+      if (lane == 0) s_a[w][k] = s;
+    }
+    wave_lds_sync();
+    const float div = static_cast<float>(cnt > 1 ? cnt : 1);
+    for (int o = lane; o < Cout; o += 64) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < KP_K; ++k) v = fmaf(s_a[w][k], W[k * Cout + o], v);
+      v = v / div;
+      if (bias) v += bias[o];
+      out[m * Cout + o] = v;
+    }
+    wave_lds_sync();
+  }
+}
+
+// maxpool over neighbours with a zero shadow row (kpconv/functional.py:54-67)
+template <typename IdxT>
+__global__ __launch_bounds__(256) void k_maxpool(const float* __restrict__ x, const IdxT* __restrict__ idx, int64_t M, int64_t Ns, int H, int C,
+                                                 float* __restrict__ out) {
+  __shared__ int32_t s_idx[4][KP_HMAX];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int64_t m = static_cast<int64_t>(blockIdx.x) * 4 + w; m < M; m += static_cast<int64_t>(gridDim.x) * 4) {
+    int n = 0;
+    bool any_shadow = false;
+    for (int h0 = 0; h0 < H; h0 += 64) {
+      const int h = h0 + lane;
+      int64_t j = Ns;
+      if (h < H) j = static_cast<int64_t>(idx[m * H + h]);
+      const bool ok = j >= 0 && j < Ns;
+      const uint64_t mk = __ballot(ok);
+      if (ok) s_idx[w][n + __popcll(mk & lanemask_lt())] = static_cast<int32_t>(j);
+      any_shadow |= (__ballot(h < H && !ok) != 0ull);
+      n += __popcll(mk);
+    }
+    wave_lds_sync();
+    for (int c = lane; c < C; c += 64) {
+      float v = any_shadow ? 0.f : -INFINITY;
+      for (int h = 0; h < n; ++h) v = fmaxf(v, x[static_cast<int64_t>(s_idx[w][h]) * C + c]);
+      out[m * C + c] = v;
+    }
+    wave_lds_sync();
+  }
+}
+
+// pos[n] = (sum_c x[n][c] > 0): the per-support flag behind KPConv's neighbour count (kpconv.py:113-114)
+__global__ __launch_bounds__(256) void k_row_pos(const float* __restrict__ x, int64_t N, int C, uint8_t* __restrict__ pos) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int64_t n = static_cast<int64_t>(blockIdx.x) * 4 + w; n < N; n += static_cast<int64_t>(gridDim.x) * 4) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += x[n * C + c];
+    s = wave_sum(s);
+    if (lane == 0) pos[n] = s > 0.f ? 1 : 0;
+  }
+}
+
+static KPoints load_kp(const float* kp_host) {
+  KPoints k;
+  for (int i = 0; i < KP_K; ++i)
+    for (int d = 0; d < 3; ++d) k.p[i][d] = kp_host[3 * i + d];
+  return k;
+}
+
+static int grid_for(int64_t rows, int per_block) { return static_cast<int>(std::min<int64_t>((rows + per_block - 1) / per_block, 256 * 16)); }
+
+template <typename IdxT>
+static int launch_aggregate(const float* s_feats, const uint8_t* s_pos, const float* q_pts, const float* s_pts, const IdxT* idx, int64_t M,
+                            int64_t Ns, int H, int C, const KPoints& kp, float sigma, float* A, float* nn, hipStream_t st) {
+  dim3 grid(grid_for(M, KP_WAVES)), block(KP_WAVES * 64);
+  switch (C) {
+    case 32: hipLaunchKernelGGL((k_kpconv_aggregate<IdxT, 1, true>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn); break;
+    case 64: hipLaunchKernelGGL((k_kpconv_aggregate<IdxT, 1, false>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn); break;
+    case 128: hipLaunchKernelGGL((k_kpconv_aggregate<IdxT, 2, false>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn); break;
+    case 256: hipLaunchKernelGGL((k_kpconv_aggregate<IdxT, 4, false>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn); break;
+    default: set_error("lcr_kpconv_aggregate: C must be 32, 64, 128 or 256 (got %d)", C); return LCR_EARG;
+  }
+  return check_launch("lcr_kpconv_aggregate");
+}
+
+}  // namespace lcr
+
+using namespace lcr;
+
+extern "C" int lcr_kpconv_aggregate(const float* s_feats, const uint8_t* s_pos, const float* q_pts, const float* s_pts, const void* idx,
+                                    int idx_is_64, int64_t M, int64_t Ns, int H, int C, const float* kernel_points_host, float sigma,
+                                    float* A, float* nn, void* stream) {
+  if (!s_feats || !s_pos || !q_pts || !s_pts || !idx || !kernel_points_host || !A || !nn || M < 0 || Ns < 0 || H < 1 || H > KP_HMAX ||
+      !(sigma > 0.f)) {
+    set_error("lcr_kpconv_aggregate: bad argument (H must be in [1,%d])", KP_HMAX);
+    return LCR_EARG;
+  }
+  if (M == 0) return LCR_OK;
+  const KPoints kp = load_kp(kernel_points_host);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return idx_is_64 ? launch_aggregate(s_feats, s_pos, q_pts, s_pts, static_cast<const int64_t*>(idx), M, Ns, H, C, kp, sigma, A, nn, st)
+                   : launch_aggregate(s_feats, s_pos, q_pts, s_pts, static_cast<const int32_t*>(idx), M, Ns, H, C, kp, sigma, A, nn, st);
+}
+
+extern "C" int lcr_kpconv_cin1(const float* s_feats, const float* q_pts, const float* s_pts, const void* idx, int idx_is_64, int64_t M,
+                               int64_t Ns, int H, const float* kernel_points_host, float sigma, const float* W, const float* bias, int Cout,
+                               float* out, void* stream) {
+  if (!s_feats || !q_pts || !s_pts || !idx || !kernel_points_host || !W || !out || M < 0 || H < 1 || Cout < 1 || !(sigma > 0.f)) {
+    set_error("lcr_kpconv_cin1: bad argument");
+    return LCR_EARG;
+  }
+  if (M == 0) return LCR_OK;
+  const KPoints kp = load_kp(kernel_points_host);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  dim3 grid(grid_for(M, KP_WAVES)), block(KP_WAVES * 64);
+  if (idx_is_64)
+    hipLaunchKernelGGL((k_kpconv_cin1<int64_t>), grid, block, 0, st, s_feats, q_pts, s_pts, static_cast<const int64_t*>(idx), M, Ns, H, kp, sigma, W, bias, Cout, out);
+  else
+    hipLaunchKernelGGL((k_kpconv_cin1<int32_t>), grid, block, 0, st, s_feats, q_pts, s_pts, static_cast<const int32_t*>(idx), M, Ns, H, kp, sigma, W, bias, Cout, out);
+  return check_launch("lcr_kpconv_cin1");
+}
+
+extern "C" int lcr_maxpool(const float* x, const void* idx, int idx_is_64, int64_t M, int64_t Ns, int H, int C, float* out, void* stream) {
+  if (!x || !idx || !out || M < 0 || H < 1 || H > KP_HMAX || C < 1) {
+    set_error("lcr_maxpool: bad argument");
+    return LCR_EARG;
+  }
+  if (M == 0) return LCR_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  dim3 grid(grid_for(M, 4)), block(256);
+  if (idx_is_64) hipLaunchKernelGGL((k_maxpool<int64_t>), grid, block, 0, st, x, static_cast<const int64_t*>(idx), M, Ns, H, C, out);
+  else hipLaunchKernelGGL((k_maxpool<int32_t>), grid, block, 0, st, x, static_cast<const int32_t*>(idx), M, Ns, H, C, out);
+  return check_launch("lcr_maxpool");
+}
+
+extern "C" int lcr_row_positive(const float* x, int64_t N, int C, uint8_t* pos, void* stream) {
+  if (!x || !pos || N < 0 || C < 1) {
+    set_error("lcr_row_positive: bad argument");
+    return LCR_EARG;
+  }
+  if (N == 0) return LCR_OK;
+  hipLaunchKernelGGL(k_row_pos, dim3(grid_for(N, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, N, C, pos);
+  return check_launch("lcr_row_positive");
+}

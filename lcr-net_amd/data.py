@@ -1,0 +1,98 @@
+"""Stack-mode data pipeline on the GPU — experiments/lcrnet/data.py:10-74 (`precompute_data_stack_mode`) and the
+single-scan / pair collates (:77-127, :350-406) without the DataLoader worker processes: the whole batch is prepared by
+HIP kernels on the stream that then runs the encoder.
+
+Two entry points:
+  * precompute_data_stack_mode(...)  — the reference signature and return layout (int64 indices, exact shapes), built from
+    the drop-in ops; every op synchronises once to size its output (like the reference, it is a blocking call).
+  * precompute_batch(...)            — the throughput path: capacity buffers + device-side lengths, the 4 support grids
+    shared by the 10 searches (7 if the decoder-only upsampling lists are skipped), int32 indices, ONE host sync at the end.
+"""
+import torch
+
+from .modules.ops import SupportGrid, grid_subsample, grid_subsample_device, radius_search
+
+STATUS_KEY_OVERFLOW = 1
+
+
+def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, neighbor_limits):
+    """Drop-in for data.py:10-74 on device tensors (same loop structure: voxel and radius double per stage)."""
+    assert num_stages == len(neighbor_limits)
+    points_list, lengths_list, neighbors_list, subsampling_list, upsampling_list = [], [], [], [], []
+    lengths = lengths.to(points.device)
+    for i in range(num_stages):
+        if i > 0:
+            points, lengths = grid_subsample(points, lengths, voxel_size=voxel_size)
+            points = points.contiguous()
+        points_list.append(points)
+        lengths_list.append(lengths)
+        voxel_size *= 2
+    for i in range(num_stages):
+        cur_p, cur_l = points_list[i], lengths_list[i]
+        neighbors_list.append(radius_search(cur_p, cur_p, cur_l, cur_l, radius, neighbor_limits[i]))
+        if i < num_stages - 1:
+            sub_p, sub_l = points_list[i + 1], lengths_list[i + 1]
+            subsampling_list.append(radius_search(sub_p, cur_p, sub_l, cur_l, radius, neighbor_limits[i]))
+            upsampling_list.append(radius_search(cur_p, sub_p, cur_l, sub_l, radius * 2, neighbor_limits[i + 1]))
+        radius *= 2
+    return {"points": points_list, "lengths": lengths_list, "neighbors": neighbors_list,
+            "subsampling": subsampling_list, "upsampling": upsampling_list}
+
+
+def precompute_batch(points, lengths, num_stages, voxel_size, radius, neighbor_limits, upsampling=True,
+                     index_dtype=torch.int32, key_bits_hint=32):
+    """Same five lists as precompute_data_stack_mode for a stack of B clouds, plus:
+         'lengths_host'    : list of python lists (per stage),
+         'segment_lengths' : per-stage device int64 lengths (GroupNorm segments = clouds; regroup for pair semantics).
+    points: device f32 [N,3] (exact rows), lengths: device i64 [B].  One host synchronisation."""
+    assert num_stages == len(neighbor_limits)
+    dev = points.device
+    lengths = lengths.to(dev)
+    pts, lens, statuses = [points.contiguous()], [lengths], []
+    v = voxel_size
+    for i in range(1, num_stages):
+        v *= 2
+        p, l, st = grid_subsample_device(pts[-1], lens[-1], v, key_bits_hint=key_bits_hint)
+        pts.append(p)
+        lens.append(l)
+        statuses.append(st)
+    grids = []
+    r = radius
+    for i in range(num_stages):
+        grids.append(SupportGrid(pts[i], lens[i], r))
+        r *= 2
+    neighbors, subsampling, upsamp = [], [], []
+    for i in range(num_stages):
+        neighbors.append(grids[i].query(pts[i], lens[i], neighbor_limits[i], dtype=index_dtype))
+        if i < num_stages - 1:
+            subsampling.append(grids[i].query(pts[i + 1], lens[i + 1], neighbor_limits[i], dtype=index_dtype))
+            if upsampling:
+                upsamp.append(grids[i + 1].query(pts[i], lens[i], neighbor_limits[i + 1], dtype=index_dtype))
+    host = torch.stack(lens + [torch.cat([s.long() for s in statuses] + [g.status.long() for g in grids]).sum().expand(lengths.numel())]).cpu()
+    status = int(host[-1][0])
+    if status & STATUS_KEY_OVERFLOW and key_bits_hint:
+        return precompute_batch(points, lengths, num_stages, voxel_size, radius, neighbor_limits, upsampling, index_dtype, 0)
+    if status:
+        raise RuntimeError("precompute_batch: device status 0x%x" % status)
+    lengths_host = [host[i].tolist() for i in range(num_stages)]
+    tot = [sum(l) for l in lengths_host]
+    pts = [pts[i][:tot[i]] for i in range(num_stages)]
+    neighbors = [neighbors[i][:tot[i]] for i in range(num_stages)]
+    subsampling = [subsampling[i][:tot[i + 1]] for i in range(num_stages - 1)]
+    upsamp = [upsamp[i][:tot[i]] for i in range(len(upsamp))]
+    return {"points": pts, "lengths": lens, "neighbors": neighbors, "subsampling": subsampling, "upsampling": upsamp,
+            "lengths_host": lengths_host, "segment_lengths": lens}
+
+
+def voxelize_raw_scans(points, lengths, voxel_size, key_bits_hint=40):
+    """Raw-scan ingest (replaces the offline Open3D voxel_down_sample(0.3) of data/Kitti/downsample_pcd.py:29
+    with the a-1 kernel): stacked raw scans -> stacked voxel barycentres; returns (points, lengths_dev, lengths_host)."""
+    out, out_len, status = grid_subsample_device(points, lengths, voxel_size, key_bits_hint=key_bits_hint)
+    host = torch.cat([out_len, status.long()]).cpu()
+    st = int(host[-1])
+    if st & STATUS_KEY_OVERFLOW and key_bits_hint:
+        return voxelize_raw_scans(points, lengths, voxel_size, 0)
+    if st:
+        raise RuntimeError("voxelize_raw_scans: device status 0x%x" % st)
+    lh = host[:-1].tolist()
+    return out[:sum(lh)], out_len, lh

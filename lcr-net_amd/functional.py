@@ -1,0 +1,137 @@
+"""Thin tensor-level wrappers over the C ABI (include/lcr_hip.h).  No arithmetic happens in Python: every function
+allocates the outputs with torch and launches HIP kernels on the current stream.  Inference only (no autograd)."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+GN_EPS = 1e-5
+
+
+def _seg(seg_len, n, device):
+    """GroupNorm segment lengths: None = the reference's behaviour (one segment = the whole stack)."""
+    if seg_len is None:
+        return torch.tensor([n], dtype=torch.int64, device=device)
+    return seg_len
+
+
+def _idx_args(idx):
+    if idx.dtype == torch.int64:
+        return 1
+    if idx.dtype == torch.int32:
+        return 0
+    raise RuntimeError("neighbor indices must be int32 or int64")
+
+
+def gemm(a, b, trans_b=False, trans_a=False, bias=None, rowdiv=None, seg_len=None, groups=0):
+    """C = A·B (+ fused epilogue).  a: [M,K] ([K,M] if trans_a); b: [K,N] ([N,K] if trans_b, i.e. an nn.Linear weight).
+    Returns (C, stats) where stats is the fp64 [S,groups,2] GroupNorm accumulator (or None if groups == 0)."""
+    _lib.require_cuda(a, b)
+    assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.is_contiguous() and b.is_contiguous()
+    M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    N = b.shape[0] if trans_b else b.shape[1]
+    assert (b.shape[1] if trans_b else b.shape[0]) == K, "inner dimensions differ"
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    stats = None
+    S = 0
+    if groups:
+        seg_len = _seg(seg_len, M, a.device)
+        S = seg_len.numel()
+        stats = torch.empty((S, groups, 2), dtype=torch.float64, device=a.device)
+    _lib.check(_lib.lib().lcr_gemm_f32(_lib.ptr(a), _lib.ptr(b), _lib.ptr(c), M, N, K, int(trans_a), int(trans_b), _lib.ptr(bias),
+                                       _lib.ptr(rowdiv), _lib.ptr(seg_len) if groups else None, S, int(groups), _lib.ptr(stats),
+                                       _lib.stream_ptr(a.device)), "lcr_gemm_f32")
+    return c, stats
+
+
+def groupnorm_stats(x, groups, seg_len=None):
+    seg_len = _seg(seg_len, x.shape[0], x.device)
+    stats = torch.empty((seg_len.numel(), groups, 2), dtype=torch.float64, device=x.device)
+    _lib.check(_lib.lib().lcr_groupnorm_stats(_lib.ptr(x), x.shape[0], x.shape[1], groups, _lib.ptr(seg_len), seg_len.numel(),
+                                              _lib.ptr(stats), _lib.stream_ptr(x.device)), "lcr_groupnorm_stats")
+    return stats
+
+
+def groupnorm_apply(x, stats, gamma, beta, groups, seg_len=None, res=None, res_norm=None, slope=0.1, act=True, want_pos=False):
+    """y = act(GN(x) [+ res | + GN(res)]); res_norm = (stats, gamma, beta) of the residual branch or None."""
+    seg_len = _seg(seg_len, x.shape[0], x.device)
+    y = torch.empty_like(x)
+    pos = torch.empty((x.shape[0],), dtype=torch.uint8, device=x.device) if want_pos else None
+    rs, rg, rb = res_norm if res_norm is not None else (None, None, None)
+    _lib.check(_lib.lib().lcr_groupnorm_apply(_lib.ptr(x), _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(res), _lib.ptr(rs),
+                                              _lib.ptr(rg), _lib.ptr(rb), _lib.ptr(y), x.shape[0], x.shape[1], groups, _lib.ptr(seg_len),
+                                              seg_len.numel(), GN_EPS, float(slope), int(act), _lib.ptr(pos),
+                                              _lib.stream_ptr(x.device)), "lcr_groupnorm_apply")
+    return (y, pos) if want_pos else y
+
+
+def row_positive(x):
+    pos = torch.empty((x.shape[0],), dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.lib().lcr_row_positive(_lib.ptr(x), x.shape[0], x.shape[1], _lib.ptr(pos), _lib.stream_ptr(x.device)), "lcr_row_positive")
+    return pos
+
+
+def _kp_host(kernel_points):
+    kp = np.ascontiguousarray(kernel_points, dtype=np.float32)
+    assert kp.shape == (15, 3)
+    return kp
+
+
+def kpconv_aggregate(s_feats, s_pos, q_points, s_points, idx, kernel_points_host, sigma):
+    """(A [M, 15*C], nn [M]) — the gather/influence/aggregate half of KPConv.forward."""
+    _lib.require_cuda(s_feats, q_points, s_points, idx)
+    M, H = idx.shape
+    Ns, C = s_feats.shape
+    assert idx.is_contiguous() and s_feats.is_contiguous() and q_points.is_contiguous() and s_points.is_contiguous()
+    A = torch.empty((M, 15 * C), dtype=torch.float32, device=s_feats.device)
+    nn = torch.empty((M,), dtype=torch.float32, device=s_feats.device)
+    kp = _kp_host(kernel_points_host)
+    _lib.check(_lib.lib().lcr_kpconv_aggregate(_lib.ptr(s_feats), _lib.ptr(s_pos), _lib.ptr(q_points), _lib.ptr(s_points), _lib.ptr(idx),
+                                               _idx_args(idx), M, Ns, H, C, ctypes.c_void_p(kp.ctypes.data), float(sigma), _lib.ptr(A),
+                                               _lib.ptr(nn), _lib.stream_ptr(s_feats.device)), "lcr_kpconv_aggregate")
+    return A, nn
+
+
+def kpconv_cin1(s_feats, q_points, s_points, idx, kernel_points_host, sigma, weights, bias):
+    """Whole KPConv for one input channel: weights (15,1,Cout) -> out [M,Cout]."""
+    M, H = idx.shape
+    Ns = s_feats.shape[0]
+    Cout = weights.shape[-1]
+    out = torch.empty((M, Cout), dtype=torch.float32, device=s_feats.device)
+    kp = _kp_host(kernel_points_host)
+    _lib.check(_lib.lib().lcr_kpconv_cin1(_lib.ptr(s_feats), _lib.ptr(q_points), _lib.ptr(s_points), _lib.ptr(idx), _idx_args(idx), M, Ns, H,
+                                          ctypes.c_void_p(kp.ctypes.data), float(sigma), _lib.ptr(weights), _lib.ptr(bias), Cout,
+                                          _lib.ptr(out), _lib.stream_ptr(s_feats.device)), "lcr_kpconv_cin1")
+    return out
+
+
+def maxpool(x, idx):
+    M, H = idx.shape
+    out = torch.empty((M, x.shape[1]), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().lcr_maxpool(_lib.ptr(x), _lib.ptr(idx), _idx_args(idx), M, x.shape[0], H, x.shape[1], _lib.ptr(out),
+                                      _lib.stream_ptr(x.device)), "lcr_maxpool")
+    return out
+
+
+class NetvladWeights(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "cluster_weights", "cluster_weights2", "hidden1_weights", "bn1_w", "bn1_b", "bn1_mean", "bn1_var",
+        "bn2_w", "bn2_b", "bn2_mean", "bn2_var", "gating_weights", "gbn_w", "gbn_b", "gbn_mean", "gbn_var")]
+
+
+def netvlad_forward(feats, seg_len_host, weights_struct):
+    """feats [sum(seg_len),1024] stacked coarse features -> [S,256] unit-norm descriptors."""
+    _lib.require_cuda(feats)
+    seg = np.ascontiguousarray(seg_len_host, dtype=np.int64)
+    S = int(seg.shape[0])
+    assert int(seg.sum()) == feats.shape[0] and feats.shape[1] == 1024 and feats.is_contiguous()
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(_lib.lib().lcr_netvlad_ws_bytes(feats.shape[0], S, ctypes.byref(nbytes)), "lcr_netvlad_ws_bytes")
+    ws = _lib.workspace(nbytes.value, feats.device)
+    out = torch.empty((S, 256), dtype=torch.float32, device=feats.device)
+    _lib.check(_lib.lib().lcr_netvlad_forward(_lib.ptr(feats), ctypes.c_void_p(seg.ctypes.data), S, ctypes.byref(weights_struct),
+                                              _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(feats.device)),
+               "lcr_netvlad_forward")
+    return out

@@ -1,0 +1,1 @@
+from .LCRNet_GlobalDescrition import LCRNet_GlobalDescrition, create_model  # noqa: F401

@@ -1,0 +1,62 @@
+"""KPConv — same parameters/buffers as the reference module (weights (K,Cin,Cout), bias, kernel_points buffer;
+experiments/lcrnet/modules/kpconv/kpconv.py:10-122) with the forward on the HIP kernels:
+lcr_kpconv_aggregate (gather + influences + aggregation) -> lcr_gemm_f32 (kernel-point contraction with the
+neighbour-count division, bias and GroupNorm statistics fused in its epilogue)."""
+import math
+
+import torch
+import torch.nn as nn
+
+from ... import functional as F
+from ...weights import base_kernel_points
+
+
+class KPConv(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, radius, sigma, bias=False, dimension=3, inf=1e6, eps=1e-9):
+        super().__init__()
+        assert kernel_size == 15 and dimension == 3, "the HIP path implements the 15-point rigid 3-D kernel of the reference config"
+        self.kernel_size, self.in_channels, self.out_channels = kernel_size, in_channels, out_channels
+        self.radius, self.sigma, self.dimension = radius, sigma, dimension
+        self.inf, self.eps = inf, eps
+        self.weights = nn.Parameter(torch.zeros(kernel_size, in_channels, out_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        nn.init.kaiming_uniform_(self.weights, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = nn.init._calculate_fan_in_and_fan_out(self.weights)
+            bound = 1 / math.sqrt(fan_in)
+            nn.init.uniform_(self.bias, -bound, bound)
+        # The reference rotates/jitters the disposition randomly at construction (kernel_points.py:426-455) and stores the
+        # result in the checkpoint; real values therefore always come from load_state_dict.  Default: un-rotated disposition.
+        self.register_buffer("kernel_points", torch.from_numpy(base_kernel_points() * radius).float())
+        self._kp_cache = None
+
+    def kernel_points_host(self):
+        kp = self.kernel_points
+        key = (kp.data_ptr(), kp._version)
+        if self._kp_cache is None or self._kp_cache[0] != key:
+            self._kp_cache = (key, kp.detach().cpu().numpy().copy())   # one D2H per weight load, not per forward
+        return self._kp_cache[1]
+
+    def forward_raw(self, s_feats, q_points, s_points, neighbor_indices, s_pos=None, seg_len=None, groups=0):
+        """Returns (q_feats (M,Cout), stats) — stats = GroupNorm sums of the output when groups > 0."""
+        kp = self.kernel_points_host()
+        if self.in_channels == 1:
+            out = F.kpconv_cin1(s_feats.contiguous().view(-1), q_points, s_points, neighbor_indices, kp, self.sigma,
+                                self.weights, self.bias)
+            stats = F.groupnorm_stats(out, groups, seg_len) if groups else None
+            return out, stats
+        if s_pos is None:
+            s_pos = F.row_positive(s_feats)
+        A, nn_cnt = F.kpconv_aggregate(s_feats, s_pos, q_points, s_points, neighbor_indices, kp, self.sigma)
+        W = self.weights.view(self.kernel_size * self.in_channels, self.out_channels)
+        return F.gemm(A, W, bias=self.bias, rowdiv=nn_cnt, seg_len=seg_len, groups=groups)
+
+    def forward(self, s_feats, q_points, s_points, neighbor_indices):
+        return self.forward_raw(s_feats, q_points, s_points, neighbor_indices)[0]
+
+    def __repr__(self):
+        return (f"KPConv(kernel_size: {self.kernel_size}, in_channels: {self.in_channels}, out_channels: {self.out_channels}, "
+                f"radius: {self.radius:g}, sigma: {self.sigma:g}, bias: {self.bias is not None})")

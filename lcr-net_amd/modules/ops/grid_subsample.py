@@ -10,8 +10,10 @@ import torch
 from ... import _lib
 
 
-def grid_subsample_device(points, lengths, voxel_size):
-    """Sync-free form: returns (out_xyz [N,3] capacity buffer, out_len i64[B] on device, status)."""
+def grid_subsample_device(points, lengths, voxel_size, key_bits_hint=0):
+    """Sync-free form: returns (out_xyz [N,3] capacity buffer, out_len i64[B] on device, status).
+    key_bits_hint > 0 promises voxel-key bits + cloud-id bits <= hint (fewer radix passes); a broken promise sets
+    LCR_STATUS_KEY_OVERFLOW in `status` and the caller must retry with 0."""
     _lib.require_cuda(points)
     if points.dtype != torch.float32:
         raise RuntimeError("points must be a float tensor")
@@ -31,9 +33,9 @@ def grid_subsample_device(points, lengths, voxel_size):
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     out = torch.empty((max(n, 1), 3), dtype=torch.float32, device=dev)
     out_len = torch.empty((B,), dtype=torch.int64, device=dev)
-    _lib.check(L.lcr_grid_subsample(_lib.ptr(points), _lib.ptr(lengths), B, n, float(voxel_size), _lib.ptr(out),
-                                    _lib.ptr(out_len), _lib.ptr(status), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
-               "lcr_grid_subsample")
+    _lib.check(L.lcr_grid_subsample_ex(_lib.ptr(points), _lib.ptr(lengths), B, n, float(voxel_size), int(key_bits_hint),
+                                       _lib.ptr(out), _lib.ptr(out_len), _lib.ptr(status), _lib.ptr(ws), ws.numel(),
+                                       _lib.stream_ptr(dev)), "lcr_grid_subsample")
     return out, out_len, status
 
 

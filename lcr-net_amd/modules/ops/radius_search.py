@@ -69,3 +69,38 @@ def radius_search(q_points, s_points, q_lengths, s_lengths, radius, neighbor_lim
     want64 = dtype == torch.int64
     out64, out32, _, _ = _call(q_points, s_points, q_lengths, s_lengths, radius, limit, want64, not want64, False)
     return out64 if want64 else out32
+
+
+class SupportGrid:
+    """A uniform grid over stacked support clouds, built once and queried by several query sets (the 10 searches of
+    precompute_data_stack_mode need only 4 grids: neighbors[i], subsampling[i] and upsampling[i-1] share support and radius).
+    Sync-free: lengths stay on the device, `s_points` may be a capacity buffer whose first sum(s_lengths) rows are valid."""
+
+    def __init__(self, s_points, s_lengths, radius):
+        _lib.require_cuda(s_points, s_lengths)
+        assert s_points.dtype == torch.float32 and s_points.is_contiguous() and s_lengths.dtype == torch.int64
+        self.s_points, self.s_lengths, self.radius = s_points, s_lengths, float(radius)
+        self.B, self.ns_cap = s_lengths.numel(), s_points.shape[0]
+        dev = s_points.device
+        L = _lib.lib()
+        nbytes = ctypes.c_size_t(0)
+        _lib.check(L.lcr_support_grid_ws_bytes(self.ns_cap, self.B, ctypes.byref(nbytes)), "lcr_support_grid_ws_bytes")
+        self.ws = _lib.workspace(nbytes.value, dev)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(L.lcr_support_grid_build(_lib.ptr(s_points), _lib.ptr(s_lengths), self.B, self.ns_cap, self.radius,
+                                            _lib.ptr(self.status), _lib.ptr(self.ws), self.ws.numel(), _lib.stream_ptr(dev)),
+                   "lcr_support_grid_build")
+
+    def query(self, q_points, q_lengths, neighbor_limit, dtype=torch.int32, want_counts=False):
+        """[nq_cap, limit] indices (rows beyond sum(q_lengths) are left unwritten) and optionally the in-radius counts."""
+        assert q_points.dtype == torch.float32 and q_points.is_contiguous() and q_lengths.numel() == self.B
+        dev = q_points.device
+        nq = q_points.shape[0]
+        limit = int(neighbor_limit)
+        out = torch.empty((nq, limit), dtype=dtype, device=dev) if limit > 0 else None
+        cnt = torch.empty((nq,), dtype=torch.int32, device=dev) if (want_counts or limit == 0) else None
+        o64, o32 = (out, None) if dtype == torch.int64 else (None, out)
+        _lib.check(_lib.lib().lcr_radius_query(_lib.ptr(q_points), _lib.ptr(q_lengths), self.B, nq, _lib.ptr(self.ws), self.ns_cap,
+                                               self.radius, limit, _lib.ptr(o64), _lib.ptr(o32), _lib.ptr(cnt), _lib.stream_ptr(dev)),
+                   "lcr_radius_query")
+        return (out, cnt) if (want_counts or limit == 0) else out

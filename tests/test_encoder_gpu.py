@@ -1,0 +1,150 @@
+"""GPU parity tests for the floating-point half of the path (KPConv encoder, segmented GroupNorm, NetVLAD head), through
+the C ABI.  References: oracle/torch_ref.py (fp32 torch restatement, pinned to the imported reference by
+tests/test_torch_ref_golden.py) on the same inputs, and the golden descriptors generated from the reference model itself.
+Tolerance (north_star): descriptors within 1e-4 fp32."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, LIMITS, NUM_STAGES, RADIUS, VOXEL, load_scan
+from oracle import ops as oracle_ops
+from oracle import torch_ref
+
+pytestmark = pytest.mark.gpu
+DESC_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def model_golden():
+    return np.load(os.path.join(GOLDEN, "model_golden.npz"))
+
+
+@pytest.fixture(scope="module")
+def model():
+    from lcrnet_amd.model_family import create_model
+    from lcrnet_amd.weights import seeded_state_dict
+    m = create_model().eval()
+    seed = json.load(open(os.path.join(GOLDEN, "model_manifest.json")))["seed"]
+    m.load_state_dict(seeded_state_dict(m.state_dict(), seed), strict=True)
+    return m.cuda()
+
+
+def cpu_sd(model):
+    return {k: v.detach().cpu() for k, v in model.state_dict().items()}
+
+
+def oracle_stack(xyz_list, limits=LIMITS):
+    xyz = np.concatenate(xyz_list)
+    lens = np.array([len(x) for x in xyz_list], dtype=np.int64)
+    st = oracle_ops.precompute_data_stack_mode(xyz, lens, NUM_STAGES, VOXEL, RADIUS, limits)
+    return {k: [torch.from_numpy(np.ascontiguousarray(t)) for t in v] for k, v in st.items()}
+
+
+def to_dev(dd):
+    return {k: [t.cuda() for t in v] for k, v in dd.items()}
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb", [(1000, 64, 96, 0, 0), (777, 32, 480, 0, 0), (300, 128, 64, 0, 1), (129, 256, 1920, 0, 0),
+                                          (1024, 64, 844, 1, 0), (5, 1024, 256, 0, 1), (4097, 64, 960, 0, 0), (260, 96, 100, 1, 1)])
+def test_gemm_f32_matches_torch(M, N, K, ta, tb):
+    from lcrnet_amd import functional as F
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn((K, M) if ta else (M, K), generator=g)
+    b = torch.randn((N, K) if tb else (K, N), generator=g)
+    bias = torch.randn(N, generator=g)
+    div = torch.randint(1, 60, (M,), generator=g).float()
+    want = ((a.t() if ta else a).double() @ (b.t() if tb else b).double()) / div.double()[:, None] + bias.double()
+    got, _ = F.gemm(a.cuda(), b.cuda(), trans_a=bool(ta), trans_b=bool(tb), bias=bias.cuda(), rowdiv=div.cuda())
+    err = (got.cpu().double() - want).abs().max().item()
+    assert err < 2e-4 * max(1.0, want.abs().max().item()), err
+
+
+def test_gemm_groupnorm_statistics_segmented():
+    from lcrnet_amd import functional as F
+    g = torch.Generator().manual_seed(1)
+    M, N, K, groups = 1500, 64, 64, 32
+    a, b = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g)
+    seg = torch.tensor([700, 1, 799])                       # a segment boundary inside a 128-row tile, a 1-row segment
+    c, stats = F.gemm(a.cuda(), b.cuda(), seg_len=seg.cuda(), groups=groups)
+    cc = c.cpu().double()
+    o = 0
+    for s, n in enumerate(seg.tolist()):
+        blk = cc[o:o + n].reshape(n, groups, N // groups)
+        assert torch.allclose(stats[s, :, 0].cpu(), blk.sum((0, 2)), rtol=1e-5, atol=1e-3)   # 16-value fp32 partials, fp64 across
+        assert torch.allclose(stats[s, :, 1].cpu(), (blk ** 2).sum((0, 2)), rtol=1e-5, atol=1e-3)
+        o += n
+
+
+def test_residual_blocks_match_torch_ref(model):
+    """Every encoder block against the torch fp32 restatement on one real scan (same inputs per block)."""
+    dd = oracle_stack([load_scan("000560")])
+    sd = cpu_sd(model)
+    trace = {}
+    with torch.no_grad():
+        torch_ref.kp_encoder(sd, torch.ones(dd["points"][0].shape[0], 1), dd, trace=trace)
+        d = to_dev(dd)
+        feats = model.encoder(torch.ones(d["points"][0].shape[0], 1, device="cuda"), d)
+    got = {"encoder1_2": feats[0], "encoder2_3": feats[1], "encoder3_3": feats[2], "encoder4_3": feats[3]}
+    for name, g in got.items():
+        err = (g.cpu() - trace[name]).abs().max().item()
+        assert err < 5e-4, (name, err)
+
+
+def test_descriptor_matches_reference_golden(model, model_golden):
+    for name in ["003854", "000026", "004481"]:
+        dd = to_dev(oracle_stack([load_scan(name)]))
+        dd["features"] = torch.ones(dd["points"][0].shape[0], 1, device="cuda")
+        with torch.no_grad():
+            out = model(dd)
+        g = out["anc_global"].cpu()
+        want = torch.from_numpy(model_golden[f"{name}/anc_global"])
+        assert g.shape == (1, 256)
+        assert (g - want).abs().max().item() < DESC_TOL, (name, (g - want).abs().max().item())
+        if name == "003854":
+            fc = torch.from_numpy(model_golden["003854/feats_c"])
+            assert (out["feats_c"].cpu() - fc).abs().max().item() < 1e-3
+
+
+def test_gpu_pipeline_batch_equals_single_scans(model, model_golden):
+    """precompute_batch (HIP ops, int32 indices, per-scan GroupNorm segments) + batched NetVLAD == the reference's
+    one-scan-per-stack results."""
+    from lcrnet_amd.data import precompute_batch
+    names = ["003854", "000958", "004481"]
+    scans = [load_scan(n) for n in names]
+    pts = torch.from_numpy(np.concatenate(scans)).cuda()
+    lens = torch.tensor([len(s) for s in scans], dtype=torch.int64, device="cuda")
+    dd = precompute_batch(pts, lens, NUM_STAGES, VOXEL, RADIUS, LIMITS)
+    # indices identical to the oracle run on each scan alone (after removing the stack offsets)
+    off_s = 0
+    for b, s in enumerate(scans):
+        single = oracle_ops.precompute_data_stack_mode(s, np.array([len(s)]), NUM_STAGES, VOXEL, RADIUS, LIMITS)
+        n0 = len(s)
+        got = dd["neighbors"][0][off_s:off_s + n0].cpu().numpy().astype(np.int64)
+        pad = got == pts.shape[0]
+        got = np.where(pad, n0, got - off_s)
+        assert np.array_equal(got, single["neighbors"][0])
+        off_s += n0
+    dd["features"] = torch.ones(pts.shape[0], 1, device="cuda")
+    dd["lengths_c_host"] = dd["lengths_host"][-1]
+    with torch.no_grad():
+        out = model(dd)["anc_global"].cpu()
+    assert out.shape == (3, 256)
+    for i, n in enumerate(names):
+        want = torch.from_numpy(model_golden[f"{n}/anc_global"])[0]
+        assert (out[i] - want).abs().max().item() < DESC_TOL, (n, (out[i] - want).abs().max().item())
+
+
+def test_pair_stack_groupnorm_over_pair(model, model_golden):
+    """Reference pair semantics: GroupNorm statistics over BOTH clouds (default: no segment_lengths)."""
+    dd = to_dev(oracle_stack([load_scan("003854"), load_scan("000958")]))
+    n0 = int(dd["lengths"][-1][0])
+    with torch.no_grad():
+        fc = model.encoder(torch.ones(dd["points"][0].shape[0], 1, device="cuda"), dd)[-1]
+        g = model.netvlad.describe(fc, [n0, fc.shape[0] - n0]).cpu()
+    r = model_golden["pair/feats_c_rows"]
+    assert (fc.cpu()[r] - torch.from_numpy(model_golden["pair/feats_c_vals"])).abs().max().item() < 1e-3
+    assert (g[0] - torch.from_numpy(model_golden["pair/pos_global"])[0]).abs().max().item() < DESC_TOL
+    assert (g[1] - torch.from_numpy(model_golden["pair/anc_global"])[0]).abs().max().item() < DESC_TOL
