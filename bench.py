@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""bench.py — scans/s of the per-scan hot path on MI355X (BASELINE.json metric, configs[1]).
+
+One step = one batch of 8 synthetic 64-beam scans (~120 k points each, already resident in HBM) through the whole path:
+0.3 m voxelisation (a-1) -> 3 grid subsamples + 10 radius searches (a-1/a-2/a-3) -> KPConv encoder (a-4..a-6) ->
+NetVLAD (a-7) -> 8 unit-norm 256-D descriptors.  Weights: seeded random in the reference checkpoint layout (no checkpoint
+in the containers).  N GPUs = N ranks, each with its own batch (scan-parallel, weak scaling), descriptors all-gathered
+over RCCL inside the timed region (the exchange step of the retrieval).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BATCH = 8
+VOXEL, RADIUS, NUM_STAGES = 0.3, 1.275, 4
+LIMITS = [64, 65, 74, 80]          # reference training/eval default (dataset_loop_detection.py:25,80)
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
+FP32_PEAK_TFLOPS = 157.3           # dense fp32 MFMA/vector peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-upsampling", action="store_true", help="skip the 3 decoder-only upsampling searches")
+    return ap.parse_args()
+
+
+def make_batch(rank):
+    import lcrnet_amd.synthetic as synthetic
+    scans = [synthetic.synthetic_scan(rank * BATCH + i) for i in range(BATCH)]
+    return scans
+
+
+def step(model, raw_pts, raw_lens, upsampling=True):
+    from lcrnet_amd.data import precompute_batch, voxelize_raw_scans
+    pts, lens_dev, _ = voxelize_raw_scans(raw_pts, raw_lens, VOXEL)
+    dd = precompute_batch(pts.contiguous(), lens_dev, NUM_STAGES, VOXEL, RADIUS, LIMITS, upsampling=upsampling)
+    dd["features"] = torch.ones(pts.shape[0], 1, device=pts.device)
+    dd["lengths_c_host"] = dd["lengths_host"][-1]
+    out = model(dd)
+    return out["anc_global"], dd
+
+
+def cpu_baseline(scans, n_scans=2):
+    """The same path on host cores: native ops from the compiled reference when oracle/_ref is present (else the C++
+    restatement), encoder + NetVLAD from the torch fp32 restatement.  Bounded sample, rank 0 only."""
+    from oracle import ops as oracle_ops
+    from oracle import torch_ref
+    from lcrnet_amd.model_family import create_model
+    from lcrnet_amd.weights import seeded_state_dict
+    impl = "ref" if oracle_ops.have_ref() else "oracle"
+    m = create_model()
+    sd = seeded_state_dict(m.state_dict(), 7351)
+    threads = torch.get_num_threads()
+    t_pre = t_enc = 0.0
+    t0 = time.time()
+    with torch.no_grad():
+        for raw in scans[:n_scans]:
+            t = time.time()
+            p, l = oracle_ops.grid_subsample(raw, np.array([len(raw)]), VOXEL, impl=impl)
+            st = oracle_ops.precompute_data_stack_mode(p, l, NUM_STAGES, VOXEL, RADIUS, LIMITS, impl=impl)
+            t_pre += time.time() - t
+            t = time.time()
+            dd = {k: [torch.from_numpy(np.ascontiguousarray(x)) for x in v] for k, v in st.items()}
+            feats = torch_ref.kp_encoder(sd, torch.ones(len(p), 1), dd)
+            torch_ref.global_descriptor(sd, feats[-1])
+            t_enc += time.time() - t
+    dt = time.time() - t0
+    return {"value": round(n_scans / dt, 4), "unit": "scans/s", "cores": threads,
+            "kind": "reference" if impl == "ref" else "port",
+            "sample": "%d of the %d scans of this batch, end to end; native ops: %s (1 thread, %.2f s/scan); encoder+NetVLAD: torch fp32 "
+                      "restatement on %d threads (%.2f s/scan)" % (n_scans, BATCH, "reference C++ compiled from source (oracle/_ref)"
+                                                                    if impl == "ref" else "oracle C++ restatement", t_pre / n_scans,
+                                                                    threads, t_enc / n_scans)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from lcrnet_amd import functional as F
+    from lcrnet_amd.model_family import create_model
+    from lcrnet_amd.weights import seeded_state_dict
+    model = create_model().eval()
+    model.load_state_dict(seeded_state_dict(model.state_dict(), 7351))
+    model = model.to(dev)
+
+    scans = make_batch(rank)
+    raw_pts = torch.from_numpy(np.concatenate(scans)).to(dev)
+    raw_lens = torch.tensor([len(s) for s in scans], dtype=torch.int64, device=dev)
+    gathered = torch.empty((world * BATCH, 256), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def one():
+        with torch.no_grad():
+            desc, dd = step(model, raw_pts, raw_lens, upsampling=not args.no_upsampling)
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, desc.contiguous())
+        return desc, dd
+
+    for _ in range(args.warmup):
+        one()
+    # ---- timed region: exactly K steps between barrier + synchronize
+    timer = F.KernelTimer({"kpconv_aggregate", "gemm"})
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    F.set_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        desc, dd = one()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    F.set_timer(None)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        assert torch.isfinite(desc).all() and abs(float(desc.norm(dim=1).mean()) - 1.0) < 1e-3
+        # ---- roofline of the dominant kernel (measured live with HIP events on the launch stream)
+        summ = timer.summary()
+        agg = summ["kpconv_aggregate"]
+        t_agg = sum(t for t, _ in agg)
+        t_gemm = sum(t for t, _ in summ["gemm"])
+        # algorithmic bytes of one aggregate launch: indices + query/support xyz + support features + pos flags + the (M,15C) output
+        def agg_bytes(m):
+            M, Ns, H, C, isz = m
+            return M * H * isz + (M + Ns) * 12 + Ns * C * 4 + Ns + M * 15 * C * 4 + M * 4
+        bytes_agg = sum(agg_bytes(m) for _, m in agg)
+        roof = {"bound": "hbm", "kernel": "k_kpconv_aggregate (all 10 launches per step)",
+                "achieved": round(bytes_agg / t_agg / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(bytes_agg / t_agg / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_us": round(t_agg / max(len(agg), 1) * 1e6, 2),
+                "gemm_tflops": round(sum(2.0 * m[0] * m[1] * m[2] for _, m in summ["gemm"]) / max(t_gemm, 1e-9) / 1e12, 2),
+                "share_of_step": {"kpconv_aggregate": round(t_agg / dt, 3), "gemm": round(t_gemm / dt, 3)}}
+        line = {
+            "metric": "scans/s (120k-pt KITTI-shape scan -> 256-D descriptor)",
+            "value": round(world * BATCH * args.steps / dt, 3), "unit": "scans/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: batch of 8 synthetic 64-beam scans (~120k pts, 0.3 m voxel -> ~16k pts), "
+                                   "voxelise + 3 subsamples + %d radius searches + KPConv encoder + NetVLAD, seeded random weights"
+                                   % (7 if args.no_upsampling else 10),
+                       "scans_per_step_per_gpu": BATCH, "raw_points_per_scan": int(raw_pts.shape[0] // BATCH),
+                       "stage_points_per_batch": [sum(l) for l in dd["lengths_host"]], "neighbor_limits": LIMITS,
+                       "parallelism": "scan-parallel x%d, all-gather of descriptors" % world},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(scans)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -5,7 +5,8 @@
 hipcc cross-compiles without a GPU.  Objects go to csrc/_obj/, the library to lcr-net_amd/liblcr_hip.so
 (git-ignored, but it travels to the GPU box with the working tree).  -ffp-contract=off everywhere: the
 subsample / radius-search kernels must reproduce the reference's un-fused fp32 arithmetic bit for bit
-(SURVEY §7 "hard parts"); kernels that want FMA call fmaf / MFMA explicitly.
+(SURVEY §7 "hard parts"); kernels that want FMA call fmaf / MFMA explicitly.  -munsafe-fp-atomics: hardware
+fp64/fp32 atomic adds (global_atomic_add_f64 / ds_add_f64) instead of CAS loops for the GroupNorm statistics.
 """
 import concurrent.futures as cf
 import glob
@@ -18,7 +19,7 @@ PKG = os.path.dirname(HERE)
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(PKG, "liblcr_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-munsafe-fp-atomics",
          "-Wno-unused-value", "-Wno-unused-result"]
 
 

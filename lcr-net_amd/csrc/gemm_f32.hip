@@ -6,17 +6,18 @@
 // (kpconv.py:108-110: (M, 15*C) x (15*C, Cout), TB=0), NetVLAD's assignment / aggregation GEMMs (TA=1 for x^T·a).
 // fp32 in, fp32 accumulate: bf16 would break the 1e-4 descriptor tolerance.
 //
-// Tiling: 256 threads = 4 wavefronts stacked along M; block tile 128 x BN x 32; each wavefront owns 32 rows x BN columns
-// = BN/32 accumulators of 16 VGPRs.  Operands are staged through LDS K-major (As[k][m], Bs[k][n]) so that an MFMA
-// operand fetch is one conflict-free ds_read_b32 per lane; global loads are 16-B vectors, double-buffered in LDS with
-// register prefetch (one barrier per K-step).
+// Tiling: 256 threads = 4 wavefronts arranged WM x WN; block tile BM x BN x 32; every wavefront owns 32 rows x (BN/WN)
+// columns = NT accumulators of 16 registers.  Operands are staged through LDS K-major (As[k][m], Bs[k][n]) so an MFMA
+// operand fetch is one conflict-free ds_read_b32 per lane.  Because the fp32 MFMA is slow (64 cycles per 4 KFLOP) the
+// only thing that matters is never exposing a latency: global loads are branch-free 16-B vectors issued one K-step ahead
+// into registers (double-buffered LDS, one barrier per K-step), LDS fragments are prefetched one MFMA group ahead, and the
+// tile shape is chosen so that >= ~400 workgroups exist (two per CU) even for the short-M stages.
 #include "common.h"
 
 namespace lcr {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int GM_BM = 128;
 constexpr int GM_BK = 32;
 constexpr int GM_T = 256;
 
@@ -29,31 +30,35 @@ struct GemmEpilogue {
   double*        stats;     // [S, groups, 2] (sum, sumsq), accumulated atomically; null = no statistics
 };
 
-// rows x 32 tile of a row-major [rows_total x K] matrix -> S[k][r]   (transposing loader; src contiguous along k)
-template <int R, int LD>
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// R x 32 tile of a row-major [rows_total x K] matrix -> S[k][r]   (transposing loader; src contiguous along k).
+// Branch-free: out-of-range pieces read a valid clamped address and are zeroed by a select.
+template <int R, int LD, bool VEC>
 struct LoaderT {
   static constexpr int PIECES = R * 8 / GM_T;   // float4 pieces per thread
   float4 reg[PIECES];
-  __device__ __forceinline__ void load(const float* __restrict__ src, int64_t rows_total, int K, int64_t r0, int k0, bool vec) {
+  __device__ __forceinline__ void load(const float* __restrict__ src, int64_t rows_total, int K, int64_t r0, int k0) {
 #pragma unroll
     for (int j = 0; j < PIECES; ++j) {
       const int f = threadIdx.x + GM_T * j;
       const int row = f >> 3, c4 = f & 7;
-      const int64_t gr = r0 + row;
+      int64_t gr = r0 + row;
+      gr = gr < rows_total ? gr : rows_total - 1;          // duplicate rows only feed outputs that are never stored
       const int gk = k0 + c4 * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gr < rows_total) {
-        const float* p = src + gr * K + gk;
-        if (vec && gk + 3 < K) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (gk + 0 < K) v.x = p[0];
-          if (gk + 1 < K) v.y = p[1];
-          if (gk + 2 < K) v.z = p[2];
-          if (gk + 3 < K) v.w = p[3];
-        }
+      if (VEC) {
+        const bool ok = gk < K;                               // K % 4 == 0: a piece is entirely in or out
+        float4 v = ld4(src + gr * K + (ok ? gk : 0));
+        reg[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        const float* p = src + gr * K;
+        float4 v;
+        v.x = gk + 0 < K ? p[gk + 0] : 0.f;
+        v.y = gk + 1 < K ? p[gk + 1] : 0.f;
+        v.z = gk + 2 < K ? p[gk + 2] : 0.f;
+        v.w = gk + 3 < K ? p[gk + 3] : 0.f;
+        reg[j] = v;
       }
-      reg[j] = v;
     }
   }
   __device__ __forceinline__ void store(float* __restrict__ S) const {
@@ -70,30 +75,31 @@ struct LoaderT {
 };
 
 // 32 x W tile of a row-major [K x cols_total] matrix -> S[k][c]   (straight loader; src contiguous along c)
-template <int W, int LD>
+template <int W, int LD, bool VEC>
 struct LoaderN {
   static constexpr int PIECES = 8 * W / GM_T;
   float4 reg[PIECES];
-  __device__ __forceinline__ void load(const float* __restrict__ src, int64_t cols_total, int K, int64_t c0, int k0, bool vec) {
+  __device__ __forceinline__ void load(const float* __restrict__ src, int64_t cols_total, int K, int64_t c0, int k0) {
 #pragma unroll
     for (int j = 0; j < PIECES; ++j) {
       const int f = threadIdx.x + GM_T * j;
       const int kr = f / (W / 4), c4 = f % (W / 4);
       const int gk = k0 + kr;
       const int64_t gc = c0 + c4 * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gk < K) {
-        const float* p = src + static_cast<int64_t>(gk) * cols_total + gc;
-        if (vec && gc + 3 < cols_total) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (gc + 0 < cols_total) v.x = p[0];
-          if (gc + 1 < cols_total) v.y = p[1];
-          if (gc + 2 < cols_total) v.z = p[2];
-          if (gc + 3 < cols_total) v.w = p[3];
-        }
+      const bool kok = gk < K;
+      const float* p = src + static_cast<int64_t>(kok ? gk : 0) * cols_total;
+      if (VEC) {
+        const bool ok = kok && gc < cols_total;              // cols_total % 4 == 0
+        float4 v = ld4(p + (gc < cols_total ? gc : 0));
+        reg[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        float4 v;
+        v.x = (kok && gc + 0 < cols_total) ? p[gc + 0] : 0.f;
+        v.y = (kok && gc + 1 < cols_total) ? p[gc + 1] : 0.f;
+        v.z = (kok && gc + 2 < cols_total) ? p[gc + 2] : 0.f;
+        v.w = (kok && gc + 3 < cols_total) ? p[gc + 3] : 0.f;
+        reg[j] = v;
       }
-      reg[j] = v;
     }
   }
   __device__ __forceinline__ void store(float* __restrict__ S) const {
@@ -116,34 +122,31 @@ __device__ __forceinline__ int seg_of_row(const int64_t* __restrict__ seg_len, i
   return s;
 }
 
-template <int BN, bool TA, bool TB>
-__global__ __launch_bounds__(GM_T) void k_gemm_f32(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
-                                                    int64_t M, int N, int K, GemmEpilogue ep) {
-  constexpr int LDA = TA ? GM_BM + 4 : GM_BM + 1;
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC>
+__global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                       int64_t M, int N, int K, GemmEpilogue ep) {
+  static_assert(WM * WN == 4 && BM == 32 * WM, "one 32-row MFMA tile per wavefront along M");
+  constexpr int LDA = TA ? BM + 4 : BM + 1;
   constexpr int LDB = TB ? BN + 1 : BN + 4;
-  constexpr int NT = BN / 32;
+  constexpr int NT = BN / (32 * WN);
   __shared__ __attribute__((aligned(16))) float As[2][GM_BK * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[2][GM_BK * LDB];
-  __shared__ double s_red[BN][2];
 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * GM_BM;
+  const int wm = w / WN, wn = w % WN;
+  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * BM;
   const int n0 = blockIdx.y * BN;
 
-  // 16-byte vector loads need an aligned leading dimension (and base: torch allocations are 256-B aligned)
-  const bool vecA = TA ? ((M & 3) == 0) : ((K & 3) == 0);
-  const bool vecB = TB ? ((K & 3) == 0) : ((N & 3) == 0);
-
-  LoaderT<GM_BM, LDA> la_t;
-  LoaderN<GM_BM, LDA> la_n;
-  LoaderT<BN, LDB>    lb_t;
-  LoaderN<BN, LDB>    lb_n;
+  LoaderT<BM, LDA, VEC> la_t;
+  LoaderN<BM, LDA, VEC> la_n;
+  LoaderT<BN, LDB, VEC> lb_t;
+  LoaderN<BN, LDB, VEC> lb_n;
 
   auto gload = [&](int k0) {
-    if (TA) la_n.load(A, M, K, m0, k0, vecA);
-    else la_t.load(A, M, K, m0, k0, vecA);
-    if (TB) lb_t.load(B, N, K, n0, k0, vecB);
-    else lb_n.load(B, N, K, n0, k0, vecB);
+    if (TA) la_n.load(A, M, K, m0, k0);
+    else la_t.load(A, M, K, m0, k0);
+    if (TB) lb_t.load(B, N, K, n0, k0);
+    else lb_n.load(B, N, K, n0, k0);
   };
   auto sstore = [&](int buf) {
     if (TA) la_n.store(As[buf]);
@@ -162,21 +165,28 @@ __global__ __launch_bounds__(GM_T) void k_gemm_f32(const float* __restrict__ A, 
   gload(0);
   sstore(0);
   __syncthreads();
-  const int a_off = (lane >> 5) * LDA + w * 32 + (lane & 31);
-  const int b_off = (lane >> 5) * LDB + (lane & 31);
+  const int a_off = (lane >> 5) * LDA + wm * 32 + (lane & 31);
+  const int b_off = (lane >> 5) * LDB + wn * (32 * NT) + (lane & 31);
   for (int t = 0; t < nk; ++t) {
     const int buf = t & 1;
-    if (t + 1 < nk) gload((t + 1) * GM_BK);
-    const float* as = As[buf];
-    const float* bs = Bs[buf];
+    if (t + 1 < nk) gload((t + 1) * GM_BK);     // lands in registers while this K-step's MFMAs run
+    const float* as = As[buf] + a_off;
+    const float* bs = Bs[buf] + b_off;
+    // fragments prefetched one MFMA group ahead (explicit register double buffer)
+    float af[2], bf[2][NT];
+    af[0] = as[0];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bf[0][j] = bs[j * 32];
 #pragma unroll
     for (int kk = 0; kk < GM_BK / 2; ++kk) {
-      const float a = as[kk * 2 * LDA + a_off];
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < GM_BK / 2) {
+        af[nxt] = as[(kk + 1) * 2 * LDA];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const float b = bs[kk * 2 * LDB + b_off + j * 32];
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) bf[nxt][j] = bs[(kk + 1) * 2 * LDB + j * 32];
       }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur], bf[cur][j], acc[j], 0, 0, 0);
     }
     if (t + 1 < nk) sstore(buf ^ 1);
     __syncthreads();
@@ -185,92 +195,83 @@ __global__ __launch_bounds__(GM_T) void k_gemm_f32(const float* __restrict__ A, 
   // ---- epilogue -------------------------------------------------------------------------------------------------
   const bool want_stats = ep.stats != nullptr;
   const int gs = want_stats ? N / ep.groups : 1;   // channels per group
-  if (want_stats) {
-    for (int i = threadIdx.x; i < BN * 2; i += GM_T) (&s_red[0][0])[i] = 0.0;
-    __syncthreads();
-  }
-  const int64_t wrow0 = m0 + w * 32;
-  int seg_first = 0, seg_last = 0;
-  if (want_stats && wrow0 < M) {
-    seg_first = seg_of_row(ep.seg_len, ep.S, wrow0);
-    seg_last = seg_of_row(ep.seg_len, ep.S, min(wrow0 + 31, M - 1));
-  }
-  // all rows of the BLOCK in one segment?  (block-uniform decision so the LDS reduction below is valid)
-  int blk_seg_first = 0, blk_seg_last = 0;
-  if (want_stats) {
-    blk_seg_first = seg_of_row(ep.seg_len, ep.S, m0);
-    blk_seg_last = seg_of_row(ep.seg_len, ep.S, min(m0 + GM_BM - 1, M - 1));
-  }
-  const bool uniform_seg = blk_seg_first == blk_seg_last;
-  (void)seg_first;
-  (void)seg_last;
+  const int64_t wrow0 = m0 + wm * 32;
 
+  // store (and keep the final values in the accumulators for the statistics pass)
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int col = n0 + j * 32 + (lane & 31);
+    const int col = n0 + wn * (32 * NT) + j * 32 + (lane & 31);
     const float bv = (ep.bias && col < N) ? ep.bias[col] : 0.f;
-    float s = 0.f, ss = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row < M && col < N) {
-        float v = acc[j][r];
+      float v = acc[j][r];
+      if (row < M) {
         if (ep.rowdiv) v = v / ep.rowdiv[row];
         v += bv;
-        C[row * N + col] = v;
-        if (want_stats) {
-          if (uniform_seg) {
-            s += v;
-            ss = fmaf(v, v, ss);
-          } else {
-            const int sg = seg_of_row(ep.seg_len, ep.S, row);
-            double* d = ep.stats + (static_cast<int64_t>(sg) * ep.groups + col / gs) * 2;
-            atomicAdd(d, static_cast<double>(v));
-            atomicAdd(d + 1, static_cast<double>(v) * static_cast<double>(v));
-          }
-        }
+        if (col < N) C[row * N + col] = v;
+      } else {
+        v = 0.f;
       }
-    }
-    if (want_stats && uniform_seg) {
-      double ds = s, dss = ss;
-      // fold the two row-halves, then the lanes of one group (gs consecutive columns, capped at the 32-column tile)
-      ds += __shfl_xor(ds, 32);
-      dss += __shfl_xor(dss, 32);
-      const int span = gs < 32 ? gs : 32;
-      for (int d = 1; d < span; d <<= 1) {
-        ds += __shfl_xor(ds, d);
-        dss += __shfl_xor(dss, d);
-      }
-      if (lane < 32 && (lane & (span - 1)) == 0 && col < N) {
-        const int gl = (col - n0) / gs;   // group index local to this block's column range
-        atomicAdd(&s_red[gl][0], ds);
-        atomicAdd(&s_red[gl][1], dss);
-      }
+      acc[j][r] = v;
     }
   }
-  if (want_stats && uniform_seg) {
-    __syncthreads();
-    const int ngl = (BN + gs - 1) / gs;
-    for (int i = threadIdx.x; i < ngl; i += GM_T) {
-      const int g = n0 / gs + i;
-      if (g < ep.groups && (n0 + i * gs) < N) {
-        double* d = ep.stats + (static_cast<int64_t>(blk_seg_first) * ep.groups + g) * 2;
-        atomicAdd(d, s_red[i][0]);
-        atomicAdd(d + 1, s_red[i][1]);
+
+  // GroupNorm statistics: per wavefront, per segment present in its 32 rows (one, except at the B-1 segment boundaries)
+  if (want_stats && wrow0 < M) {
+    const int64_t wlast = min(wrow0 + 31, M - 1);
+    int sg = 0;
+    int64_t seg_start = 0, seg_end = ep.seg_len[0];
+    while (sg + 1 < ep.S && wrow0 >= seg_end) {
+      ++sg;
+      seg_start = seg_end;
+      seg_end += ep.seg_len[sg];
+    }
+    while (true) {   // wave-uniform loop over the segments that intersect [wrow0, wlast]
+      const bool whole = seg_start <= wrow0 && wlast < seg_end;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int col = n0 + wn * (32 * NT) + j * 32 + (lane & 31);
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const float v = (whole || (row >= seg_start && row < seg_end)) ? acc[j][r] : 0.f;
+          s += v;
+          ss = fmaf(v, v, ss);
+        }
+        double ds = s, dss = ss;
+        // fold the two row-halves, then the lanes of one group (gs consecutive columns, capped at the 32-column tile)
+        ds += __shfl_xor(ds, 32);
+        dss += __shfl_xor(dss, 32);
+        const int span = gs < 32 ? gs : 32;
+        for (int d = 1; d < span; d <<= 1) {
+          ds += __shfl_xor(ds, d);
+          dss += __shfl_xor(dss, d);
+        }
+        if (lane < 32 && (lane & (span - 1)) == 0 && col < N) {
+          double* d = ep.stats + (static_cast<int64_t>(sg) * ep.groups + col / gs) * 2;
+          atomicAdd(d, ds);
+          atomicAdd(d + 1, dss);
+        }
       }
+      if (wlast < seg_end || sg + 1 >= ep.S) break;
+      ++sg;
+      seg_start = seg_end;
+      seg_end += ep.seg_len[sg];
     }
   }
 }
 
-template <int BN>
+template <int BM, int BN, int WM, int WN, bool VEC>
 static int launch_gemm(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB, const GemmEpilogue& ep,
                        hipStream_t st) {
-  dim3 grid(div_up(M, GM_BM), div_up(N, BN));
+  dim3 grid(div_up(M, BM), div_up(N, BN));
   dim3 block(GM_T);
-  if (!transA && !transB) hipLaunchKernelGGL((k_gemm_f32<BN, false, false>), grid, block, 0, st, A, B, C, M, N, K, ep);
-  else if (!transA && transB) hipLaunchKernelGGL((k_gemm_f32<BN, false, true>), grid, block, 0, st, A, B, C, M, N, K, ep);
-  else if (transA && !transB) hipLaunchKernelGGL((k_gemm_f32<BN, true, false>), grid, block, 0, st, A, B, C, M, N, K, ep);
-  else hipLaunchKernelGGL((k_gemm_f32<BN, true, true>), grid, block, 0, st, A, B, C, M, N, K, ep);
+  if (!transA && !transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, false, false, VEC>), grid, block, 0, st, A, B, C, M, N, K, ep);
+  else if (!transA && transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, false, true, VEC>), grid, block, 0, st, A, B, C, M, N, K, ep);
+  else if (transA && !transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, true, false, VEC>), grid, block, 0, st, A, B, C, M, N, K, ep);
+  else hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, true, true, VEC>), grid, block, 0, st, A, B, C, M, N, K, ep);
   return check_launch("lcr_gemm_f32");
 }
 
@@ -290,7 +291,7 @@ extern "C" int lcr_gemm_f32(const float* A, const float* B, float* C, int64_t M,
   }
   if (stats) {
     const int gs = N / groups;
-    if ((gs & (gs - 1)) != 0 || (gs < 32 && 32 % gs != 0) || (gs > 32 && gs % 32 != 0)) {
+    if ((gs & (gs - 1)) != 0) {
       set_error("lcr_gemm_f32: channels per group must be a power of two");
       return LCR_EARG;
     }
@@ -299,7 +300,20 @@ extern "C" int lcr_gemm_f32(const float* A, const float* B, float* C, int64_t M,
   if (stats) hipMemsetAsync(stats, 0, sizeof(double) * 2 * S * groups, st);
   if (M == 0) return LCR_OK;
   GemmEpilogue ep{bias, rowdiv, seg_len, S, groups, stats};
-  if (N <= 32) return launch_gemm<32>(A, B, C, M, N, K, transA, transB, ep, st);
-  if (N <= 64) return launch_gemm<64>(A, B, C, M, N, K, transA, transB, ep, st);
-  return launch_gemm<128>(A, B, C, M, N, K, transA, transB, ep, st);
+  // 16-byte vector loads need leading dimensions that are multiples of 4 floats (bases: torch allocations are >= 256-B aligned,
+  // row offsets inside them are multiples of the leading dimension)
+  const int64_t lda = transA ? M : K, ldb = transB ? K : N;
+  const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (reinterpret_cast<uintptr_t>(B) % 16 == 0);
+  if (!vec) return launch_gemm<128, 64, 4, 1, false>(A, B, C, M, N, K, transA, transB, ep, st);
+  constexpr int64_t ENOUGH = 384;   // workgroups wanted before a bigger tile is worth it (256 CUs, 2 resident per CU)
+  const int64_t b128 = (M + 127) / 128, b64 = (M + 63) / 64;
+  if (N <= 32) return launch_gemm<128, 32, 4, 1, true>(A, B, C, M, N, K, transA, transB, ep, st);
+  if (N <= 64) {
+    if (b128 >= ENOUGH) return launch_gemm<128, 64, 4, 1, true>(A, B, C, M, N, K, transA, transB, ep, st);
+    return launch_gemm<64, 64, 2, 2, true>(A, B, C, M, N, K, transA, transB, ep, st);
+  }
+  const int64_t nb128 = (N + 127) / 128;
+  if (b128 * nb128 >= ENOUGH) return launch_gemm<128, 128, 4, 1, true>(A, B, C, M, N, K, transA, transB, ep, st);
+  if (b64 * nb128 >= ENOUGH) return launch_gemm<64, 128, 2, 2, true>(A, B, C, M, N, K, transA, transB, ep, st);
+  return launch_gemm<64, 64, 2, 2, true>(A, B, C, M, N, K, transA, transB, ep, st);
 }

@@ -135,17 +135,7 @@ __global__ void k_gs_init(GsHeader* h, const int64_t* __restrict__ len, int B, i
 }
 
 __global__ __launch_bounds__(256) void k_gs_bbox(GsHeader* h, const float* __restrict__ xyz) {
-  const int B = h->B;
-  const int64_t n = h->rx.n;
-  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-    const int b = cloud_of(h->in_off, B, i);
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const uint32_t u = f2ord(xyz[3 * i + d]);
-      if (u < h->bb_min[b][d]) atomicMin(&h->bb_min[b][d], u);
-      if (u > h->bb_max[b][d]) atomicMax(&h->bb_max[b][d], u);
-    }
-  }
+  bbox_accumulate(xyz, h->rx.n, h->in_off, h->B, h->bb_min, h->bb_max);
 }
 
 __device__ __forceinline__ int bits_of(uint64_t v) { return v ? 64 - __clzll(static_cast<long long>(v)) : 0; }
@@ -238,14 +228,38 @@ __global__ __launch_bounds__(256) void k_gs_reduce(GsHeader* h, const float* __r
     float sx = 0.f, sy = 0.f, sz = 0.f;
     int cnt = 0;
     int64_t j = i;
-    do {
-      const uint32_t r = v[j];
-      sx = fadd(sx, xyz[3 * r + 0]);
-      sy = fadd(sy, xyz[3 * r + 1]);
-      sz = fadd(sz, xyz[3 * r + 2]);
-      ++cnt;
-      ++j;
-    } while (j < n && k[j] == key);
+    // runs are walked in chunks of 8: the key / index / coordinate loads of a chunk are independent (issued together),
+    // only the fp32 additions are serial — they must be, the order is part of the contract
+    bool more = true;
+    while (more) {
+      bool in_run[8];
+      uint32_t r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t ju = j + u;
+        in_run[u] = ju < n && k[ju < n ? ju : n - 1] == key;
+        r[u] = v[ju < n ? ju : n - 1];
+      }
+      float px[8], py[8], pz[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        px[u] = xyz[3 * static_cast<int64_t>(r[u]) + 0];
+        py[u] = xyz[3 * static_cast<int64_t>(r[u]) + 1];
+        pz[u] = xyz[3 * static_cast<int64_t>(r[u]) + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (more && in_run[u]) {
+          sx = fadd(sx, px[u]);
+          sy = fadd(sy, py[u]);
+          sz = fadd(sz, pz[u]);
+          ++cnt;
+        } else {
+          more = false;
+        }
+      }
+      j += 8;
+    }
     const float rc = static_cast<float>(1.0 / static_cast<double>(cnt));
     bary[3 * seg + 0] = fmul(sx, rc);
     bary[3 * seg + 1] = fmul(sy, rc);

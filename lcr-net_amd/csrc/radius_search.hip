@@ -92,18 +92,8 @@ __global__ void k_grid_init(GridHeader* h, const int64_t* __restrict__ slen, int
 }
 
 __global__ __launch_bounds__(256) void k_grid_bbox(GridHeader* h, const float* __restrict__ s) {
-  const int B = h->B;
-  const int64_t n = min(h->ns_total, h->ns_cap);
-  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-    const int b = cloud_of(h->s_off, B, i);
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const uint32_t u = f2ord(s[3 * i + d]);
-      // cheap filter before the atomic: most points are not on the hull
-      if (u < h->bb_min[b][d]) atomicMin(&h->bb_min[b][d], u);
-      if (u > h->bb_max[b][d]) atomicMax(&h->bb_max[b][d], u);
-    }
-  }
+  const int64_t n = h->ns_total < h->ns_cap ? h->ns_total : h->ns_cap;
+  bbox_accumulate(s, n, h->s_off, h->B, h->bb_min, h->bb_max);
 }
 
 __global__ void k_grid_params(GridHeader* h, float radius) {

@@ -10,6 +10,43 @@ from . import _lib
 GN_EPS = 1e-5
 
 
+class KernelTimer:
+    """Opt-in per-op timing with HIP events on the launch stream (bench.py's roofline leg).  `names`: ops to time, e.g.
+    {"kpconv_aggregate"}; each timed call records (start, stop) events around its launches; `.summary()` synchronises."""
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.events = {n: [] for n in self.names}
+        self.meta = {n: [] for n in self.names}
+
+    def wrap(self, name, fn, meta=None):
+        if name not in self.names:
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = fn()
+        b.record()
+        self.events[name].append((a, b))
+        self.meta[name].append(meta)
+        return out
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return {n: [(a.elapsed_time(b) * 1e-3, m) for (a, b), m in zip(ev, self.meta[n])] for n, ev in self.events.items()}
+
+
+_TIMER = None
+
+
+def set_timer(timer):
+    global _TIMER
+    _TIMER = timer
+
+
+def _timed(name, fn, meta=None):
+    return fn() if _TIMER is None else _TIMER.wrap(name, fn, meta)
+
+
 def _seg(seg_len, n, device):
     """GroupNorm segment lengths: None = the reference's behaviour (one segment = the whole stack)."""
     if seg_len is None:
@@ -40,9 +77,10 @@ def gemm(a, b, trans_b=False, trans_a=False, bias=None, rowdiv=None, seg_len=Non
         seg_len = _seg(seg_len, M, a.device)
         S = seg_len.numel()
         stats = torch.empty((S, groups, 2), dtype=torch.float64, device=a.device)
-    _lib.check(_lib.lib().lcr_gemm_f32(_lib.ptr(a), _lib.ptr(b), _lib.ptr(c), M, N, K, int(trans_a), int(trans_b), _lib.ptr(bias),
-                                       _lib.ptr(rowdiv), _lib.ptr(seg_len) if groups else None, S, int(groups), _lib.ptr(stats),
-                                       _lib.stream_ptr(a.device)), "lcr_gemm_f32")
+    _timed("gemm", lambda: _lib.check(_lib.lib().lcr_gemm_f32(
+        _lib.ptr(a), _lib.ptr(b), _lib.ptr(c), M, N, K, int(trans_a), int(trans_b), _lib.ptr(bias), _lib.ptr(rowdiv),
+        _lib.ptr(seg_len) if groups else None, S, int(groups), _lib.ptr(stats), _lib.stream_ptr(a.device)), "lcr_gemm_f32"),
+        meta=(M, N, K))
     return c, stats
 
 
@@ -88,9 +126,10 @@ def kpconv_aggregate(s_feats, s_pos, q_points, s_points, idx, kernel_points_host
     A = torch.empty((M, 15 * C), dtype=torch.float32, device=s_feats.device)
     nn = torch.empty((M,), dtype=torch.float32, device=s_feats.device)
     kp = _kp_host(kernel_points_host)
-    _lib.check(_lib.lib().lcr_kpconv_aggregate(_lib.ptr(s_feats), _lib.ptr(s_pos), _lib.ptr(q_points), _lib.ptr(s_points), _lib.ptr(idx),
-                                               _idx_args(idx), M, Ns, H, C, ctypes.c_void_p(kp.ctypes.data), float(sigma), _lib.ptr(A),
-                                               _lib.ptr(nn), _lib.stream_ptr(s_feats.device)), "lcr_kpconv_aggregate")
+    _timed("kpconv_aggregate", lambda: _lib.check(_lib.lib().lcr_kpconv_aggregate(
+        _lib.ptr(s_feats), _lib.ptr(s_pos), _lib.ptr(q_points), _lib.ptr(s_points), _lib.ptr(idx), _idx_args(idx), M, Ns, H, C,
+        ctypes.c_void_p(kp.ctypes.data), float(sigma), _lib.ptr(A), _lib.ptr(nn), _lib.stream_ptr(s_feats.device)),
+        "lcr_kpconv_aggregate"), meta=(M, Ns, H, C, idx.element_size()))
     return A, nn
 
 

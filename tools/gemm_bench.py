@@ -1,0 +1,43 @@
+"""Micro-benchmark of lcr_gemm_f32 on the encoder's shapes (batch of 8 scans): TFLOP/s per launch, HIP events."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lcrnet_amd import functional as F  # noqa: E402
+
+SHAPES = [  # (tag, M, N, K, transB, stats, rowdiv)
+    ("1_2 unary1", 128000, 32, 64, 1, 1, 0), ("1_2 kpconv", 128000, 32, 480, 0, 1, 1), ("1_2 unary2", 128000, 128, 32, 1, 1, 0),
+    ("1_2 shortcut", 128000, 128, 64, 1, 1, 0), ("2_2 kpconv", 51000, 64, 960, 0, 1, 1), ("2_2 unary2", 51000, 256, 64, 1, 1, 0),
+    ("3_2 kpconv", 19000, 128, 1920, 0, 1, 1), ("3_2 unary2", 19000, 512, 128, 1, 1, 0), ("4_2 kpconv", 6500, 256, 3840, 0, 1, 1),
+    ("4_2 unary2", 6500, 1024, 256, 1, 1, 0), ("4_3 unary1", 6500, 256, 1024, 1, 1, 0), ("netvlad assign", 6500, 64, 1024, 0, 0, 0),
+    ("big square", 8192, 1024, 1024, 0, 0, 0),
+]
+
+
+def main():
+    dev = torch.device("cuda")
+    for tag, M, N, K, tb, stats, rd in SHAPES:
+        a = torch.randn(M, K, device=dev)
+        b = torch.randn((N, K) if tb else (K, N), device=dev)
+        bias = torch.randn(N, device=dev)
+        div = torch.rand(M, device=dev) + 1 if rd else None
+        seg = torch.tensor([M // 8] * 7 + [M - 7 * (M // 8)], dtype=torch.int64, device=dev)
+        kw = dict(trans_b=bool(tb), bias=bias, rowdiv=div, seg_len=seg if stats else None, groups=32 if stats else 0)
+        for _ in range(3):
+            F.gemm(a, b, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        reps = 20
+        for _ in range(reps):
+            F.gemm(a, b, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / reps * 1e-3
+        print(f"{tag:16s} M={M:7d} N={N:5d} K={K:5d}  {t*1e6:9.1f} us  {2.0*M*N*K/t/1e12:7.2f} TFLOP/s  A-stream {M*K*4/t/1e9:8.1f} GB/s")
+
+
+if __name__ == "__main__":
+    main()
