@@ -132,6 +132,17 @@ int lcr_netvlad_ws_bytes(int64_t n_rows, int S, size_t* bytes);
 int lcr_netvlad_forward(const float* feats /*[sum(seg_len),1024]*/, const int64_t* seg_len_host, int S,
                         const LcrNetvladWeights* weights_host, float* out /*[S,256]*/, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * a-9  descriptor retrieval: exhaustive squared-L2 top-k with the temporal exclusion window — replaces the per-query
+ *      faiss IndexIVFFlat(nlist=1) loop of experiments/loop_detection/eval_loop_detection_overlap_dataset.py:183-214.
+ * Query row r is global frame q0+r; its database is frames [0, q0+r-exclude).  Rows ascending in (d2, index); short rows
+ * are padded with (-1, +inf).  k <= 128.
+ * ------------------------------------------------------------------------------------------------ */
+int lcr_retrieval_ws_bytes(int64_t Q, int64_t C, size_t* bytes);
+int lcr_retrieval_topk(const float* queries /*[Q,D]*/, int64_t Q, int64_t q0, const float* database /*[C,D]*/, int64_t C,
+                       int D, int k, int exclude, int32_t* out_idx /*[Q,k]*/, float* out_d2 /*[Q,k]*/,
+                       void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,7 @@ struct GsLayout {
   float*    bary;        // [n,3] barycentre per segment
   uint64_t* seg_key;     // [n]
   uint32_t* seg_first;   // [n]
+  int32_t*  seg_start;   // [n]   first sorted position of every run
   uint64_t* ins_key;     // [n]   keys in insertion (first-occurrence) order, per cloud at out_off[b]
   int32_t*  ins_seg;     // [n]
   int32_t*  hm_t;        // [n]   timestamps / positions
@@ -91,6 +92,7 @@ static GsLayout gs_layout(void* ws, int64_t n_cap, int B) {
   L.bary = c.take<float>(3 * n);
   L.seg_key = c.take<uint64_t>(n);
   L.seg_first = c.take<uint32_t>(n);
+  L.seg_start = c.take<int32_t>(n);
   L.ins_key = c.take<uint64_t>(n);
   L.ins_seg = c.take<int32_t>(n);
   L.hm_t = c.take<int32_t>(n);
@@ -211,35 +213,36 @@ __global__ __launch_bounds__(256) void k_gs_heads(const GsHeader* __restrict__ h
     head[i] = (i < n && (i == 0 || k[i] != k[i - 1])) ? 1 : 0;
 }
 
+__global__ __launch_bounds__(256) void k_gs_seg_starts(const GsHeader* __restrict__ h, const int32_t* __restrict__ head_scan,
+                                                       int32_t* __restrict__ seg_start) {
+  const int64_t n = h->rx.n;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    if (head_scan[i + 1] != head_scan[i]) seg_start[head_scan[i]] = static_cast<int32_t>(i);
+}
+
 // one lane per voxel run: in-order fp32 sums (.h:17-20), barycentre = sum * float(1.0 / count) (:46)
 __global__ __launch_bounds__(256) void k_gs_reduce(GsHeader* h, const float* __restrict__ xyz, const uint64_t* __restrict__ kA,
                                                    const uint64_t* __restrict__ kB, const uint32_t* __restrict__ vA,
                                                    const uint32_t* __restrict__ vB, const int32_t* __restrict__ head_scan,
-                                                   float* __restrict__ bary, uint64_t* __restrict__ seg_key,
-                                                   uint32_t* __restrict__ seg_first, int32_t* __restrict__ first_flag) {
+                                                   const int32_t* __restrict__ seg_start, float* __restrict__ bary,
+                                                   uint64_t* __restrict__ seg_key, uint32_t* __restrict__ seg_first,
+                                                   int32_t* __restrict__ first_flag) {
   const int64_t n = h->rx.n;
+  const int64_t nseg = n > 0 ? head_scan[n] : 0;   // exclusive scan of the head flags: total at index n
   const uint64_t* k = sorted_keys(h, kA, kB);
   const uint32_t* v = sorted_vals(h, vA, vB);
   const int kbits = h->kbits;
-  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-    const int seg = head_scan[i];
-    if (head_scan[i + 1] == seg) continue;   // not a run head (exclusive scan of the flags: head <=> next value differs)
+  for (int64_t seg = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; seg < nseg; seg += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t i = seg_start[seg];
+    const int64_t end = seg + 1 < nseg ? seg_start[seg + 1] : n;   // runs are contiguous in the sorted order
     const uint64_t key = k[i];
     float sx = 0.f, sy = 0.f, sz = 0.f;
-    int cnt = 0;
-    int64_t j = i;
-    // runs are walked in chunks of 8: the key / index / coordinate loads of a chunk are independent (issued together),
-    // only the fp32 additions are serial — they must be, the order is part of the contract
-    bool more = true;
-    while (more) {
-      bool in_run[8];
+    // chunks of 8: the index / coordinate loads of a chunk are independent (issued together), only the fp32 additions
+    // are serial — they must be, the order is part of the contract
+    for (int64_t j = i; j < end; j += 8) {
       uint32_t r[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int64_t ju = j + u;
-        in_run[u] = ju < n && k[ju < n ? ju : n - 1] == key;
-        r[u] = v[ju < n ? ju : n - 1];
-      }
+      for (int u = 0; u < 8; ++u) r[u] = v[j + u < end ? j + u : end - 1];
       float px[8], py[8], pz[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -249,17 +252,14 @@ __global__ __launch_bounds__(256) void k_gs_reduce(GsHeader* h, const float* __r
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        if (more && in_run[u]) {
+        if (j + u < end) {
           sx = fadd(sx, px[u]);
           sy = fadd(sy, py[u]);
           sz = fadd(sz, pz[u]);
-          ++cnt;
-        } else {
-          more = false;
         }
       }
-      j += 8;
     }
+    const int cnt = static_cast<int>(end - i);
     const float rc = static_cast<float>(1.0 / static_cast<double>(cnt));
     bary[3 * seg + 0] = fmul(sx, rc);
     bary[3 * seg + 1] = fmul(sy, rc);
@@ -269,14 +269,18 @@ __global__ __launch_bounds__(256) void k_gs_reduce(GsHeader* h, const float* __r
     const uint32_t f = v[i];   // stable sort => first element of the run is the first occurrence
     seg_first[seg] = f;
     first_flag[f] = 1;
-    atomicAdd(&h->M[b], 1);
+    (void)b;
   }
 }
 
-__global__ void k_gs_offsets(GsHeader* h, int64_t* __restrict__ out_len) {
+__global__ void k_gs_offsets(GsHeader* h, const int32_t* __restrict__ head_scan, int64_t* __restrict__ out_len) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   int64_t o = 0;
   for (int b = 0; b < h->B; ++b) {
+    // the sort key carries the cloud id in its top bits, so cloud b owns sorted positions [in_off[b], in_off[b+1]) and its
+    // number of distinct voxels is the number of run heads in that range (no per-run atomics)
+    const int64_t lo = min(h->in_off[b], h->rx.n), hi = min(h->in_off[b + 1], h->rx.n);
+    h->M[b] = head_scan ? head_scan[hi] - head_scan[lo] : 0;
     h->out_off[b] = o;
     out_len[b] = h->M[b];
     o += h->M[b];
@@ -448,7 +452,7 @@ extern "C" int lcr_grid_subsample_ex(const float* xyz, const int64_t* len, int B
   const int nblk = n_cap > 0 ? min(div_up(n_cap, 256), 2048) : 1;
   hipLaunchKernelGGL(k_gs_init, dim3(1), dim3(64), 0, st, L.hdr, len, B, n_cap, status);
   if (n_cap == 0) {
-    hipLaunchKernelGGL(k_gs_offsets, dim3(1), dim3(64), 0, st, L.hdr, out_len);
+    hipLaunchKernelGGL(k_gs_offsets, dim3(1), dim3(64), 0, st, L.hdr, static_cast<const int32_t*>(nullptr), out_len);
     return check_launch("lcr_grid_subsample");
   }
   hipLaunchKernelGGL(k_gs_bbox, dim3(nblk), dim3(256), 0, st, L.hdr, xyz);
@@ -461,11 +465,12 @@ extern "C" int lcr_grid_subsample_ex(const float* xyz, const int64_t* len, int B
   rc = exclusive_scan_i32(L.head, L.head, n_cap + 1, nullptr, L.scan_ws, st);
   if (rc) return rc;
   hipMemsetAsync(L.first, 0, sizeof(int32_t) * (n_cap + 1), st);
-  hipLaunchKernelGGL(k_gs_reduce, dim3(nblk), dim3(256), 0, st, L.hdr, xyz, L.keyA, L.keyB, L.valA, L.valB, L.head, L.bary, L.seg_key,
-                     L.seg_first, L.first);
+  hipLaunchKernelGGL(k_gs_seg_starts, dim3(nblk), dim3(256), 0, st, L.hdr, L.head, L.seg_start);
+  hipLaunchKernelGGL(k_gs_reduce, dim3(nblk), dim3(256), 0, st, L.hdr, xyz, L.keyA, L.keyB, L.valA, L.valB, L.head, L.seg_start, L.bary,
+                     L.seg_key, L.seg_first, L.first);
   rc = exclusive_scan_i32(L.first, L.first, n_cap + 1, nullptr, L.scan_ws, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_gs_offsets, dim3(1), dim3(64), 0, st, L.hdr, out_len);
+  hipLaunchKernelGGL(k_gs_offsets, dim3(1), dim3(64), 0, st, L.hdr, L.head, out_len);
   hipLaunchKernelGGL(k_gs_insertion, dim3(nblk), dim3(256), 0, st, L.hdr, L.first, L.seg_key, L.seg_first, L.ins_key, L.ins_seg);
   hipLaunchKernelGGL(k_gs_hashorder, dim3(B), dim3(HM_T), 0, st, L.hdr, L.ins_key, L.ins_seg, L.bary, L.hm_t, L.hm_bk, L.hm_mem, L.hm_at,
                      L.hm_gmin, L.hm_cnt, L.hm_start, out_xyz);

@@ -30,74 +30,117 @@ __device__ __forceinline__ int seg_of(const int64_t* __restrict__ seg_len, int S
   return s;
 }
 
-// one wavefront per row; lanes stride the channels
+// Flat float4 mapping: thread t handles 4 consecutive channels of one row (C % 4 == 0), so loads/stores are 16-B vectors and
+// all 64 lanes are busy for every C.  Row flags (pos) are reduced across the C/4 lanes of a row (C <= 256).
+constexpr int GN_TABLE = 2048;   // (segment, group) pairs whose mean / rstd fit the LDS table
+
+template <bool POS>
 __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, GnSide gx, const float* __restrict__ res, GnSide gr,
                                                   float* __restrict__ y, int64_t N, int C, int groups, const int64_t* __restrict__ seg_len, int S,
                                                   float eps, float slope, int act, uint8_t* __restrict__ pos) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __shared__ float2 s_x[GN_TABLE], s_r[GN_TABLE];   // (mean, rstd) per (segment, group): the fp64 finalisation runs once per block
   const int gs = C / groups;
-  for (int64_t n = static_cast<int64_t>(blockIdx.x) * 4 + w; n < N; n += static_cast<int64_t>(gridDim.x) * 4) {
+  for (int i = threadIdx.x; i < S * groups; i += blockDim.x) {
+    const double cnt = static_cast<double>(seg_len[i / groups]) * gs;
+    const double m = gx.stats[2 * i] / cnt;
+    const double var = fmax(gx.stats[2 * i + 1] / cnt - m * m, 0.0);
+    s_x[i] = make_float2(static_cast<float>(m), static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps))));
+    if (gr.stats) {
+      const double rm = gr.stats[2 * i] / cnt;
+      const double rv = fmax(gr.stats[2 * i + 1] / cnt - rm * rm, 0.0);
+      s_r[i] = make_float2(static_cast<float>(rm), static_cast<float>(1.0 / sqrt(rv + static_cast<double>(eps))));
+    }
+  }
+  __syncthreads();
+  const int c4n = C >> 2;                         // float4 pieces per row
+  const int64_t total = N * c4n;
+  for (int64_t t = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; t < ((total + 63) & ~int64_t(63));
+       t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const bool live = t < total;
+    const int64_t n = live ? t / c4n : N - 1;
+    const int c0 = live ? static_cast<int>(t - n * c4n) * 4 : 0;
     int64_t slen;
     const int s = seg_of(seg_len, S, n, &slen);
-    const double cnt = static_cast<double>(slen) * gs;
+    const float4 xv = *reinterpret_cast<const float4*>(x + n * C + c0);
+    const float4 gam = *reinterpret_cast<const float4*>(gx.gamma + c0);
+    const float4 bet = *reinterpret_cast<const float4*>(gx.beta + c0);
+    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f), rgam = rv, rbet = rv;
+    if (res) rv = *reinterpret_cast<const float4*>(res + n * C + c0);
+    if (gr.stats) {
+      rgam = *reinterpret_cast<const float4*>(gr.gamma + c0);
+      rbet = *reinterpret_cast<const float4*>(gr.beta + c0);
+    }
+    const float xin[4] = {xv.x, xv.y, xv.z, xv.w}, g4[4] = {gam.x, gam.y, gam.z, gam.w}, b4[4] = {bet.x, bet.y, bet.z, bet.w};
+    const float rin[4] = {rv.x, rv.y, rv.z, rv.w}, rg4[4] = {rgam.x, rgam.y, rgam.z, rgam.w}, rb4[4] = {rbet.x, rbet.y, rbet.z, rbet.w};
+    float out[4];
     float rowsum = 0.f;
-    for (int c = lane; c < C; c += 64) {
-      const int g = c / gs;
-      const double* st = gx.stats + (static_cast<int64_t>(s) * groups + g) * 2;
-      const double mean = st[0] / cnt;
-      const double var = fmax(st[1] / cnt - mean * mean, 0.0);
-      const float rstd = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
-      float v = (x[n * C + c] - static_cast<float>(mean)) * rstd * gx.gamma[c] + gx.beta[c];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int gi = s * groups + (c0 + u) / gs;
+      const float2 mr = s_x[gi];
+      float v = (xin[u] - mr.x) * mr.y * g4[u] + b4[u];
       if (res) {
-        float r = res[n * C + c];
+        float r = rin[u];
         if (gr.stats) {
-          const double* rt = gr.stats + (static_cast<int64_t>(s) * groups + g) * 2;
-          const double rm = rt[0] / cnt;
-          const double rv = fmax(rt[1] / cnt - rm * rm, 0.0);
-          r = (r - static_cast<float>(rm)) * static_cast<float>(1.0 / sqrt(rv + static_cast<double>(eps))) * gr.gamma[c] + gr.beta[c];
+          const float2 rr = s_r[gi];
+          r = (r - rr.x) * rr.y * rg4[u] + rb4[u];
         }
         v += r;
       }
       if (act) v = v > 0.f ? v : v * slope;
-      y[n * C + c] = v;
+      out[u] = v;
       rowsum += v;
     }
-    if (pos) {
-      rowsum = wave_sum(rowsum);
-      if (lane == 0) pos[n] = rowsum > 0.f ? 1 : 0;
+    if (live) *reinterpret_cast<float4*>(y + n * C + c0) = make_float4(out[0], out[1], out[2], out[3]);
+    if (POS) {
+      // the c4n (<= 64, power of two) lanes of a row are consecutive and aligned inside the wavefront
+      for (int d = 1; d < c4n; d <<= 1) rowsum += __shfl_xor(rowsum, d);
+      if (live && c0 == 0) pos[n] = rowsum > 0.f ? 1 : 0;
     }
   }
 }
 
-// plain segmented statistics for tensors that do not come out of lcr_gemm_f32 (e.g. the fused C_in = 1 KPConv)
+// plain segmented statistics for tensors that do not come out of lcr_gemm_f32 (e.g. the fused C_in = 1 KPConv):
+// a wavefront walks 64 consecutive rows with lanes = channels (coalesced rows), folds the lanes of a group and issues one
+// pair of fp64 atomics per (segment, group, wavefront).
 __global__ __launch_bounds__(256) void k_gn_stats(const float* __restrict__ x, int64_t N, int C, int groups, const int64_t* __restrict__ seg_len,
                                                   int S, double* __restrict__ stats) {
-  // block = 256 consecutive rows; thread t owns channels t, t+256, ...
   const int gs = C / groups;
-  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * 256;
-  const int64_t r1 = r0 + 256 < N ? r0 + 256 : N;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    double s = 0.0, ss = 0.0;
-    int cur = -1;
-    for (int64_t n = r0; n < r1; ++n) {
-      int64_t slen;
-      const int sg = seg_of(seg_len, S, n, &slen);
-      if (sg != cur) {
-        if (cur >= 0) {
-          atomicAdd(&stats[(static_cast<int64_t>(cur) * groups + c / gs) * 2], s);
-          atomicAdd(&stats[(static_cast<int64_t>(cur) * groups + c / gs) * 2 + 1], ss);
-        }
-        s = ss = 0.0;
-        cur = sg;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t r0 = (static_cast<int64_t>(blockIdx.x) * 4 + w) * 64;
+  const int64_t r1 = r0 + 64 < N ? r0 + 64 : N;
+  if (r0 >= N) return;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + lane;
+    float s = 0.f, ss = 0.f;
+    int64_t slen;
+    int cur = seg_of(seg_len, S, r0, &slen);
+    int64_t seg_end = 0;
+    for (int i = 0; i <= cur; ++i) seg_end += seg_len[i];
+    auto flush = [&](int sg) {
+      double ds = s, dss = ss;
+      const int span = gs < 64 ? gs : 64;
+      for (int d = 1; d < span; d <<= 1) {
+        ds += __shfl_xor(ds, d);
+        dss += __shfl_xor(dss, d);
       }
-      const double v = x[n * C + c];
+      if (c < C && (lane & (span - 1)) == 0) {
+        atomicAdd(&stats[(static_cast<int64_t>(sg) * groups + c / gs) * 2], ds);
+        atomicAdd(&stats[(static_cast<int64_t>(sg) * groups + c / gs) * 2 + 1], dss);
+      }
+      s = ss = 0.f;
+    };
+    for (int64_t n = r0; n < r1; ++n) {
+      while (n >= seg_end && cur + 1 < S) {   // wave-uniform
+        flush(cur);
+        ++cur;
+        seg_end += seg_len[cur];
+      }
+      const float v = c < C ? x[n * C + c] : 0.f;
       s += v;
-      ss += v * v;
+      ss = fmaf(v, v, ss);
     }
-    if (cur >= 0) {
-      atomicAdd(&stats[(static_cast<int64_t>(cur) * groups + c / gs) * 2], s);
-      atomicAdd(&stats[(static_cast<int64_t>(cur) * groups + c / gs) * 2 + 1], ss);
-    }
+    flush(cur);
   }
 }
 
@@ -115,9 +158,22 @@ extern "C" int lcr_groupnorm_apply(const float* x, const double* stats, const fl
   }
   if (N == 0) return LCR_OK;
   GnSide gx{stats, gamma, beta}, gr{res_stats, res_gamma, res_beta};
-  const int nblk = static_cast<int>(std::min<int64_t>((N + 3) / 4, 256 * 16));
-  hipLaunchKernelGGL(k_gn_apply, dim3(nblk), dim3(256), 0, static_cast<hipStream_t>(stream), x, gx, res, gr, y, N, C, groups, seg_len, S, eps,
-                     slope, act, pos);
+  if (C % 4 != 0 || S * groups > GN_TABLE) {
+    set_error("lcr_groupnorm_apply: C must be a multiple of 4 and S*groups <= %d", GN_TABLE);
+    return LCR_EARG;
+  }
+  const int c4n = C / 4;
+  if (pos && (c4n > 64 || (c4n & (c4n - 1)) != 0)) {
+    set_error("lcr_groupnorm_apply: row flags need C/4 to be a power of two <= 64");
+    return LCR_EARG;
+  }
+  const int nblk = static_cast<int>(std::min<int64_t>((N * c4n + 255) / 256, 256 * 16));
+  if (pos)
+    hipLaunchKernelGGL((k_gn_apply<true>), dim3(nblk), dim3(256), 0, static_cast<hipStream_t>(stream), x, gx, res, gr, y, N, C, groups, seg_len,
+                       S, eps, slope, act, pos);
+  else
+    hipLaunchKernelGGL((k_gn_apply<false>), dim3(nblk), dim3(256), 0, static_cast<hipStream_t>(stream), x, gx, res, gr, y, N, C, groups, seg_len,
+                       S, eps, slope, act, pos);
   return check_launch("lcr_groupnorm_apply");
 }
 
@@ -129,6 +185,6 @@ extern "C" int lcr_groupnorm_stats(const float* x, int64_t N, int C, int groups,
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipMemsetAsync(stats, 0, sizeof(double) * 2 * S * groups, st);
   if (N == 0) return LCR_OK;
-  hipLaunchKernelGGL(k_gn_stats, dim3(static_cast<int>((N + 255) / 256)), dim3(256), 0, st, x, N, C, groups, seg_len, S, stats);
+  hipLaunchKernelGGL(k_gn_stats, dim3(static_cast<int>((N + 255) / 256)), dim3(256), 0, st, x, N, C, groups, seg_len, S, stats);   // 4 waves x 64 rows
   return check_launch("lcr_groupnorm_stats");
 }

@@ -55,6 +55,19 @@ __device__ __forceinline__ int gather_neighbours(const IdxT* __restrict__ row, i
   return n;
 }
 
+// the 15 influences of one neighbour (padded to 16 floats, 64-B aligned): four 16-B LDS reads instead of fifteen 4-B ones
+__device__ __forceinline__ void load_w16(const float* __restrict__ p, float (&w)[16]) {
+  const float4* q = reinterpret_cast<const float4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float4 v = q[i];
+    w[4 * i + 0] = v.x;
+    w[4 * i + 1] = v.y;
+    w[4 * i + 2] = v.z;
+    w[4 * i + 3] = v.w;
+  }
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -69,7 +82,7 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate(const float*
                                                                     float sigma, float* __restrict__ A, float* __restrict__ nn) {
   constexpr int C = HALF ? 32 : 64 * CPL;
   __shared__ int32_t s_idx[KP_WAVES][KP_HMAX];
-  __shared__ float   s_w[KP_WAVES][KP_HMAX * 16];
+  __shared__ __attribute__((aligned(16))) float s_w[KP_WAVES][KP_HMAX * 16];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int64_t m = static_cast<int64_t>(blockIdx.x) * KP_WAVES + w; m < M; m += static_cast<int64_t>(gridDim.x) * KP_WAVES) {
     const float q[3] = {q_pts[3 * m], q_pts[3 * m + 1], q_pts[3 * m + 2]};
@@ -88,11 +101,22 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate(const float*
 
     if (HALF) {
       const int g = lane >> 5, c = lane & 31;
-      for (int h = g; h < n; h += 2) {
-        const float f = s_feats[static_cast<int64_t>(s_idx[w][h]) * C + c];
-        const float* wp = &s_w[w][h * 16];
+      int h = g;
+      for (; h + 2 < n; h += 4) {   // two neighbours of this half-wave in flight
+        const float f0 = s_feats[static_cast<int64_t>(s_idx[w][h]) * C + c];
+        const float f1 = s_feats[static_cast<int64_t>(s_idx[w][h + 2]) * C + c];
+        float w0[16], w1[16];
+        load_w16(&s_w[w][h * 16], w0);
+        load_w16(&s_w[w][(h + 2) * 16], w1);
 #pragma unroll
-        for (int k = 0; k < KP_K; ++k) acc[0][k] = fmaf(wp[k], f, acc[0][k]);
+        for (int k = 0; k < KP_K; ++k) acc[0][k] = fmaf(w1[k], f1, fmaf(w0[k], f0, acc[0][k]));
+      }
+      for (; h < n; h += 2) {
+        const float f = s_feats[static_cast<int64_t>(s_idx[w][h]) * C + c];
+        float w0[16];
+        load_w16(&s_w[w][h * 16], w0);
+#pragma unroll
+        for (int k = 0; k < KP_K; ++k) acc[0][k] = fmaf(w0[k], f, acc[0][k]);
       }
 #pragma unroll
       for (int k = 0; k < KP_K; ++k) acc[0][k] += __shfl_xor(acc[0][k], 32);
@@ -112,18 +136,19 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate(const float*
           f0[j] = r0[lane + 64 * j];
           f1[j] = r1[lane + 64 * j];
         }
-        const float* w0 = &s_w[w][h * 16];
-        const float* w1 = w0 + 16;
+        float w0[16], w1[16];
+        load_w16(&s_w[w][h * 16], w0);
+        load_w16(&s_w[w][(h + 1) * 16], w1);
 #pragma unroll
         for (int k = 0; k < KP_K; ++k) {
-          const float a = w0[k], b = w1[k];
 #pragma unroll
-          for (int j = 0; j < CPL; ++j) acc[j][k] = fmaf(b, f1[j], fmaf(a, f0[j], acc[j][k]));
+          for (int j = 0; j < CPL; ++j) acc[j][k] = fmaf(w1[k], f1[j], fmaf(w0[k], f0[j], acc[j][k]));
         }
       }
       if (h < n) {
         const float* r0 = s_feats + static_cast<int64_t>(s_idx[w][h]) * C;
-        const float* w0 = &s_w[w][h * 16];
+        float w0[16];
+        load_w16(&s_w[w][h * 16], w0);
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
           const float f = r0[lane + 64 * j];

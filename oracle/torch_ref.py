@@ -186,17 +186,38 @@ def thd_roformer(sd, ref_pts, src_pts, ref_feats, src_feats, pfx="transformer.",
 
 
 # ------------------------------------------------------------------------------------------------ retrieval
-def retrieval_topk(desc, k=50, exclude=100, start=101):
-    """experiments/loop_detection/eval_loop_detection_overlap_dataset.py:183-214: for query i in [start, C-1):
-    database = descriptors [0, i-exclude), top-k by squared L2, ascending.  Returns (idx (Q,k), d2 (Q,k)) with -1 / inf
-    where the database holds fewer than k entries.  (faiss IndexIVFFlat with nlist=1 is exhaustive.)"""
+def retrieval_topk(desc, k=50, exclude=100, start=101, stop=None):
+    """experiments/loop_detection/eval_loop_detection_overlap_dataset.py:183-214: for query i in [start, C-1) the database
+    is descriptors [0, i-exclude); top-k by squared L2, ascending (ties: ascending index).  faiss IndexIVFFlat with
+    nlist=1 is exhaustive, so this is a plain masked exhaustive search (fp64 distances: an exact reference).
+    Returns (query ids (Q,), idx (Q,k) with -1 padding, d2 (Q,k) with +inf padding)."""
     C = desc.shape[0]
-    qs = torch.arange(start, C - 1)
-    d2 = (desc[qs] ** 2).sum(1, keepdim=True) - 2 * desc[qs] @ desc.t() + (desc ** 2).sum(1)[None]
-    d2 = ((desc[qs][:, None, :] - desc[None]) ** 2).sum(-1) if C <= 2048 else d2
+    stop = C - 1 if stop is None else stop
+    qs = torch.arange(start, stop)
+    d = desc.double()
+    d2 = ((d[qs][:, None, :] - d[None]) ** 2).sum(-1) if C * len(qs) <= 4_000_000 else \
+        (d[qs] ** 2).sum(1, keepdim=True) - 2 * d[qs] @ d.t() + (d ** 2).sum(1)[None]
+    d2 = d2.clamp(min=0)
     mask = torch.arange(C)[None, :] >= (qs[:, None] - exclude)
     d2 = d2.masked_fill(mask, float("inf"))
-    kk = min(k, C)
-    val, idx = torch.topk(d2, kk, dim=1, largest=False, sorted=True)
-    idx = idx.masked_fill(torch.isinf(val), -1)
+    order = torch.argsort(d2, dim=1, stable=True)[:, :k]          # stable: ties keep ascending index
+    val = torch.gather(d2, 1, order)
+    idx = order.masked_fill(torch.isinf(val), -1)
+    if idx.shape[1] < k:
+        pad = k - idx.shape[1]
+        idx = torch.cat([idx, torch.full((len(qs), pad), -1, dtype=idx.dtype)], 1)
+        val = torch.cat([val, torch.full((len(qs), pad), float("inf"), dtype=val.dtype)], 1)
     return qs, idx, val
+
+
+def recall_at_1(qs, idx, gt):
+    """compute_topN with N=1 (eval_loop_detection_overlap_dataset.py:29-62): fraction of GT-bearing query frames whose first
+    retrieved frame is a ground-truth loop.  gt: dict frame -> set of frames."""
+    hit = tot = 0
+    for q, row in zip(qs.tolist(), idx.tolist()):
+        g = gt.get(q)
+        if not g:
+            continue
+        tot += 1
+        hit += int(row[0] in g)
+    return hit / max(tot, 1)
