@@ -133,6 +133,20 @@ int lcr_netvlad_forward(const float* feats /*[sum(seg_len),1024]*/, const int64_
                         const LcrNetvladWeights* weights_host, float* out /*[S,256]*/, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * a-8  3D-RoFormer attention block (fp32) — RPEMultiHeadAttention / MultiHeadAttention of
+ *      modules/thdroformer/rpetransformer.py:41-108 and vanilla_transformer.py:30-118.
+ * ------------------------------------------------------------------------------------------------ */
+/* x[N, heads*32] <- x*cos(theta) + rot(x)*sin(theta) in place, theta[N, heads*16] (one angle per adjacent channel pair). */
+int lcr_rotary_embed(float* x, const float* theta, int64_t N, int heads, void* stream);
+/* out[Nq, heads*32] = softmax(q k^T / sqrt(32)) v per head, fused (no score matrix in memory); head_dim must be 32. */
+int lcr_attention_f32(const float* q, const float* k, const float* v, int64_t Nq, int64_t Nk, int heads, int head_dim,
+                      float* out, void* stream);
+/* y = LayerNorm(a + b) (b may be NULL), rows of D <= 1024 features. */
+int lcr_add_layernorm(const float* a, const float* b, const float* gamma, const float* beta, int64_t N, int D, float eps,
+                      float* y, void* stream);
+int lcr_relu_inplace(float* x, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * a-9  descriptor retrieval: exhaustive squared-L2 top-k with the temporal exclusion window — replaces the per-query
  *      faiss IndexIVFFlat(nlist=1) loop of experiments/loop_detection/eval_loop_detection_overlap_dataset.py:183-214.
  * Query row r is global frame q0+r; its database is frames [0, q0+r-exclude).  Rows ascending in (d2, index); short rows

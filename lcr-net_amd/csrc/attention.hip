@@ -1,0 +1,227 @@
+// attention.hip — a-8: the 3D-RoFormer attention block (rotary self-attention / vanilla cross-attention), fp32.
+//
+// Reference: RPEMultiHeadAttention.forward (experiments/lcrnet/modules/thdroformer/rpetransformer.py:77-108),
+// RotaryPositionalEmbedding.forward (:45-54), dynamic_attention with k=None (:19-39: full softmax),
+// MultiHeadAttention.forward (vanilla_transformer.py:46-85), AttentionLayer / AttentionOutput residual LayerNorms (:13-28, 88-118).
+// The reference materialises (1,4,N,M) score tensors and runs ~15 small torch ops per layer; here:
+//   k_rotary     : q,k <- q·cos(theta) + rot(q)·sin(theta) in place, theta = learned 3-D position code (one angle per
+//                  adjacent channel pair; the SAME theta rotates q and k), one pass, sincosf once per pair;
+//   k_attention  : flash-style fused QK^T / softmax / PV on the fp32 matrix cores — the only dense QK^T·V on the path, so
+//                  this is where MFMA is spent (v_mfma_f32_32x32x2_f32; fp32 inputs are required for the 1e-4 tolerance).
+//                  One wavefront per (head, 32-query tile).  Scores are computed TRANSPOSED (S^T = K·Q^T) so that a lane
+//                  owns one query column: its running max / sum / rescale are per-lane scalars, the 32 keys of a tile sit
+//                  in the lane's 16 accumulator registers + its partner lane's (lane ^ 32), and P feeds the second MFMA
+//                  (O^T = V^T·P^T) straight from registers with one cross-half swap per step — no LDS round trip for P,
+//                  no score matrix in memory;
+//   k_add_layernorm : y = LayerNorm(a + b) (d_model = 128: one wavefront per row).
+#include <algorithm>
+#include <cmath>
+
+#include "common.h"
+
+namespace lcr {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int AT_D = 32;    // head dim (d_model 128 / 4 heads)
+constexpr int AT_LD = 33;   // LDS row stride: conflict-free ds_read_b32 for both "row = lane" operand patterns
+
+// x [N, H*32] in place; theta [N, H*16]
+__global__ __launch_bounds__(256) void k_rotary(float* __restrict__ x, const float* __restrict__ theta, int64_t N, int heads) {
+  const int pairs = heads * 16;
+  const int64_t total = N * pairs;
+  for (int64_t t = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; t < total; t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t n = t / pairs;
+    const int p = static_cast<int>(t - n * pairs);
+    float s, c;
+    sincosf(theta[n * pairs + p], &s, &c);
+    float2* q = reinterpret_cast<float2*>(x + n * (pairs * 2) + 2 * p);
+    const float2 v = *q;
+    *q = make_float2(v.x * c - v.y * s, v.y * c + v.x * s);
+  }
+}
+
+__device__ __forceinline__ void load_tile(const float* __restrict__ src, int64_t rows, int64_t r0, int ld_src, int col0, float* __restrict__ dst) {
+  // 32 x 32 tile (rows r0.., columns col0..col0+31) of a row-major matrix -> dst[32][AT_LD]; rows beyond `rows` -> 0
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = lane + 64 * i;          // 256 float4 pieces
+    const int r = f >> 3, c4 = f & 7;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < rows) v = *reinterpret_cast<const float4*>(src + (r0 + r) * ld_src + col0 + c4 * 4);
+    float* d = dst + r * AT_LD + c4 * 4;
+    d[0] = v.x;
+    d[1] = v.y;
+    d[2] = v.z;
+    d[3] = v.w;
+  }
+}
+
+// q [Nq, H*32], k/v [Nk, H*32] -> out [Nq, H*32];  grid (ceil(Nq/32), H), 64 threads
+__global__ __launch_bounds__(64) void k_attention(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                  int64_t Nq, int64_t Nk, int heads, float scale, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float s_q[32 * AT_LD], s_k[32 * AT_LD], s_v[32 * AT_LD];
+  const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
+  const int head = blockIdx.y;
+  const int64_t q0 = static_cast<int64_t>(blockIdx.x) * 32;
+  const int ld = heads * AT_D;
+  load_tile(q, Nq, q0, ld, head * AT_D, s_q);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // B operand of S^T = K·Q^T: B[kd][j=query] = Q[query][kd]; hoisted: 16 values per lane
+  float qf[16];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) qf[kk] = s_q[col * AT_LD + 2 * kk + half] * scale;
+
+  floatx16 o;   // O^T[d = row][query = col]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+
+  for (int64_t k0 = 0; k0 < Nk; k0 += 32) {
+    __builtin_amdgcn_wave_barrier();
+    load_tile(k, Nk, k0, ld, head * AT_D, s_k);
+    load_tile(v, Nk, k0, ld, head * AT_D, s_v);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // S^T[key][query] = sum_d K[key][d] * Q[query][d]
+    floatx16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const float a = s_k[col * AT_LD + 2 * kk + half];   // A[i=key][kd]
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qf[kk], s, 0, 0, 0);
+    }
+    // this lane: query `col`, keys key(r) = (r&3) + 8*(r>>2) + 4*half; partner lane (lane^32) holds the other 16 keys
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (key >= Nk) s[r] = -INFINITY;
+      tmax = fmaxf(tmax, s[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m, tmax);                 // finite: every tile holds at least one valid key
+    const float alpha = expf(m - m_new);                 // exp(-inf) = 0 on the first tile
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = expf(s[r] - m_new);
+      psum += s[r];
+    }
+    psum += __shfl_xor(psum, 32);
+    l = l * alpha + psum;
+    m = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] *= alpha;
+    // O^T[d][query] += sum_key V[key][d] * P[key][query]:  A[i=d][kk] = V[key][d],  B[kk][j=query] = P[key][query]
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      // the key this lane must supply is 2*kk + half; it lives in half hp = (kk>>1)&1, register 2*(kk&1) + (key&1) + 4*(kk>>2)
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int hp = (kk >> 1) & 1;
+      const int rbase = 2 * (kk & 1) + 4 * (kk >> 2);
+      const float own = (half == 0) ? s[rbase + 0] : s[rbase + 1];       // value for a requester in my own half
+      const float other = (half == 0) ? s[rbase + 1] : s[rbase + 0];     // value my partner (other half) needs
+      const float recv = __shfl_xor(other, 32);
+      const float b = (half == hp) ? own : recv;
+      const float a = s_v[(2 * kk + half) * AT_LD + col];                 // A[i=d=col][key]
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, o, 0, 0, 0);
+    }
+  }
+  // O^T[d][query]: lane = query `col`, rows d = (r&3) + 8*(r>>2) + 4*half
+  const int64_t qi = q0 + col;
+  if (qi < Nq) {
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int d = (r & 3) + 8 * (r >> 2) + 4 * half;
+      out[qi * ld + head * AT_D + d] = o[r] * inv;
+    }
+  }
+}
+
+// y = LayerNorm(a + b) * gamma + beta, rows of D (<= 1024) features; one wavefront per row
+__global__ __launch_bounds__(256) void k_add_layernorm(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int64_t N, int D, float eps, float* __restrict__ y) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int64_t n = static_cast<int64_t>(blockIdx.x) * 4 + w; n < N; n += static_cast<int64_t>(gridDim.x) * 4) {
+    float vals[16];
+    float s = 0.f;
+    int cnt = 0;
+    for (int c = lane; c < D; c += 64, ++cnt) {
+      const float t = a[n * D + c] + (b ? b[n * D + c] : 0.f);
+      vals[cnt] = t;
+      s += t;
+    }
+    s = wave_sum(s);
+    const float mean = s / D;
+    float ss = 0.f;
+    for (int i = 0; i < cnt; ++i) {
+      const float d = vals[i] - mean;
+      ss = fmaf(d, d, ss);
+    }
+    ss = wave_sum(ss);
+    const float rstd = 1.f / sqrtf(ss / D + eps);
+    cnt = 0;
+    for (int c = lane; c < D; c += 64, ++cnt) y[n * D + c] = (vals[cnt] - mean) * rstd * gamma[c] + beta[c];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_relu_inplace(float* __restrict__ x, int64_t n) {
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    x[i] = fmaxf(x[i], 0.f);
+}
+
+}  // namespace lcr
+
+using namespace lcr;
+
+extern "C" int lcr_rotary_embed(float* x, const float* theta, int64_t N, int heads, void* stream) {
+  if (!x || !theta || N < 0 || heads < 1) {
+    set_error("lcr_rotary_embed: bad argument");
+    return LCR_EARG;
+  }
+  if (N == 0) return LCR_OK;
+  const int64_t total = N * heads * 16;
+  hipLaunchKernelGGL(k_rotary, dim3(static_cast<int>(std::min<int64_t>((total + 255) / 256, 4096))), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     theta, N, heads);
+  return check_launch("lcr_rotary_embed");
+}
+
+extern "C" int lcr_attention_f32(const float* q, const float* k, const float* v, int64_t Nq, int64_t Nk, int heads, int head_dim, float* out,
+                                 void* stream) {
+  if (!q || !k || !v || !out || Nq < 0 || Nk < 1 || heads < 1 || head_dim != AT_D) {
+    set_error("lcr_attention_f32: bad argument (head_dim must be %d, Nk >= 1)", AT_D);
+    return LCR_EARG;
+  }
+  if (Nq == 0) return LCR_OK;
+  const float scale = 1.f / sqrtf(static_cast<float>(head_dim));
+  hipLaunchKernelGGL(k_attention, dim3(static_cast<int>((Nq + 31) / 32), heads), dim3(64), 0, static_cast<hipStream_t>(stream), q, k, v, Nq, Nk,
+                     heads, scale, out);
+  return check_launch("lcr_attention_f32");
+}
+
+extern "C" int lcr_add_layernorm(const float* a, const float* b, const float* gamma, const float* beta, int64_t N, int D, float eps, float* y,
+                                 void* stream) {
+  if (!a || !gamma || !beta || !y || N < 0 || D < 1 || D > 1024) {
+    set_error("lcr_add_layernorm: bad argument (D <= 1024)");
+    return LCR_EARG;
+  }
+  if (N == 0) return LCR_OK;
+  hipLaunchKernelGGL(k_add_layernorm, dim3(static_cast<int>(std::min<int64_t>((N + 3) / 4, 4096))), dim3(256), 0, static_cast<hipStream_t>(stream), a, b,
+                     gamma, beta, N, D, eps, y);
+  return check_launch("lcr_add_layernorm");
+}
+
+extern "C" int lcr_relu_inplace(float* x, int64_t n, void* stream) {
+  if (!x || n < 0) return LCR_EARG;
+  if (n == 0) return LCR_OK;
+  hipLaunchKernelGGL(k_relu_inplace, dim3(static_cast<int>(std::min<int64_t>((n + 255) / 256, 4096))), dim3(256), 0, static_cast<hipStream_t>(stream), x, n);
+  return check_launch("lcr_relu_inplace");
+}

@@ -174,3 +174,34 @@ def netvlad_forward(feats, seg_len_host, weights_struct):
                                               _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(feats.device)),
                "lcr_netvlad_forward")
     return out
+
+
+def linear(x, weight, bias=None, relu=False):
+    """nn.Linear (weight [out,in]) on the MFMA GEMM, optional ReLU."""
+    y = gemm(x.contiguous(), weight, trans_b=True, bias=bias)[0]
+    if relu:
+        _lib.check(_lib.lib().lcr_relu_inplace(_lib.ptr(y), y.numel(), _lib.stream_ptr(y.device)), "lcr_relu_inplace")
+    return y
+
+
+def rotary_embed_(x, theta, heads):
+    """In place rotary position embedding (rpetransformer.py:41-54): x [N, heads*32], theta [N, heads*16]."""
+    assert x.is_contiguous() and theta.is_contiguous() and x.shape[1] == heads * 32 and theta.shape[1] == heads * 16
+    _lib.check(_lib.lib().lcr_rotary_embed(_lib.ptr(x), _lib.ptr(theta), x.shape[0], heads, _lib.stream_ptr(x.device)), "lcr_rotary_embed")
+    return x
+
+
+def attention(q, k, v, heads):
+    """Fused softmax(q k^T / sqrt(d)) v per head; q [Nq, heads*32], k/v [Nk, heads*32]."""
+    assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
+    out = torch.empty_like(q)
+    _lib.check(_lib.lib().lcr_attention_f32(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), q.shape[0], k.shape[0], heads, q.shape[1] // heads,
+                                            _lib.ptr(out), _lib.stream_ptr(q.device)), "lcr_attention_f32")
+    return out
+
+
+def add_layernorm(a, b, gamma, beta, eps=1e-5):
+    y = torch.empty_like(a)
+    _lib.check(_lib.lib().lcr_add_layernorm(_lib.ptr(a), _lib.ptr(b), _lib.ptr(gamma), _lib.ptr(beta), a.shape[0], a.shape[1], float(eps),
+                                            _lib.ptr(y), _lib.stream_ptr(a.device)), "lcr_add_layernorm")
+    return y

@@ -1,0 +1,117 @@
+"""ThDRoFormer (3D-RoFormer) — module tree / parameter names of experiments/lcrnet/modules/thdroformer
+(thdroformer_linear.py:12-97, rpetransformer.py:57-220, vanilla_transformer.py:13-144, Rotary3DPosEmb.py:27-38) so the
+`transformer.*` checkpoint keys load unchanged; forward on the HIP kernels (lcr_gemm_f32 for every Linear,
+lcr_rotary_embed, the fused MFMA attention lcr_attention_f32, lcr_add_layernorm).  Batch 1 pair, like the reference."""
+import torch.nn as nn
+
+from ... import functional as F
+
+
+class LinearLearnablePosEmbedding(nn.Module):
+    def __init__(self, hidden_dim, reduction_a="max"):
+        super().__init__()
+        self.encoder = nn.Linear(3, int(hidden_dim))
+        self.encoder2 = nn.Linear(int(hidden_dim), int(hidden_dim / 2))
+
+    def forward(self, points):
+        """points (N,3) -> theta (N, hidden/2); two Linears, no activation (Rotary3DPosEmb.py:34-38)."""
+        return F.linear(F.linear(points, self.encoder.weight, self.encoder.bias), self.encoder2.weight, self.encoder2.bias)
+
+
+class _MultiHeadAttention(nn.Module):
+    """Parameters of RPEMultiHeadAttention / MultiHeadAttention (identical names; the rotary variant has no extra parameters)."""
+
+    def __init__(self, d_model, num_heads):
+        super().__init__()
+        assert d_model % num_heads == 0 and d_model // num_heads == 32, "the fused attention kernel is built for head_dim 32"
+        self.d_model, self.num_heads = d_model, num_heads
+        self.proj_q = nn.Linear(d_model, d_model)
+        self.proj_k = nn.Linear(d_model, d_model)
+        self.proj_v = nn.Linear(d_model, d_model)
+
+    def forward(self, input_q, input_k, input_v, theta_q=None):
+        q = F.linear(input_q, self.proj_q.weight, self.proj_q.bias)
+        k = F.linear(input_k, self.proj_k.weight, self.proj_k.bias)
+        v = F.linear(input_v, self.proj_v.weight, self.proj_v.bias)
+        if theta_q is not None:                                   # self layers: the SAME theta rotates q and k
+            F.rotary_embed_(q, theta_q, self.num_heads)
+            F.rotary_embed_(k, theta_q, self.num_heads)
+        return F.attention(q, k, v, self.num_heads)
+
+
+class _AttentionLayer(nn.Module):
+    def __init__(self, d_model, num_heads):
+        super().__init__()
+        self.attention = _MultiHeadAttention(d_model, num_heads)
+        self.linear = nn.Linear(d_model, d_model)
+        self.norm = nn.LayerNorm(d_model)
+
+    def forward(self, x, memory, theta=None):
+        h = self.attention(x, memory, memory, theta)
+        h = F.linear(h, self.linear.weight, self.linear.bias)
+        return F.add_layernorm(h, x, self.norm.weight, self.norm.bias, self.norm.eps)
+
+
+class _AttentionOutput(nn.Module):
+    def __init__(self, d_model):
+        super().__init__()
+        self.expand = nn.Linear(d_model, d_model * 2)
+        self.squeeze = nn.Linear(d_model * 2, d_model)
+        self.norm = nn.LayerNorm(d_model)
+
+    def forward(self, x):
+        h = F.linear(x, self.expand.weight, self.expand.bias, relu=True)
+        h = F.linear(h, self.squeeze.weight, self.squeeze.bias)
+        return F.add_layernorm(x, h, self.norm.weight, self.norm.bias, self.norm.eps)
+
+
+class _TransformerLayer(nn.Module):
+    def __init__(self, d_model, num_heads):
+        super().__init__()
+        self.attention = _AttentionLayer(d_model, num_heads)
+        self.output = _AttentionOutput(d_model)
+
+    def forward(self, x, memory, theta=None):
+        return self.output(self.attention(x, memory, theta))
+
+
+class RPEConditionalTransformer(nn.Module):
+    def __init__(self, blocks, d_model, num_heads, parallel=False):
+        super().__init__()
+        self.blocks, self.parallel = list(blocks), parallel
+        self.layers = nn.ModuleList([_TransformerLayer(d_model, num_heads) for _ in self.blocks])
+
+    def forward(self, feats0, feats1, theta0, theta1):
+        for i, block in enumerate(self.blocks):
+            if block == "self":                                   # one shared module for both clouds (rpetransformer.py:203-206)
+                feats0 = self.layers[i](feats0, feats0, theta0)
+                feats1 = self.layers[i](feats1, feats1, theta1)
+            elif self.parallel:
+                feats0, feats1 = self.layers[i](feats0, feats1), self.layers[i](feats1, feats0)
+            else:                                                 # sequential: cloud 1 attends to the UPDATED cloud 0 (:213-214)
+                feats0 = self.layers[i](feats0, feats1)
+                feats1 = self.layers[i](feats1, feats0)
+        return feats0, feats1
+
+
+class ThDRoFormer(nn.Module):
+    def __init__(self, input_dim, output_dim, hidden_dim, num_heads, num_layers, k=None, dropout=None, activation_fn="ReLU", reduction_a="max"):
+        super().__init__()
+        assert k is None and dropout is None and activation_fn == "ReLU", "reference configuration: full softmax, no dropout, ReLU"
+        self.embedding = LinearLearnablePosEmbedding(hidden_dim, reduction_a=reduction_a)
+        self.in_proj = nn.Linear(input_dim, hidden_dim)
+        self.transformer = RPEConditionalTransformer(["self", "cross"] * num_layers, hidden_dim, num_heads)
+        self.out_proj = nn.Linear(hidden_dim, output_dim)
+
+    def forward(self, ref_points, src_points, ref_feats, src_feats):
+        """(N,3), (M,3), (N,C), (M,C)  [a leading batch dim of 1 as in the reference is accepted] -> (N,out), (M,out)."""
+        squeeze = ref_points.dim() == 3
+        if squeeze:
+            ref_points, src_points, ref_feats, src_feats = ref_points[0], src_points[0], ref_feats[0], src_feats[0]
+        t0, t1 = self.embedding(ref_points.contiguous()), self.embedding(src_points.contiguous())
+        f0 = F.linear(ref_feats, self.in_proj.weight, self.in_proj.bias)
+        f1 = F.linear(src_feats, self.in_proj.weight, self.in_proj.bias)
+        f0, f1 = self.transformer(f0, f1, t0, t1)
+        f0 = F.linear(f0, self.out_proj.weight, self.out_proj.bias)
+        f1 = F.linear(f1, self.out_proj.weight, self.out_proj.bias)
+        return (f0[None], f1[None]) if squeeze else (f0, f1)

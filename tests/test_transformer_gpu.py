@@ -1,0 +1,67 @@
+"""GPU: 3D-RoFormer (a-8) — fused rotary / MFMA attention kernels vs torch, and the whole transformer + pair model vs the
+torch fp32 oracle and the golden vectors generated from the imported reference (tolerance 1e-4 on O(1) features)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, LIMITS, NUM_STAGES, RADIUS, VOXEL, load_scan
+from oracle import ops as oracle_ops
+from oracle import torch_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("Nq,Nk", [(844, 844), (844, 823), (33, 1), (100, 257)])
+def test_attention_kernel(Nq, Nk):
+    from lcrnet_amd import functional as F
+    g = torch.Generator().manual_seed(Nq * 1000 + Nk)
+    q, k, v = torch.randn(Nq, 128, generator=g), torch.randn(Nk, 128, generator=g) * 2, torch.randn(Nk, 128, generator=g)
+    hq, hk, hv = (t.reshape(t.shape[0], 4, 32).permute(1, 0, 2).double() for t in (q, k, v))
+    s = torch.softmax(torch.einsum("hnd,hmd->hnm", hq, hk) / math.sqrt(32), dim=-1)
+    want = torch.einsum("hnm,hmd->hnd", s, hv).permute(1, 0, 2).reshape(Nq, 128)
+    got = F.attention(q.cuda(), k.cuda(), v.cuda(), 4).cpu().double()
+    assert (got - want).abs().max().item() < 2e-5
+
+
+def test_rotary_and_layernorm():
+    from lcrnet_amd import functional as F
+    g = torch.Generator().manual_seed(5)
+    x, th = torch.randn(500, 128, generator=g), torch.randn(500, 64, generator=g) * 3
+    want = torch_ref.rotary(torch_ref._heads(x, 4), torch_ref._heads(th, 4)).permute(1, 0, 2).reshape(500, 128)
+    got = F.rotary_embed_(x.clone().cuda(), th.cuda(), 4).cpu()
+    assert (got - want).abs().max().item() < 1e-5
+    a, b = torch.randn(77, 128, generator=g), torch.randn(77, 128, generator=g)
+    w, bb = torch.randn(128, generator=g), torch.randn(128, generator=g)
+    want = torch.nn.functional.layer_norm(a + b, (128,), w, bb, 1e-5)
+    got = F.add_layernorm(a.cuda(), b.cuda(), w.cuda(), bb.cuda()).cpu()
+    assert (got - want).abs().max().item() < 1e-5
+
+
+def test_pair_model_transformer_and_descriptors():
+    from lcrnet_amd.model_family import LCRNet
+    from lcrnet_amd.weights import seeded_state_dict
+    golden = np.load(os.path.join(GOLDEN, "model_golden.npz"))
+    seed = json.load(open(os.path.join(GOLDEN, "model_manifest.json")))["seed"]
+    m = LCRNet().eval()
+    m.load_state_dict(seeded_state_dict(m.state_dict(), seed), strict=True)
+    m = m.cuda()
+    a, b = load_scan("003854"), load_scan("000958")
+    st = oracle_ops.precompute_data_stack_mode(np.concatenate([a, b]), np.array([len(a), len(b)]), NUM_STAGES, VOXEL, RADIUS, LIMITS)
+    dd = {k: [torch.from_numpy(np.ascontiguousarray(t)).cuda() for t in v] for k, v in st.items()}
+    dd["features"] = torch.ones(len(a) + len(b), 1, device="cuda")
+    with torch.no_grad():
+        out = m(dd)
+    assert (out["pos_feature_global"].cpu() - torch.from_numpy(golden["pair/pos_global"])).abs().max().item() < 1e-4
+    assert (out["anc_feature_global"].cpu() - torch.from_numpy(golden["pair/anc_global"])).abs().max().item() < 1e-4
+    l2 = float(torch.sqrt(((out["pos_feature_global"] - out["anc_feature_global"]) ** 2).sum()))
+    assert abs(l2 - float(golden["pair/l2"])) < 1e-4                   # the number demo.py prints (demo.py:67-78)
+    for tag, e in (("pos", out["pos_feats_c_enhanced"]), ("anc", out["anc_feats_c_enhanced"])):
+        rows = golden[f"pair/{tag}_tf_rows"]
+        want = torch.from_numpy(golden[f"pair/{tag}_tf_vals"])
+        err = (e.cpu()[rows] - want).abs().max().item()
+        assert err < 5e-4, (tag, err)
+        assert abs(e.abs().mean().item() - golden[f"pair/{tag}_tf_stats"][1]) < 1e-4
