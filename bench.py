@@ -145,22 +145,32 @@ def main():
 
     if rank == 0:
         assert torch.isfinite(desc).all() and abs(float(desc.norm(dim=1).mean()) - 1.0) < 1e-3
-        # ---- roofline of the dominant kernel (measured live with HIP events on the launch stream)
+        # ---- roofline of the dominant kernel family, measured live with HIP events on the launch stream.
+        # Dominant by time = lcr::k_gemm_f32 (all tile variants; ~30 % of the step, profiles/): compute-bound on the fp32
+        # matrix cores, so "achieved" = algorithmic flops (2*M*N*K per launch) / launch time vs the 157.3 TFLOP/s
+        # dense fp32 MFMA peak.  HBM traffic per launch comes from the committed rocprofv3 PMC passes (profiles/*pmc*.json).
         summ = timer.summary()
-        agg = summ["kpconv_aggregate"]
-        t_agg = sum(t for t, _ in agg)
-        t_gemm = sum(t for t, _ in summ["gemm"])
-        # algorithmic bytes of one aggregate launch: indices + query/support xyz + support features + pos flags + the (M,15C) output
-        def agg_bytes(m):
+        gem, agg = summ["gemm"], summ["kpconv_aggregate"]
+        t_gemm, t_agg = sum(t for t, _ in gem), sum(t for t, _ in agg)
+        flops = sum(2.0 * m[0] * m[1] * m[2] for _, m in gem)
+
+        def agg_bytes(m):   # indices + query/support xyz + support features + pos flags + the (M,15C) output + counts
             M, Ns, H, C, isz = m
             return M * H * isz + (M + Ns) * 12 + Ns * C * 4 + Ns + M * 15 * C * 4 + M * 4
         bytes_agg = sum(agg_bytes(m) for _, m in agg)
-        roof = {"bound": "hbm", "kernel": "k_kpconv_aggregate (all 10 launches per step)",
-                "achieved": round(bytes_agg / t_agg / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(bytes_agg / t_agg / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                "avg_launch_us": round(t_agg / max(len(agg), 1) * 1e6, 2),
-                "gemm_tflops": round(sum(2.0 * m[0] * m[1] * m[2] for _, m in summ["gemm"]) / max(t_gemm, 1e-9) / 1e12, 2),
-                "share_of_step": {"kpconv_aggregate": round(t_agg / dt, 3), "gemm": round(t_gemm / dt, 3)}}
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("k_gemm_f32", {}).get("traffic_bytes")
+        roof = {"bound": "mfma", "kernel": "lcr::k_gemm_f32 (fp32 MFMA, %d launches/step)" % (len(gem) // max(args.steps, 1)),
+                "achieved": round(flops / t_gemm / 1e12, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(flops / t_gemm / 1e12 / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
+                "avg_launch_us": round(t_gemm / max(len(gem), 1) * 1e6, 2),
+                "gflop_per_launch": round(flops / max(len(gem), 1) / 1e9, 3),
+                "share_of_step": {"gemm": round(t_gemm / dt, 3), "kpconv_aggregate": round(t_agg / dt, 3)},
+                "secondary": {"kernel": "lcr::k_kpconv_aggregate", "bound": "hbm", "achieved": round(bytes_agg / t_agg / 1e9, 1),
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bytes_agg / t_agg / 1e9 / HBM_PEAK_GBS, 4),
+                              "avg_launch_us": round(t_agg / max(len(agg), 1) * 1e6, 2)}}
         line = {
             "metric": "scans/s (120k-pt KITTI-shape scan -> 256-D descriptor)",
             "value": round(world * BATCH * args.steps / dt, 3), "unit": "scans/s", "n_gpus": world, "steps": args.steps,

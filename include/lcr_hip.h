@@ -29,7 +29,8 @@ extern "C" {
 
 /* bits of the device-side status word written by data-dependent stages */
 #define LCR_STATUS_KEY_OVERFLOW 1u   /* voxel key needs more than 64 bits together with the cloud id */
-#define LCR_STATUS_LEN_MISMATCH 2u   /* sum(lengths) exceeds the capacity passed by the host */
+#define LCR_STATUS_LEN_MISMATCH 2u
+#define LCR_GN_REPLICAS 8           /* copies of every GroupNorm statistics table (see lcr_gemm_f32) */   /* sum(lengths) exceeds the capacity passed by the host */
 
 const char* lcr_last_error(void);
 int lcr_version(void);
@@ -87,7 +88,8 @@ int lcr_radius_search(const float* q, const float* s, const int64_t* qlen, const
  * padded with Ns like the reference's neighbour lists; feature tensors are row-major [N,C].
  * ------------------------------------------------------------------------------------------------ */
 /* C = A·B on the fp32 matrix cores with fused epilogue: C[m][:] = (A·B)[m][:] / rowdiv[m] + bias, and per-(segment,group)
- * sum / sum-of-squares of C accumulated into stats[S,groups,2] (fp64) for the GroupNorm that follows.
+ * sum / sum-of-squares of C accumulated into stats[LCR_GN_REPLICAS,S,groups,2] (fp64; consumers add the replicas — they
+ * only spread same-address atomics) for the GroupNorm that follows.
  * transA: A is stored [K,M]; transB: B is stored [N,K] (nn.Linear weight).  Replaces F.linear + the (15,C,Cout)
  * contraction of KPConv.forward (modules/kpconv/kpconv.py:108-116) and torch.matmul in NetVlad.py:56,68. */
 int lcr_gemm_f32(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB,
@@ -107,7 +109,7 @@ int lcr_kpconv_cin1(const float* s_feats, const float* q_pts, const float* s_pts
 int lcr_maxpool(const float* x, const void* idx, int idx_is_64, int64_t M, int64_t Ns, int H, int C, float* out, void* stream);
 /* pos[n] = (sum_c x[n][c] > 0) — the flag behind KPConv's neighbour count. */
 int lcr_row_positive(const float* x, int64_t N, int C, uint8_t* pos, void* stream);
-/* Segmented GroupNorm statistics (sum, sumsq per segment and group, fp64) of x[N,C]; seg_len i64[S] on the device. */
+/* Segmented GroupNorm statistics (sum, sumsq per segment and group, fp64, [LCR_GN_REPLICAS,S,groups,2]) of x[N,C]. */
 int lcr_groupnorm_stats(const float* x, int64_t N, int C, int groups, const int64_t* seg_len, int S, double* stats, void* stream);
 /* y = act( GN(x; stats,gamma,beta) [+ res | + GN(res; res_stats,res_gamma,res_beta)] ), act = LeakyReLU(slope) if act != 0
  * (modules/kpconv/modules.py:33-50, 78-84, 207-225).  Optional pos[n] = (sum_c y[n][c] > 0). */

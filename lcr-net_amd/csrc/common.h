@@ -10,6 +10,10 @@ namespace lcr {
 
 constexpr int WAVE = 64;
 
+// GroupNorm statistics are accumulated into GN_REPLICAS copies of the [S, groups, 2] fp64 table (copy = workgroup % R) so that
+// same-address fp64 atomics — which serialise in the memory-side atomic unit — are spread out; consumers sum the copies.
+constexpr int GN_REPLICAS = 8;
+
 void set_error(const char* fmt, ...);
 
 inline int check_launch(const char* what) {

@@ -27,7 +27,7 @@ struct GemmEpilogue {
   const int64_t* seg_len;   // [S] rows per GroupNorm segment (device) or null
   int            S;
   int            groups;    // GroupNorm groups over N
-  double*        stats;     // [S, groups, 2] (sum, sumsq), accumulated atomically; null = no statistics
+  double*        stats;     // [GN_REPLICAS, S, groups, 2] (sum, sumsq), accumulated atomically; null = no statistics
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -217,48 +217,85 @@ __global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ 
     }
   }
 
-  // GroupNorm statistics: per wavefront, per segment present in its 32 rows (one, except at the B-1 segment boundaries)
-  if (want_stats && wrow0 < M) {
-    const int64_t wlast = min(wrow0 + 31, M - 1);
-    int sg = 0;
+  // GroupNorm statistics.  Fast path (all BM rows of the workgroup in one segment — all but B-1 workgroups): wavefront
+  // partials are folded in LDS (ds_add_f64) and the workgroup issues one pair of global fp64 atomics per group, into the
+  // statistics replica (blockIdx.x % GN_REPLICAS).  Slow path (a segment boundary inside the tile): per wavefront, per
+  // segment present in its 32 rows, straight to global memory.
+  if (want_stats) {
+    __shared__ double s_red[BN][2];
+    double* rep = ep.stats + static_cast<int64_t>(blockIdx.x % GN_REPLICAS) * ep.S * ep.groups * 2;
+    int blk_first = 0;
     int64_t seg_start = 0, seg_end = ep.seg_len[0];
-    while (sg + 1 < ep.S && wrow0 >= seg_end) {
-      ++sg;
+    while (blk_first + 1 < ep.S && m0 >= seg_end) {
+      ++blk_first;
       seg_start = seg_end;
-      seg_end += ep.seg_len[sg];
+      seg_end += ep.seg_len[blk_first];
     }
-    while (true) {   // wave-uniform loop over the segments that intersect [wrow0, wlast]
-      const bool whole = seg_start <= wrow0 && wlast < seg_end;
+    const int64_t blk_last_row = min(m0 + BM - 1, M - 1);
+    const bool uniform = blk_last_row < seg_end;      // block-uniform
+    if (uniform) {
+      for (int i = threadIdx.x; i < BN * 2; i += GM_T) (&s_red[0][0])[i] = 0.0;
+      __syncthreads();
+    }
+    if (wrow0 < M) {
+      const int64_t wlast = min(wrow0 + 31, M - 1);
+      int sg = blk_first;
+      while (sg + 1 < ep.S && wrow0 >= seg_end) {
+        ++sg;
+        seg_start = seg_end;
+        seg_end += ep.seg_len[sg];
+      }
+      while (true) {   // wave-uniform loop over the segments that intersect [wrow0, wlast]
+        const bool whole = seg_start <= wrow0 && wlast < seg_end;
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int col = n0 + wn * (32 * NT) + j * 32 + (lane & 31);
-        float s = 0.f, ss = 0.f;
+        for (int j = 0; j < NT; ++j) {
+          const int col = n0 + wn * (32 * NT) + j * 32 + (lane & 31);
+          float s = 0.f, ss = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          const float v = (whole || (row >= seg_start && row < seg_end)) ? acc[j][r] : 0.f;
-          s += v;
-          ss = fmaf(v, v, ss);
+          for (int r = 0; r < 16; ++r) {
+            const int64_t row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float v = (whole || (row >= seg_start && row < seg_end)) ? acc[j][r] : 0.f;
+            s += v;
+            ss = fmaf(v, v, ss);
+          }
+          double ds = s, dss = ss;
+          // fold the two row-halves, then the lanes of one group (gs consecutive columns, capped at the 32-column tile)
+          ds += __shfl_xor(ds, 32);
+          dss += __shfl_xor(dss, 32);
+          const int span = gs < 32 ? gs : 32;
+          for (int d = 1; d < span; d <<= 1) {
+            ds += __shfl_xor(ds, d);
+            dss += __shfl_xor(dss, d);
+          }
+          if (lane < 32 && (lane & (span - 1)) == 0 && col < N) {
+            if (uniform) {
+              const int gl = (col - n0) / gs;
+              atomicAdd(&s_red[gl][0], ds);
+              atomicAdd(&s_red[gl][1], dss);
+            } else {
+              double* d = rep + (static_cast<int64_t>(sg) * ep.groups + col / gs) * 2;
+              atomicAdd(d, ds);
+              atomicAdd(d + 1, dss);
+            }
+          }
         }
-        double ds = s, dss = ss;
-        // fold the two row-halves, then the lanes of one group (gs consecutive columns, capped at the 32-column tile)
-        ds += __shfl_xor(ds, 32);
-        dss += __shfl_xor(dss, 32);
-        const int span = gs < 32 ? gs : 32;
-        for (int d = 1; d < span; d <<= 1) {
-          ds += __shfl_xor(ds, d);
-          dss += __shfl_xor(dss, d);
-        }
-        if (lane < 32 && (lane & (span - 1)) == 0 && col < N) {
-          double* d = ep.stats + (static_cast<int64_t>(sg) * ep.groups + col / gs) * 2;
-          atomicAdd(d, ds);
-          atomicAdd(d + 1, dss);
+        if (wlast < seg_end || sg + 1 >= ep.S) break;
+        ++sg;
+        seg_start = seg_end;
+        seg_end += ep.seg_len[sg];
+      }
+    }
+    if (uniform) {
+      __syncthreads();
+      const int ngl = (BN + gs - 1) / gs;
+      for (int i = threadIdx.x; i < ngl; i += GM_T) {
+        const int g = n0 / gs + i;
+        if (g < ep.groups && (n0 + i * gs) < N) {
+          double* d = rep + (static_cast<int64_t>(blk_first) * ep.groups + g) * 2;
+          atomicAdd(d, s_red[i][0]);
+          atomicAdd(d + 1, s_red[i][1]);
         }
       }
-      if (wlast < seg_end || sg + 1 >= ep.S) break;
-      ++sg;
-      seg_start = seg_end;
-      seg_end += ep.seg_len[sg];
     }
   }
 }
@@ -297,7 +334,7 @@ extern "C" int lcr_gemm_f32(const float* A, const float* B, float* C, int64_t M,
     }
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (stats) hipMemsetAsync(stats, 0, sizeof(double) * 2 * S * groups, st);
+  if (stats) hipMemsetAsync(stats, 0, sizeof(double) * 2 * S * groups * GN_REPLICAS, st);
   if (M == 0) return LCR_OK;
   GemmEpilogue ep{bias, rowdiv, seg_len, S, groups, stats};
   // 16-byte vector loads need leading dimensions that are multiples of 4 floats (bases: torch allocations are >= 256-B aligned,

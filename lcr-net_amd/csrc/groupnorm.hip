@@ -42,12 +42,22 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, G
   const int gs = C / groups;
   for (int i = threadIdx.x; i < S * groups; i += blockDim.x) {
     const double cnt = static_cast<double>(seg_len[i / groups]) * gs;
-    const double m = gx.stats[2 * i] / cnt;
-    const double var = fmax(gx.stats[2 * i + 1] / cnt - m * m, 0.0);
+    double sx = 0.0, sxx = 0.0, rx = 0.0, rxx = 0.0;
+    for (int rep = 0; rep < GN_REPLICAS; ++rep) {     // fold the statistics replicas (fixed order: deterministic given the sums)
+      const int64_t o = (static_cast<int64_t>(rep) * S * groups + i) * 2;
+      sx += gx.stats[o];
+      sxx += gx.stats[o + 1];
+      if (gr.stats) {
+        rx += gr.stats[o];
+        rxx += gr.stats[o + 1];
+      }
+    }
+    const double m = sx / cnt;
+    const double var = fmax(sxx / cnt - m * m, 0.0);
     s_x[i] = make_float2(static_cast<float>(m), static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps))));
     if (gr.stats) {
-      const double rm = gr.stats[2 * i] / cnt;
-      const double rv = fmax(gr.stats[2 * i + 1] / cnt - rm * rm, 0.0);
+      const double rm = rx / cnt;
+      const double rv = fmax(rxx / cnt - rm * rm, 0.0);
       s_r[i] = make_float2(static_cast<float>(rm), static_cast<float>(1.0 / sqrt(rv + static_cast<double>(eps))));
     }
   }
@@ -125,8 +135,9 @@ __global__ __launch_bounds__(256) void k_gn_stats(const float* __restrict__ x, i
         dss += __shfl_xor(dss, d);
       }
       if (c < C && (lane & (span - 1)) == 0) {
-        atomicAdd(&stats[(static_cast<int64_t>(sg) * groups + c / gs) * 2], ds);
-        atomicAdd(&stats[(static_cast<int64_t>(sg) * groups + c / gs) * 2 + 1], dss);
+        double* rep = stats + static_cast<int64_t>(blockIdx.x % GN_REPLICAS) * S * groups * 2;
+        atomicAdd(&rep[(static_cast<int64_t>(sg) * groups + c / gs) * 2], ds);
+        atomicAdd(&rep[(static_cast<int64_t>(sg) * groups + c / gs) * 2 + 1], dss);
       }
       s = ss = 0.f;
     };
@@ -183,7 +194,7 @@ extern "C" int lcr_groupnorm_stats(const float* x, int64_t N, int C, int groups,
     return LCR_EARG;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipMemsetAsync(stats, 0, sizeof(double) * 2 * S * groups, st);
+  hipMemsetAsync(stats, 0, sizeof(double) * 2 * S * groups * GN_REPLICAS, st);
   if (N == 0) return LCR_OK;
   hipLaunchKernelGGL(k_gn_stats, dim3(static_cast<int>((N + 255) / 256)), dim3(256), 0, st, x, N, C, groups, seg_len, S, stats);   // 4 waves x 64 rows
   return check_launch("lcr_groupnorm_stats");

@@ -99,24 +99,28 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate(const float*
 #pragma unroll
       for (int k = 0; k < KP_K; ++k) acc[j][k] = 0.f;
 
+    // Feature rows are gathered PF neighbours ahead (PF independent global loads in flight per lane) — the gather latency
+    // (L2 / Infinity-Cache misses on ~random rows) is what bounds this loop, not the 15 FMAs per neighbour and channel.
     if (HALF) {
+      constexpr int PF = 4;                       // per half-wave => 8 neighbours of the query in flight
       const int g = lane >> 5, c = lane & 31;
-      int h = g;
-      for (; h + 2 < n; h += 4) {   // two neighbours of this half-wave in flight
-        const float f0 = s_feats[static_cast<int64_t>(s_idx[w][h]) * C + c];
-        const float f1 = s_feats[static_cast<int64_t>(s_idx[w][h + 2]) * C + c];
-        float w0[16], w1[16];
-        load_w16(&s_w[w][h * 16], w0);
-        load_w16(&s_w[w][(h + 2) * 16], w1);
+      const int nh = (n - g + 1) / 2;             // neighbours owned by this half-wave: h = g, g+2, ...
+      for (int i0 = 0; i0 < nh; i0 += PF) {
+        float f[PF];
 #pragma unroll
-        for (int k = 0; k < KP_K; ++k) acc[0][k] = fmaf(w1[k], f1, fmaf(w0[k], f0, acc[0][k]));
-      }
-      for (; h < n; h += 2) {
-        const float f = s_feats[static_cast<int64_t>(s_idx[w][h]) * C + c];
-        float w0[16];
-        load_w16(&s_w[w][h * 16], w0);
+        for (int u = 0; u < PF; ++u) {
+          const int i = i0 + u < nh ? i0 + u : nh - 1;
+          f[u] = s_feats[static_cast<int64_t>(s_idx[w][g + 2 * i]) * C + c];
+        }
 #pragma unroll
-        for (int k = 0; k < KP_K; ++k) acc[0][k] = fmaf(w0[k], f, acc[0][k]);
+        for (int u = 0; u < PF; ++u) {
+          if (i0 + u < nh) {
+            float wv[16];
+            load_w16(&s_w[w][(g + 2 * (i0 + u)) * 16], wv);
+#pragma unroll
+            for (int k = 0; k < KP_K; ++k) acc[0][k] = fmaf(wv[k], f[u], acc[0][k]);
+          }
+        }
       }
 #pragma unroll
       for (int k = 0; k < KP_K; ++k) acc[0][k] += __shfl_xor(acc[0][k], 32);
@@ -126,34 +130,26 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate(const float*
         for (int k = 0; k < KP_K; ++k) out[k * C + c] = acc[0][k];
       }
     } else {
-      int h = 0;
-      for (; h + 2 <= n; h += 2) {   // two neighbours in flight
-        const float* r0 = s_feats + static_cast<int64_t>(s_idx[w][h]) * C;
-        const float* r1 = s_feats + static_cast<int64_t>(s_idx[w][h + 1]) * C;
-        float f0[CPL], f1[CPL];
+      constexpr int PF = CPL >= 4 ? 2 : (CPL == 2 ? 4 : 8);
+      for (int h0 = 0; h0 < n; h0 += PF) {
+        float f[PF][CPL];
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-          f0[j] = r0[lane + 64 * j];
-          f1[j] = r1[lane + 64 * j];
+        for (int u = 0; u < PF; ++u) {
+          const int h = h0 + u < n ? h0 + u : n - 1;
+          const float* r0 = s_feats + static_cast<int64_t>(s_idx[w][h]) * C;
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) f[u][j] = r0[lane + 64 * j];
         }
-        float w0[16], w1[16];
-        load_w16(&s_w[w][h * 16], w0);
-        load_w16(&s_w[w][(h + 1) * 16], w1);
 #pragma unroll
-        for (int k = 0; k < KP_K; ++k) {
+        for (int u = 0; u < PF; ++u) {
+          if (h0 + u < n) {                        // wave-uniform
+            float wv[16];
+            load_w16(&s_w[w][(h0 + u) * 16], wv);
 #pragma unroll
-          for (int j = 0; j < CPL; ++j) acc[j][k] = fmaf(w1[k], f1[j], fmaf(w0[k], f0[j], acc[j][k]));
-        }
-      }
-      if (h < n) {
-        const float* r0 = s_feats + static_cast<int64_t>(s_idx[w][h]) * C;
-        float w0[16];
-        load_w16(&s_w[w][h * 16], w0);
+            for (int k = 0; k < KP_K; ++k)
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-          const float f = r0[lane + 64 * j];
-#pragma unroll
-          for (int k = 0; k < KP_K; ++k) acc[j][k] = fmaf(w0[k], f, acc[j][k]);
+              for (int j = 0; j < CPL; ++j) acc[j][k] = fmaf(wv[k], f[u][j], acc[j][k]);
+          }
         }
       }
       float* out = A + m * (KP_K * C);
@@ -236,7 +232,13 @@ __global__ __launch_bounds__(256) void k_maxpool(const float* __restrict__ x, co
     wave_lds_sync();
     for (int c = lane; c < C; c += 64) {
       float v = any_shadow ? 0.f : -INFINITY;
-      for (int h = 0; h < n; ++h) v = fmaxf(v, x[static_cast<int64_t>(s_idx[w][h]) * C + c]);
+      for (int h0 = 0; h0 < n; h0 += 8) {          // 8 independent row gathers in flight
+        float f[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) f[u] = x[static_cast<int64_t>(s_idx[w][h0 + u < n ? h0 + u : n - 1]) * C + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v = fmaxf(v, f[u]);   // duplicates of the last row do not change a max
+      }
       out[m * C + c] = v;
     }
     wave_lds_sync();

@@ -8,6 +8,7 @@ import torch
 from . import _lib
 
 GN_EPS = 1e-5
+GN_REPLICAS = 8   # must match csrc/common.h: statistics tables are [GN_REPLICAS, S, groups, 2]
 
 
 class KernelTimer:
@@ -64,7 +65,8 @@ def _idx_args(idx):
 
 def gemm(a, b, trans_b=False, trans_a=False, bias=None, rowdiv=None, seg_len=None, groups=0):
     """C = A·B (+ fused epilogue).  a: [M,K] ([K,M] if trans_a); b: [K,N] ([N,K] if trans_b, i.e. an nn.Linear weight).
-    Returns (C, stats) where stats is the fp64 [S,groups,2] GroupNorm accumulator (or None if groups == 0)."""
+    Returns (C, stats) where stats is the fp64 [GN_REPLICAS,S,groups,2] GroupNorm accumulator (sum the replicas; None if
+    groups == 0)."""
     _lib.require_cuda(a, b)
     assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.is_contiguous() and b.is_contiguous()
     M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
@@ -76,7 +78,7 @@ def gemm(a, b, trans_b=False, trans_a=False, bias=None, rowdiv=None, seg_len=Non
     if groups:
         seg_len = _seg(seg_len, M, a.device)
         S = seg_len.numel()
-        stats = torch.empty((S, groups, 2), dtype=torch.float64, device=a.device)
+        stats = torch.empty((GN_REPLICAS, S, groups, 2), dtype=torch.float64, device=a.device)
     _timed("gemm", lambda: _lib.check(_lib.lib().lcr_gemm_f32(
         _lib.ptr(a), _lib.ptr(b), _lib.ptr(c), M, N, K, int(trans_a), int(trans_b), _lib.ptr(bias), _lib.ptr(rowdiv),
         _lib.ptr(seg_len) if groups else None, S, int(groups), _lib.ptr(stats), _lib.stream_ptr(a.device)), "lcr_gemm_f32"),
@@ -86,7 +88,7 @@ def gemm(a, b, trans_b=False, trans_a=False, bias=None, rowdiv=None, seg_len=Non
 
 def groupnorm_stats(x, groups, seg_len=None):
     seg_len = _seg(seg_len, x.shape[0], x.device)
-    stats = torch.empty((seg_len.numel(), groups, 2), dtype=torch.float64, device=x.device)
+    stats = torch.empty((GN_REPLICAS, seg_len.numel(), groups, 2), dtype=torch.float64, device=x.device)
     _lib.check(_lib.lib().lcr_groupnorm_stats(_lib.ptr(x), x.shape[0], x.shape[1], groups, _lib.ptr(seg_len), seg_len.numel(),
                                               _lib.ptr(stats), _lib.stream_ptr(x.device)), "lcr_groupnorm_stats")
     return stats

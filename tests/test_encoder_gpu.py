@@ -70,6 +70,7 @@ def test_gemm_groupnorm_statistics_segmented():
     seg = torch.tensor([700, 1, 799])                       # a segment boundary inside a 128-row tile, a 1-row segment
     c, stats = F.gemm(a.cuda(), b.cuda(), seg_len=seg.cuda(), groups=groups)
     cc = c.cpu().double()
+    stats = stats.sum(0)          # fold the statistics replicas
     o = 0
     for s, n in enumerate(seg.tolist()):
         blk = cc[o:o + n].reshape(n, groups, N // groups)
