@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-upsampling", action="store_true", help="skip the 3 decoder-only upsampling searches")
+    ap.add_argument("--no-overlap", action="store_true", help="run pre-processing and encoder on one stream (no pipelining)")
     return ap.parse_args()
 
 
@@ -44,15 +45,6 @@ def make_batch(rank):
     scans = [synthetic.synthetic_scan(rank * BATCH + i) for i in range(BATCH)]
     return scans
 
-
-def step(model, raw_pts, raw_lens, upsampling=True):
-    from lcrnet_amd.data import precompute_batch, voxelize_raw_scans
-    pts, lens_dev, _ = voxelize_raw_scans(raw_pts, raw_lens, VOXEL)
-    dd = precompute_batch(pts.contiguous(), lens_dev, NUM_STAGES, VOXEL, RADIUS, LIMITS, upsampling=upsampling)
-    dd["features"] = torch.ones(pts.shape[0], 1, device=pts.device)
-    dd["lengths_c_host"] = dd["lengths_host"][-1]
-    out = model(dd)
-    return out["anc_global"], dd
 
 
 def cpu_baseline(scans, n_scans=2):
@@ -115,15 +107,22 @@ def main():
     raw_lens = torch.tensor([len(s) for s in scans], dtype=torch.int64, device=dev)
     gathered = torch.empty((world * BATCH, 256), dtype=torch.float32, device=dev) if world > 1 else None
 
-    def one():
-        with torch.no_grad():
-            desc, dd = step(model, raw_pts, raw_lens, upsampling=not args.no_upsampling)
+    from lcrnet_amd.pipeline import DescriptorPipeline
+    pipe = DescriptorPipeline(model, VOXEL, RADIUS, NUM_STAGES, LIMITS, upsampling=not args.no_upsampling, raw_voxel=VOXEL,
+                              overlap=not args.no_overlap)
+
+    def run_steps(n):
+        """n steps = n batches, each fully processed (voxelise .. descriptors [+ all-gather]); the pre-processing of step
+        k+1 overlaps the encoder of step k on a second stream (DescriptorPipeline)."""
+        last = None
+        for desc in pipe.run((raw_pts, raw_lens) for _ in range(n)):
             if world > 1:
                 dist.all_gather_into_tensor(gathered, desc.contiguous())
-        return desc, dd
+            last = desc
+        return last
 
-    for _ in range(args.warmup):
-        one()
+    run_steps(args.warmup)
+    stage_points = [sum(l) for l in pipe.preprocess(raw_pts, raw_lens)["lengths_host"]]
     # ---- timed region: exactly K steps between barrier + synchronize
     timer = F.KernelTimer({"kpconv_aggregate", "gemm"})
     if world > 1:
@@ -131,8 +130,7 @@ def main():
     torch.cuda.synchronize()
     F.set_timer(timer)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        desc, dd = one()
+    desc = run_steps(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -180,7 +178,8 @@ def main():
                                    "voxelise + 3 subsamples + %d radius searches + KPConv encoder + NetVLAD, seeded random weights"
                                    % (7 if args.no_upsampling else 10),
                        "scans_per_step_per_gpu": BATCH, "raw_points_per_scan": int(raw_pts.shape[0] // BATCH),
-                       "stage_points_per_batch": [sum(l) for l in dd["lengths_host"]], "neighbor_limits": LIMITS,
+                       "stage_points_per_batch": stage_points, "neighbor_limits": LIMITS,
+                       "streams": "1" if args.no_overlap else "2 (pre-processing of step k+1 overlaps encoder of step k)",
                        "parallelism": "scan-parallel x%d, all-gather of descriptors" % world},
             "roofline": roof,
         }
