@@ -95,6 +95,11 @@ int lcr_radius_search(const float* q, const float* s, const int64_t* qlen, const
 int lcr_gemm_f32(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB,
                  const float* bias, const float* rowdiv, const int64_t* seg_len, int S, int groups, double* stats,
                  void* stream);
+/* Tuning hook for tools/gemm_bench.py: 0 = heuristic tile choice, 1..5 = force 128x128 / 128x64 / 128x32 / 64x64 / 64x128. */
+void lcr_gemm_debug_force_tile(int tile);
+/* Batched C_z[M,N] = A_z^T · B_z with A_z stored [K_z, M] (per-entry K and element offsets, HOST arrays, count <= 64). */
+int lcr_gemm_f32_batched_ta(const float* A, const float* B, float* C, int64_t M, int N, int count, const int* k_host,
+                            const int64_t* a_off_host, const int64_t* b_off_host, const int64_t* c_off_host, void* stream);
 /* Gather + kernel-point influences + weighted aggregation of KPConv.forward (kpconv.py:91-105): A[m][k*C+c] =
  * sum_h max(0, 1-|s[idx[m,h]]-q[m]-kp[k]|/sigma) * s_feats[idx[m,h]][c];  nn[m] = max(1, #neighbours with s_pos != 0)
  * (kpconv.py:113-116).  kernel_points_host: 15x3 floats in HOST memory.  C in {32,64,128,256}, H <= 128. */

@@ -21,6 +21,14 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int GM_BK = 32;
 constexpr int GM_T = 256;
 
+// Optional batching over blockIdx.z: per-entry element offsets into A/B/C and per-entry K (NetVLAD's per-scan x^T·a products).
+constexpr int GM_MAX_BATCH = 64;
+struct GemmBatch {
+  int     count;                 // 0 = plain GEMM
+  int     k[GM_MAX_BATCH];
+  int64_t a_off[GM_MAX_BATCH], b_off[GM_MAX_BATCH], c_off[GM_MAX_BATCH];
+};
+
 struct GemmEpilogue {
   const float*   bias;      // [N] or null
   const float*   rowdiv;    // [M] or null: C[m][:] /= rowdiv[m] (before the bias), KPConv neighbour-count normalisation
@@ -124,8 +132,15 @@ __device__ __forceinline__ int seg_of_row(const int64_t* __restrict__ seg_len, i
 
 template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
-                                                       int64_t M, int N, int K, GemmEpilogue ep) {
+                                                       int64_t M, int N, int K, GemmEpilogue ep, GemmBatch batch) {
   static_assert(WM * WN == 4 && BM == 32 * WM, "one 32-row MFMA tile per wavefront along M");
+  if (batch.count) {
+    const int z = blockIdx.z;
+    A += batch.a_off[z];
+    B += batch.b_off[z];
+    C += batch.c_off[z];
+    K = batch.k[z];
+  }
   constexpr int LDA = TA ? BM + 4 : BM + 1;
   constexpr int LDB = TB ? BN + 1 : BN + 4;
   constexpr int NT = BN / (32 * WN);
@@ -302,19 +317,25 @@ __global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ 
 
 template <int BM, int BN, int WM, int WN, bool VEC>
 static int launch_gemm(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB, const GemmEpilogue& ep,
-                       hipStream_t st) {
-  dim3 grid(div_up(M, BM), div_up(N, BN));
+                       hipStream_t st, const GemmBatch* batch = nullptr) {
+  static const GemmBatch no_batch = {};
+  const GemmBatch& bt = batch ? *batch : no_batch;
+  dim3 grid(div_up(M, BM), div_up(N, BN), bt.count ? bt.count : 1);
   dim3 block(GM_T);
-  if (!transA && !transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, false, false, VEC>), grid, block, 0, st, A, B, C, M, N, K, ep);
-  else if (!transA && transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, false, true, VEC>), grid, block, 0, st, A, B, C, M, N, K, ep);
-  else if (transA && !transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, true, false, VEC>), grid, block, 0, st, A, B, C, M, N, K, ep);
-  else hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, true, true, VEC>), grid, block, 0, st, A, B, C, M, N, K, ep);
+  if (!transA && !transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, false, false, VEC>), grid, block, 0, st, A, B, C, M, N, K, ep, bt);
+  else if (!transA && transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, false, true, VEC>), grid, block, 0, st, A, B, C, M, N, K, ep, bt);
+  else if (transA && !transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, true, false, VEC>), grid, block, 0, st, A, B, C, M, N, K, ep, bt);
+  else hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, true, true, VEC>), grid, block, 0, st, A, B, C, M, N, K, ep, bt);
   return check_launch("lcr_gemm_f32");
 }
 
 }  // namespace lcr
 
 using namespace lcr;
+
+// tuning hook (tools/gemm_bench.py): 0 = heuristic, 1..5 = force a tile shape
+static int g_force_tile = 0;
+extern "C" void lcr_gemm_debug_force_tile(int t) { g_force_tile = t; }
 
 extern "C" int lcr_gemm_f32(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB, const float* bias,
                             const float* rowdiv, const int64_t* seg_len, int S, int groups, double* stats, void* stream) {
@@ -342,15 +363,46 @@ extern "C" int lcr_gemm_f32(const float* A, const float* B, float* C, int64_t M,
   const int64_t lda = transA ? M : K, ldb = transB ? K : N;
   const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (reinterpret_cast<uintptr_t>(B) % 16 == 0);
   if (!vec) return launch_gemm<128, 64, 4, 1, false>(A, B, C, M, N, K, transA, transB, ep, st);
-  constexpr int64_t ENOUGH = 384;   // workgroups wanted before a bigger tile is worth it (256 CUs, 2 resident per CU)
-  const int64_t b128 = (M + 127) / 128, b64 = (M + 63) / 64;
-  if (N <= 32) return launch_gemm<128, 32, 4, 1, true>(A, B, C, M, N, K, transA, transB, ep, st);
-  if (N <= 64) {
-    if (b128 >= ENOUGH) return launch_gemm<128, 64, 4, 1, true>(A, B, C, M, N, K, transA, transB, ep, st);
-    return launch_gemm<64, 64, 2, 2, true>(A, B, C, M, N, K, transA, transB, ep, st);
+  switch (g_force_tile) {
+    case 1: return launch_gemm<128, 128, 4, 1, true>(A, B, C, M, N, K, transA, transB, ep, st);
+    case 2: return launch_gemm<128, 64, 4, 1, true>(A, B, C, M, N, K, transA, transB, ep, st);
+    case 3: return launch_gemm<128, 32, 4, 1, true>(A, B, C, M, N, K, transA, transB, ep, st);
+    case 4: return launch_gemm<64, 64, 2, 2, true>(A, B, C, M, N, K, transA, transB, ep, st);
+    case 5: return launch_gemm<64, 128, 2, 2, true>(A, B, C, M, N, K, transA, transB, ep, st);
+    default: break;
   }
-  const int64_t nb128 = (N + 127) / 128;
-  if (b128 * nb128 >= ENOUGH) return launch_gemm<128, 128, 4, 1, true>(A, B, C, M, N, K, transA, transB, ep, st);
-  if (b64 * nb128 >= ENOUGH) return launch_gemm<64, 128, 2, 2, true>(A, B, C, M, N, K, transA, transB, ep, st);
+  // Tile choice from tools/gemm_bench.py --tiles on MI355X: 64x64 (2x2 wavefronts) wins or ties on every encoder shape with
+  // N >= 64 (enough workgroups for two per CU matters more than per-tile reuse at these M); N = 32 wants the 128-row tile;
+  // only large, deep problems (>= 512 tiles of 128x128 and K >= 512) pay for the big tile.
+  const int64_t b128 = (M + 127) / 128, nb128 = (N + 127) / 128;
+  if (N <= 32) return launch_gemm<128, 32, 4, 1, true>(A, B, C, M, N, K, transA, transB, ep, st);
+  if (K >= 512 && b128 * nb128 >= 512) return launch_gemm<128, 128, 4, 1, true>(A, B, C, M, N, K, transA, transB, ep, st);
   return launch_gemm<64, 64, 2, 2, true>(A, B, C, M, N, K, transA, transB, ep, st);
+}
+
+// Batched C_z = A_z^T·B_z (transA) with per-entry K — NetVLAD's per-scan aggregation (NetVlad.py:68): one launch for S scans.
+extern "C" int lcr_gemm_f32_batched_ta(const float* A, const float* B, float* C, int64_t M, int N, int count, const int* k_host,
+                                       const int64_t* a_off_host, const int64_t* b_off_host, const int64_t* c_off_host, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || count < 1 || count > GM_MAX_BATCH || !k_host || !a_off_host || !b_off_host || !c_off_host) {
+    set_error("lcr_gemm_f32_batched_ta: bad argument (count <= %d)", GM_MAX_BATCH);
+    return LCR_EARG;
+  }
+  GemmBatch bt = {};
+  bt.count = count;
+  for (int i = 0; i < count; ++i) {
+    bt.k[i] = k_host[i];
+    bt.a_off[i] = a_off_host[i];
+    bt.b_off[i] = b_off_host[i];
+    bt.c_off[i] = c_off_host[i];
+    if (a_off_host[i] % 4 || b_off_host[i] % 4 || k_host[i] < 1) {
+      set_error("lcr_gemm_f32_batched_ta: offsets must be multiples of 4 floats and K >= 1");
+      return LCR_EARG;
+    }
+  }
+  if ((M % 4) || (N % 4)) {
+    set_error("lcr_gemm_f32_batched_ta: M and N must be multiples of 4");
+    return LCR_EARG;
+  }
+  GemmEpilogue ep{nullptr, nullptr, nullptr, 0, 0, nullptr};
+  return launch_gemm<64, 64, 2, 2, true>(A, B, C, M, N, /*K (per entry)*/ 1, 1, 0, ep, static_cast<hipStream_t>(stream), &bt);
 }

@@ -31,6 +31,10 @@ template <typename IdxT>
 __device__ __forceinline__ int gather_neighbours(const IdxT* __restrict__ row, int H, int64_t Ns, const float* __restrict__ s_pts,
                                                  const float* __restrict__ q, const KPoints& kp, float sigma,
                                                  int32_t* __restrict__ l_idx, float* __restrict__ l_w /*[KP_HMAX][16]*/) {
+  // influence = max(0, 1 - |y - k| / sigma) (kpconv.py:96-99) evaluated as 1 - sqrt(d2) * (1/sigma) with the hardware
+  // v_sqrt_f32 (1 ulp): ~2 ulp from the reference's sqrt-then-divide, far inside the 1e-4 feature tolerance, and ~2x
+  // fewer issue slots than the correctly-rounded sqrt + IEEE division sequence
+  const float inv_sigma = 1.f / sigma;
   const int lane = threadIdx.x & 63;
   int n = 0;
   for (int h0 = 0; h0 < H; h0 += 64) {
@@ -46,8 +50,8 @@ __device__ __forceinline__ int gather_neighbours(const IdxT* __restrict__ row, i
 #pragma unroll
       for (int k = 0; k < KP_K; ++k) {
         const float ex = dx - kp.p[k][0], ey = dy - kp.p[k][1], ez = dz - kp.p[k][2];
-        const float d2 = ex * ex + ey * ey + ez * ez;
-        l_w[slot * 16 + k] = fmaxf(1.f - sqrtf(d2) / sigma, 0.f);
+        const float d2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+        l_w[slot * 16 + k] = fmaxf(1.f - __builtin_amdgcn_sqrtf(d2) * inv_sigma, 0.f);
       }
     }
     n += __popcll(m);
@@ -173,6 +177,7 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_cin1(const float* __re
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int64_t m = static_cast<int64_t>(blockIdx.x) * KP_WAVES + w; m < M; m += static_cast<int64_t>(gridDim.x) * KP_WAVES) {
     const float qx = q_pts[3 * m], qy = q_pts[3 * m + 1], qz = q_pts[3 * m + 2];
+    const float inv_sigma = 1.f / sigma;
     float a[KP_K];
 #pragma unroll
     for (int k = 0; k < KP_K; ++k) a[k] = 0.f;
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_cin1(const float* __re
 #pragma unroll
         for (int k = 0; k < KP_K; ++k) {
           const float ex = dx - kp.p[k][0], ey = dy - kp.p[k][1], ez = dz - kp.p[k][2];
-          a[k] = fmaf(fmaxf(1.f - sqrtf(ex * ex + ey * ey + ez * ez) / sigma, 0.f), f, a[k]);
+          a[k] = fmaf(fmaxf(1.f - __builtin_amdgcn_sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * inv_sigma, 0.f), f, a[k]);
         }
       }
     }

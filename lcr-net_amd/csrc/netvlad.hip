@@ -10,12 +10,15 @@
 // Steps: row L2-normalise (wave per row) -> assignment GEMM (lcr_gemm_f32, K=1024, N=64) -> BN + softmax over the 64 clusters
 // (lane = cluster) -> per-segment x^T·a GEMM (TA) and column sums -> residual / intra-normalise / global normalise ->
 // split-K hidden projection -> BN2, gating GEMV, sigmoid, final L2 normalise (one workgroup per scan).
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
 
 extern "C" int lcr_gemm_f32(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB, const float* bias,
                             const float* rowdiv, const int64_t* seg_len, int S, int groups, double* stats, void* stream);
+extern "C" int lcr_gemm_f32_batched_ta(const float* A, const float* B, float* C, int64_t M, int N, int count, const int* k_host,
+                                       const int64_t* a_off_host, const int64_t* b_off_host, const int64_t* c_off_host, void* stream);
 
 namespace lcr {
 
@@ -58,15 +61,25 @@ __global__ __launch_bounds__(256) void k_bn_softmax64(float* __restrict__ act, i
   }
 }
 
-// a_sum[s][k] = sum over the rows of segment s (deterministic: fixed row partition + fixed combine order)
-__global__ __launch_bounds__(256) void k_colsum64(const float* __restrict__ act, int64_t row0, int64_t rows, float* __restrict__ out) {
-  __shared__ float part[4][NV_K];
+struct SegRows {
+  int64_t off[65];   // row offsets of up to 64 segments (+ total)
+};
+
+// a_sum[s][k] = sum over the rows of segment s = blockIdx.x (deterministic: fixed row partition + fixed combine order)
+__global__ __launch_bounds__(1024) void k_colsum64(const float* __restrict__ act, SegRows seg, float* __restrict__ out) {
+  __shared__ float part[16][NV_K];
   const int k = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t row0 = seg.off[blockIdx.x], rows = seg.off[blockIdx.x + 1] - row0;
   float s = 0.f;
-  for (int64_t n = q; n < rows; n += 4) s += act[(row0 + n) * NV_K + k];
+  for (int64_t n = q; n < rows; n += 16) s += act[(row0 + n) * NV_K + k];
   part[q][k] = s;
   __syncthreads();
-  if (q == 0) out[k] = (part[0][k] + part[1][k]) + (part[2][k] + part[3][k]);
+  if (q == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += part[i][k];
+    out[blockIdx.x * NV_K + k] = t;
+  }
 }
 
 // V[c][k] (1024 x 64 per segment): subtract a_sum * Wc2, normalise each cluster column over c (eps 1e-6), then the whole
@@ -208,15 +221,28 @@ extern "C" int lcr_netvlad_forward(const float* feats, const int64_t* seg_len_ho
   int rc = lcr_gemm_f32(xn, wt->cluster_weights, act, N, NV_K, NV_F, 0, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(k_bn_softmax64, dim3(nblk), dim3(256), 0, st, act, N, BnParams{wt->bn1_w, wt->bn1_b, wt->bn1_mean, wt->bn1_var}, bn_eps);
-  int64_t r0 = 0;
-  for (int s = 0; s < S; ++s) {
-    const int64_t n = seg_len_host[s];
-    // V_s (1024 x 64) = xn_s^T (1024 x n) · act_s (n x 64): A is stored K-major -> transA
-    rc = lcr_gemm_f32(xn + r0 * NV_F, act + r0 * NV_K, V + static_cast<size_t>(s) * NV_F * NV_K, NV_F, NV_K, static_cast<int>(n), 1, 0, nullptr,
-                      nullptr, nullptr, 0, 0, nullptr, stream);
+  // V_s (1024 x 64) = xn_s^T (1024 x n_s) · act_s (n_s x 64) for all scans, 64 scans per launch: A is stored K-major -> transA
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int cnt = std::min(64, S - s0);
+    int kk[64];
+    int64_t ao[64], bo[64], co[64];
+    SegRows seg;
+    int64_t r0 = 0;
+    for (int s = 0; s < s0; ++s) r0 += seg_len_host[s];
+    for (int i = 0; i < cnt; ++i) {
+      const int64_t n = seg_len_host[s0 + i];
+      if (n > 2147483647LL) return LCR_EARG;
+      kk[i] = static_cast<int>(n);
+      ao[i] = r0 * NV_F;
+      bo[i] = r0 * NV_K;
+      co[i] = static_cast<int64_t>(s0 + i) * NV_F * NV_K;
+      seg.off[i] = r0;
+      r0 += n;
+    }
+    seg.off[cnt] = r0;
+    rc = lcr_gemm_f32_batched_ta(xn, act, V, NV_F, NV_K, cnt, kk, ao, bo, co, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_colsum64, dim3(1), dim3(256), 0, st, act, r0, n, asum + s * NV_K);
-    r0 += n;
+    hipLaunchKernelGGL(k_colsum64, dim3(cnt), dim3(1024), 0, st, act, seg, asum + s0 * NV_K);
   }
   hipLaunchKernelGGL(k_vlad_finalize, dim3(S), dim3(1024), 0, st, V, asum, wt->cluster_weights2);
   for (int s0 = 0; s0 < S; s0 += 8)

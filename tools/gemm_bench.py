@@ -17,13 +17,22 @@ SHAPES = [  # (tag, M, N, K, transB, stats, rowdiv)
 
 
 def main():
+    import ctypes
+    from lcrnet_amd import _lib
     dev = torch.device("cuda")
-    for tag, M, N, K, tb, stats, rd in SHAPES:
+    tiles = [0] if "--tiles" not in sys.argv else [0, 1, 2, 3, 4, 5]
+    names = {0: "auto", 1: "128x128", 2: "128x64", 3: "128x32", 4: "64x64", 5: "64x128"}
+    for tile in tiles:
+      ctypes.CDLL(_lib.LIB_PATH).lcr_gemm_debug_force_tile(tile)
+      print("---- tile", names[tile])
+      for tag, M, N, K, tb, stats, rd in SHAPES:
+        if tile and ((tile == 3 and N > 32) or (tile in (2, 4) and N > 64 and False)):
+            continue
         a = torch.randn(M, K, device=dev)
         b = torch.randn((N, K) if tb else (K, N), device=dev)
         bias = torch.randn(N, device=dev)
         div = torch.rand(M, device=dev) + 1 if rd else None
-        seg = torch.tensor([M // 8] * 7 + [M - 7 * (M // 8)], dtype=torch.int64, device=dev)
+        seg = torch.tensor([M // 8 - 3] * 7 + [M - 7 * (M // 8 - 3)], dtype=torch.int64, device=dev)
         kw = dict(trans_b=bool(tb), bias=bias, rowdiv=div, seg_len=seg if stats else None, groups=32 if stats else 0)
         for _ in range(3):
             F.gemm(a, b, **kw)
