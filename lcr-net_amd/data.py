@@ -96,3 +96,28 @@ def voxelize_raw_scans(points, lengths, voxel_size, key_bits_hint=40):
         raise RuntimeError("voxelize_raw_scans: device status 0x%x" % st)
     lh = host[:-1].tolist()
     return out[:sum(lh)], out_len, lh
+
+
+def calibrate_neighbors_stack_mode(clouds, num_stages, voxel_size, search_radius, keep_ratio=0.8, sample_threshold=2000):
+    """Neighbour-limit calibration of data.py:408-433 from device-side counts: `clouds` is an iterable of f32[N,3] device
+    tensors (one stack each; the reference feeds dataset items through the collate with limit = hist_n).  Only per-row
+    in-radius counts are needed, so the searches run in count-only mode."""
+    import numpy as np
+    from .modules.ops import grid_subsample, radius_count
+    hist_n = int(np.ceil(4 / 3 * np.pi * (search_radius / voxel_size + 1) ** 3))
+    hists = np.zeros((num_stages, hist_n), dtype=np.int64)
+    for pts in clouds:
+        lens = torch.tensor([pts.shape[0]], dtype=torch.int64, device=pts.device)
+        v, r = voxel_size, search_radius
+        for i in range(num_stages):
+            if i > 0:
+                pts, lens = grid_subsample(pts, lens, v)
+                pts = pts.contiguous()
+            v *= 2
+            c = radius_count(pts, pts, lens, lens, r).clamp(max=hist_n - 1).cpu().numpy()   # width is capped at hist_n there
+            hists[i] += np.bincount(c, minlength=hist_n)[:hist_n]
+            r *= 2
+        if hists.sum(1).min() > sample_threshold:
+            break
+    cum = np.cumsum(hists.T, axis=0)
+    return np.sum(cum < (keep_ratio * cum[hist_n - 1, :]), axis=0)

@@ -1,0 +1,49 @@
+"""CPU: on-disk formats and metric definitions (host logic) — round trips and hand-checkable cases."""
+import numpy as np
+
+from lcrnet_amd import evaluation as ev
+from lcrnet_amd import io_formats as io
+
+
+def test_descriptor_npz_roundtrip(tmp_path):
+    g = np.random.default_rng(0).standard_normal((5, 256)).astype(np.float32)
+    for i in range(5):
+        io.save_descriptor(str(tmp_path), 0, i, g[i])
+    back = io.load_descriptors(str(tmp_path), 0)
+    assert back.shape == (5, 256) and np.array_equal(back, g)
+    one = np.load(tmp_path / "0_3.npz")["anc_global"]
+    assert one.shape == (1, 256) and one.dtype == np.float32
+
+
+def test_pair_dist_rows_and_metrics(tmp_path):
+    # 400 frames; frame i >= 200 revisits frame i-200 (ground truth), descriptors = place id + noise
+    rng = np.random.default_rng(1)
+    place = rng.standard_normal((200, 256)).astype(np.float32)
+    desc = np.concatenate([place, place + 0.01 * rng.standard_normal((200, 256)).astype(np.float32)])
+    desc /= np.linalg.norm(desc, axis=1, keepdims=True)
+    import torch
+    from oracle import torch_ref
+    qs, idx, d2 = torch_ref.retrieval_topk(torch.from_numpy(desc), k=50, exclude=100, start=101)
+    rows = io.pair_dist_rows(qs.numpy(), idx.numpy(), d2.numpy())
+    assert rows.shape == ((400 - 1 - 101) * 50, 3) and rows.dtype == np.float64
+    assert rows[0, 0] == 101 and rows[0, 1] == 0                      # frame 101 has a 1-frame database
+    assert rows[1, 1] == -1 and rows[1, 2] == float(io.FAISS_EMPTY_DISTANCE)
+    io.save_pair_dist(str(tmp_path), rows)
+    assert np.array_equal(np.load(tmp_path / "predicted_des_L2_dis.npz")["arr_0"], rows)
+    gt = np.empty(400, dtype=object)
+    for i in range(400):
+        gt[i] = np.array([i - 200]) if i >= 200 else np.array([])
+    # frames 1..100 have no rows and no GT; frame 0 has gt [] -> .any() False (the reference's test, :47)
+    assert ev.compute_topN(rows, gt, 1) == 1.0
+    p, r = ev.compute_PR_overlap(rows, gt)
+    f1, _ = ev.compute_F1(p, r)
+    assert f1 > 0.99 and ev.auc(p, r) >= 0.0
+
+
+def test_lcr_output_line():
+    T = np.eye(4)
+    T[:3, 3] = [1.5, -2.25, 0.125]
+    line = io.lcr_output_line(3854, 958, np.ones(256), np.zeros(256), T)
+    parts = line.split()
+    assert parts[0] == "3854" and parts[1] == "958" and parts[2] == "16.00" and len(parts) == 15
+    assert parts[3] == "1.000000" and parts[6] == "1.500000"

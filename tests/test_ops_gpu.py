@@ -124,3 +124,12 @@ def test_raw_scan_voxel03(ops_golden):
     assert gl.cpu().tolist() == [n0, int(ops_golden["syn1/voxel03_n"])]
     assert sha(got[:n0]) == str(ops_golden["syn0/voxel03_sha"])
     assert sha(got[n0:]) == str(ops_golden["syn1/voxel03_sha"])
+
+
+def test_neighbor_limit_calibration_matches_reference_demo_values():
+    """calibrate_neighbors_stack_mode (data.py:408-433) from device-side counts: the reference demo pair calibrates to
+    [74, 68, 70, 67] (measured with the reference itself)."""
+    from lcrnet_amd.data import calibrate_neighbors_stack_mode
+    clouds = [dev(load_scan("003854")), dev(load_scan("000958"))]
+    limits = calibrate_neighbors_stack_mode(clouds, NUM_STAGES, VOXEL, RADIUS)
+    assert limits.tolist() == LIMITS
