@@ -221,3 +221,227 @@ def recall_at_1(qs, idx, gt):
         tot += 1
         hit += int(row[0] in g)
     return hit / max(tot, 1)
+
+
+# ------------------------------------------------------------------------------------------------ pose tail (a-10)
+def vote_layer(sd, pfx, xyz, feats, max_range=4.2):
+    """modules/vote/vote.py:112-182 (output_feats=False): MLP(Linear-LayerNorm-ReLU x2) -> ctr_reg -> offsets clamped to
+    `max_range` -> shifted points."""
+    x = feats
+    for i in (0, 3):
+        x = F.linear(x, sd[f"{pfx}mlp_modules.{i}.weight"], sd[f"{pfx}mlp_modules.{i}.bias"])
+        x = F.relu(F.layer_norm(x, (x.shape[-1],), sd[f"{pfx}mlp_modules.{i + 1}.weight"], sd[f"{pfx}mlp_modules.{i + 1}.bias"], 1e-5))
+    off = F.linear(x, sd[pfx + "ctr_reg.weight"], sd[pfx + "ctr_reg.bias"])
+    dis = torch.norm(off, p=2, dim=1)
+    alpha = torch.where(dis > max_range, max_range / dis, torch.ones_like(dis))
+    return xyz + off * alpha[:, None]
+
+
+def greedy_nms(nodes, lengths, radius):
+    """modules/vote/vote.py:13-70 (NMS.forward without scores): per cloud, node 0 is kept; node i is kept iff its
+    nn.PairwiseDistance (||a - b + 1e-6||_2) to EVERY kept node exceeds `radius`.  Order dependent by definition."""
+    masks, lens, o = [], [], 0
+    for n in lengths:
+        n = int(n)
+        pts = nodes[o:o + n]
+        keep = torch.zeros(n, dtype=torch.bool)
+        if n:
+            keep[0] = True
+        for i in range(1, n):
+            d = torch.sqrt(((pts[i][None] - pts[keep] + 1e-6) ** 2).sum(1))
+            if bool((d > radius).all()):
+                keep[i] = True
+        masks.append(keep)
+        lens.append(int(keep.sum()))
+        o += n
+    return torch.cat(masks), torch.tensor(lens, dtype=torch.int64)
+
+
+def _radius_search(q, s, ql, sl, radius, limit):
+    from oracle import ops
+    return torch.from_numpy(ops.radius_search(q.numpy(), s.numpy(), ql.numpy(), sl.numpy(), radius, limit))
+
+
+def vote_encoder(sd, feats, data_dict, limits, init_radius=1.275, init_sigma=0.6, groups=32, pfx="vote_encoder.", nms_radius=2.4):
+    """backbone4.py:121-220 Vote_Encoder.forward on a pair stack (GroupNorm over the stack, like the reference)."""
+    lens_c = data_dict["lengths"][-1]
+    n0, n1 = int(lens_c[0]), int(lens_c[1])
+    points_c = data_dict["points"][-1]
+    shifted = vote_layer(sd, pfx + "vote.", points_c, feats)
+    mask, length = greedy_nms(shifted, lens_c, nms_radius)
+    nms_pts = shifted[mask]
+    knn = _radius_search(nms_pts, shifted, length, lens_c, 2.4, limits[-1])          # pad = n0 + n1
+    pad = n0 + n1
+    valid = knn != pad
+    sp = torch.cat([shifted, torch.zeros_like(shifted[:1])], 0)
+    centers = sp[knn].sum(1) / valid.sum(-1, keepdim=True)                          # mean of the in-radius voted points
+    sub = _radius_search(centers, points_c, length, lens_c, init_radius * 8, limits[-2])
+    nb = _radius_search(centers, centers, length, length, init_radius * 16, limits[-1])
+    f = residual_block(sd, pfx + "encoder6_1.", feats, centers, points_c, sub, init_sigma * 8, groups, True)
+    f = residual_block(sd, pfx + "encoder6_2.", f, centers, centers, nb, init_sigma * 16, groups, False)
+    f = residual_block(sd, pfx + "encoder6_3.", f, centers, centers, nb, init_sigma * 16, groups, False)
+    return {"shifted": shifted, "mask": mask, "length": length, "centers": centers, "feats_c": f,
+            "subsampling": sub, "neighbors": nb}
+
+
+def point_to_node_partition(points, nodes, point_limit):
+    """modules/ops/pointcloud_partition.py:60-107: nearest node per point (x^2 - 2xy + y^2 distances, clamp 1e-12), then per
+    node the `point_limit` nearest of its own points (ascending), padded with len(points)."""
+    d = (nodes ** 2).sum(1)[:, None] - 2 * nodes @ points.t() + (points ** 2).sum(1)[None]
+    d = d.clamp(min=1e-12)
+    p2n = d.argmin(0)
+    node_masks = torch.zeros(nodes.shape[0], dtype=torch.bool)
+    node_masks[p2n] = True
+    own = torch.zeros_like(d, dtype=torch.bool)
+    own[p2n, torch.arange(points.shape[0])] = True
+    d = d.masked_fill(~own, 1e12)
+    knn = d.topk(point_limit, dim=1, largest=False)[1]
+    knn_masks = p2n[knn] == torch.arange(nodes.shape[0])[:, None]
+    knn = knn.masked_fill(~knn_masks, points.shape[0])
+    return p2n, node_masks, knn, knn_masks
+
+
+def log_optimal_transport(scores, row_masks, col_masks, alpha, iters=100, inf=1e12):
+    """modules/sinkhorn/learnable_sinkhorn.py:20-66 (SuperGlue-style log-domain Sinkhorn with a learnable dustbin score)."""
+    B, M, N = scores.shape
+    prm = torch.zeros(B, M + 1, dtype=torch.bool)
+    prm[:, :M] = ~row_masks
+    pcm = torch.zeros(B, N + 1, dtype=torch.bool)
+    pcm[:, :N] = ~col_masks
+    S = torch.cat([torch.cat([scores, alpha.expand(B, M, 1)], -1), alpha.expand(B, 1, N + 1)], 1)
+    S = S.masked_fill(prm[:, :, None] | pcm[:, None, :], -inf)
+    nr, nc = row_masks.float().sum(1), col_masks.float().sum(1)
+    norm = -torch.log(nr + nc)
+    log_mu = norm[:, None].expand(B, M + 1).clone()
+    log_mu[:, M] = torch.log(nc) + norm
+    log_mu[prm] = -inf
+    log_nu = norm[:, None].expand(B, N + 1).clone()
+    log_nu[:, N] = torch.log(nr) + norm
+    log_nu[pcm] = -inf
+    u, v = torch.zeros_like(log_mu), torch.zeros_like(log_nu)
+    for _ in range(iters):
+        u = log_mu - torch.logsumexp(S + v[:, None, :], dim=2)
+        v = log_nu - torch.logsumexp(S + u[:, :, None], dim=1)
+    return S + u[:, :, None] + v[:, None, :] - norm[:, None, None]
+
+
+def superpoint_matching_ot(log_scores):
+    """geotransformer/superpoint_matching.py:54-187 with num_correspondences=None: a pair (i,j) is kept if it is the column
+    maximum and beats the dustbin row, OR the row maximum and beats the dustbin column; row-major order."""
+    P = torch.exp(log_scores)
+    col_top = torch.zeros_like(P)
+    ci = P.argmax(0)
+    col_top[ci, torch.arange(P.shape[1])] = P.max(0)[0]
+    src = col_top > P[-1, :][None]
+    row_top = torch.zeros_like(P)
+    ri = P.argmax(1)
+    row_top[torch.arange(P.shape[0]), ri] = P.max(1)[0]
+    ref = row_top > P[:, -1][:, None]
+    corr = (ref | src)[:-1, :-1].nonzero()
+    return corr[:, 0], corr[:, 1], P[corr[:, 0], corr[:, 1]]
+
+
+def kp_decoder(sd, feats_list, data_dict, groups=32, pfx="kpdecoder."):
+    """backbone4.py:344-373: nearest-upsample (column 0) + concat + UnaryBlock, three times; returns the finest features."""
+    def up(x, idx):
+        x = torch.cat([x, torch.zeros_like(x[:1])], 0)
+        return x[idx[:, 0]]
+    f1, f2, f3, f4 = feats_list
+    U = data_dict["upsampling"]
+    l3 = unary(sd, pfx + "decoder3.", torch.cat([up(f4, U[2]), f3], 1), groups, True)
+    l2 = unary(sd, pfx + "decoder2.", torch.cat([up(l3, U[1]), f2], 1), groups, True)
+    return F.linear(torch.cat([up(l2, U[0]), f1], 1), sd[pfx + "decoder1.mlp.weight"], sd[pfx + "decoder1.mlp.bias"])
+
+
+def weighted_procrustes(src, ref, w, eps=1e-5):
+    """modules/registration/procrustes.py:6-73 (batched): R = V diag(1,1,sign det(V U^T)) U^T of H = sum w (s - s̄)(r - r̄)^T."""
+    if src.dim() == 2:
+        return weighted_procrustes(src[None], ref[None], w[None], eps)[0]
+    w = torch.where(w < 0.0, torch.zeros_like(w), w)
+    w = (w / (w.sum(1, keepdim=True) + eps))[:, :, None]
+    sc, rc = (src * w).sum(1, keepdim=True), (ref * w).sum(1, keepdim=True)
+    H = (src - sc).transpose(1, 2) @ (w * (ref - rc))
+    U, _, V = torch.svd(H)
+    Ut = U.transpose(1, 2)
+    eye = torch.eye(3).repeat(src.shape[0], 1, 1)
+    eye[:, -1, -1] = torch.sign(torch.det(V @ Ut))
+    R = V @ eye @ Ut
+    t = (rc.transpose(1, 2) - R @ sc.transpose(1, 2))[:, :, 0]
+    T = torch.eye(4).repeat(src.shape[0], 1, 1)
+    T[:, :3, :3], T[:, :3, 3] = R, t
+    return T
+
+
+def _apply(T, p):
+    return p @ T[..., :3, :3].transpose(-1, -2) + T[..., None, :3, 3]
+
+
+def local_global_registration(ref_knn_pts, src_knn_pts, ref_masks, src_masks, log_scores, acceptance_radius=0.45, threshold=3, steps=5):
+    """geotransformer/local_global_registration.py:204-246 with k=1, mutual=False, use_dustbin=True, no correspondence limit."""
+    S = torch.exp(log_scores)
+    B, M1, N1 = S.shape
+    bi = torch.arange(B)
+    rtop = torch.zeros_like(S)
+    rv, ri = S.max(2)
+    rtop[bi[:, None], torch.arange(M1)[None], ri] = rv
+    ref_c = rtop > S[:, :, -1][:, :, None]
+    stop = torch.zeros_like(S)
+    sv, si = S.max(1)
+    stop[bi[:, None], si, torch.arange(N1)[None]] = sv
+    src_c = stop > S[:, -1, :][:, None, :]
+    corr = (ref_c | src_c)[:, :-1, :-1] & (ref_masks[:, :, None] & src_masks[:, None, :])
+    S = S[:, :-1, :-1] * corr.float()
+    b, i, j = corr.nonzero(as_tuple=True)
+    rp, sp, sc = ref_knn_pts[b, i], src_knn_pts[b, j], S[b, i, j]
+    # per-patch hypotheses (chunks of >= threshold correspondences), best by inlier count over ALL correspondences
+    counts = torch.bincount(b, minlength=B)
+    best_T, best_inl = None, -1
+    Ts = []
+    for p in torch.nonzero(counts >= threshold)[:, 0].tolist():
+        m = b == p
+        Ts.append(weighted_procrustes(sp[m], rp[m], sc[m]))
+    if Ts:
+        Ts = torch.stack(Ts)
+        res = torch.linalg.norm(rp[None] - _apply(Ts, sp[None]), dim=2)
+        inl = res < acceptance_radius
+        cur = sc * inl[inl.sum(1).argmax()].float()
+    else:
+        T = weighted_procrustes(sp, rp, sc)
+        cur = sc * (torch.linalg.norm(rp - _apply(T, sp), dim=1) < acceptance_radius).float()
+    T = weighted_procrustes(sp, rp, cur)
+    for _ in range(steps - 1):
+        cur = sc * (torch.linalg.norm(rp - _apply(T, sp), dim=1) < acceptance_radius).float()
+        T = weighted_procrustes(sp, rp, cur)
+    return rp, sp, sc, T
+
+
+def pose_tail(sd, data_dict, feats_list, enhanced_feats_c, limits, num_points_in_patch=128, iters=100):
+    """LCRNet.forward after the transformer (LCRNet.py:152-272): vote encoder -> partitions -> node Sinkhorn + matching ->
+    decoder -> patch Sinkhorn -> local-to-global registration."""
+    vd = vote_encoder(sd, enhanced_feats_c, data_dict, limits)
+    L0 = data_dict["lengths"][0]
+    nf0, nf1 = int(L0[0]), int(L0[1])
+    pts_f = data_dict["points"][0]
+    pos_f, anc_f = pts_f[:nf0], pts_f[nf0:nf0 + nf1]
+    m0 = int(vd["length"][0])
+    pos_c, anc_c = vd["centers"][:m0], vd["centers"][m0:]
+    pos_fc, anc_fc = vd["feats_c"][:m0], vd["feats_c"][m0:]
+    _, pos_nm, pos_knn, pos_km = point_to_node_partition(pos_f, pos_c, num_points_in_patch)
+    _, anc_nm, anc_knn, anc_km = point_to_node_partition(anc_f, anc_c, num_points_in_patch)
+    ns = (pos_fc @ anc_fc.t() / pos_fc.shape[1] ** 0.5)[None]
+    ns = log_optimal_transport(ns, pos_nm[None], anc_nm[None], sd["node_optimal_transport.alpha"], iters)[0]
+    pi, ai, node_scores = superpoint_matching_ot(ns)
+    fl = list(feats_list)
+    fl[-1] = enhanced_feats_c
+    feats_f = kp_decoder(sd, fl, data_dict)
+    pos_ff, anc_ff = feats_f[:nf0], feats_f[nf0:]
+    pad = lambda x: torch.cat([x, torch.zeros_like(x[:1])], 0)
+    pk, ak = pos_knn[pi], anc_knn[ai]
+    pkp, akp = pad(pos_f)[pk], pad(anc_f)[ak]
+    pkf, akf = pad(pos_ff)[pk], pad(anc_ff)[ak]
+    ms = torch.einsum("bnd,bmd->bnm", pkf, akf) / feats_f.shape[1] ** 0.5
+    ms = log_optimal_transport(ms, pos_km[pi], anc_km[ai], sd["optimal_transport.alpha"], iters)
+    rp, sp, sc, T = local_global_registration(pkp, akp, pos_km[pi], anc_km[ai], ms)
+    return {"vote": vd, "pos_node_knn_indices": pos_knn, "anc_node_knn_indices": anc_knn, "pos_node_corr_indices": pi,
+            "anc_node_corr_indices": ai, "node_scores": ns, "feats_f": feats_f, "matching_scores": ms,
+            "pos_corr_points": rp, "anc_corr_points": sp, "corr_scores": sc, "estimated_transform": T}
