@@ -164,6 +164,55 @@ int lcr_retrieval_topk(const float* queries /*[Q,D]*/, int64_t Q, int64_t q0, co
                        int D, int k, int exclude, int32_t* out_idx /*[Q,k]*/, float* out_d2 /*[Q,k]*/,
                        void* ws, size_t ws_bytes, void* stream);
 
+/* Uniform batched GEMM: C_z = op(A_z)·op(B_z), constant strides in floats (multiples of 4), count <= 65535
+ * (einsum('bnd,bmd->bnm') of LCRNet.py:237). */
+int lcr_gemm_f32_strided_batched(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB,
+                                 int64_t strideA, int64_t strideB, int64_t strideC, int count, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a-10  registration tail (all device-side; replaces op chains with .cpu() hops and Python loops)
+ * ------------------------------------------------------------------------------------------------ */
+/* out = xyz + off * min(1, max_range/|off|)  (modules/vote/vote.py:166-175) */
+int lcr_vote_shift(const float* xyz, const float* offsets, int64_t N, float max_range, float* out, void* stream);
+/* Greedy NMS of modules/vote/vote.py:13-70, exact (order-dependent rule replayed in parallel rounds), one cloud per
+ * workgroup.  keep u8[n_total], out_len i64[B]; ws: n_total bytes. */
+int lcr_greedy_nms(const float* pts, const int64_t* len, int B, int64_t n_total, float radius, uint8_t* keep,
+                   int64_t* out_len, void* ws, void* stream);
+/* out[m] = mean of pts[idx[m,h]] over the valid (0 <= idx < pad) neighbours (backbone4.py:161-175). */
+int lcr_neighbor_mean(const float* pts, const void* idx, int idx_is_64, int64_t M, int H, int64_t pad, float* out, void* stream);
+/* point_to_node_partition (modules/ops/pointcloud_partition.py:60-107): knn i64[M,K] padded with N, knn_mask u8[M,K],
+ * node_mask u8[M], optional p2n i32[N]; M <= 4000. */
+int lcr_point_to_node_ws_bytes(int64_t N, int M, size_t* bytes);
+int lcr_point_to_node_partition(const float* points, int64_t N, const float* nodes, int M, int K, int32_t* p2n, int64_t* knn,
+                                uint8_t* knn_mask, uint8_t* node_mask, uint32_t* status, void* ws, size_t ws_bytes, void* stream);
+/* S[B,M+1,N+1] = scale*raw with dustbin row/col = alpha[0] and masked rows/cols = -inf_val (learnable_sinkhorn.py:36-45). */
+int lcr_build_padded_scores(const float* raw, const uint8_t* row_mask, const uint8_t* col_mask, int64_t B, int M, int N,
+                            float scale, const float* alpha, float inf_val, float* S, void* stream);
+/* LearnableLogOptimalTransport.forward (learnable_sinkhorn.py:13-66) in place on S; uv_ws: B*2*(M+N+2) floats. */
+int lcr_log_sinkhorn(float* S, const uint8_t* row_mask, const uint8_t* col_mask, int64_t B, int M, int N, int iters,
+                     float inf_val, float* uv_ws, void* stream);
+/* Dustbin top-1 matching in the exp domain (superpoint_matching.py:130-162; local_global_registration.py:49-92 with k=1,
+ * mutual=False, use_dustbin=True): (b,i,j) kept if it is its row's maximum beating the dustbin column OR its column's
+ * maximum beating the dustbin row (and row/col masks, if given).  Phase 1: out_bij == NULL -> *total (device i64);
+ * phase 2: same arguments with out_bij i32[total,3], out_score f32[total].  Row-major order. */
+int lcr_top1_matching_ws_bytes(int64_t B, int M, int N, size_t* bytes);
+int lcr_top1_matching(const float* logS, int64_t B, int M, int N, const uint8_t* row_mask, const uint8_t* col_mask,
+                      int64_t* total, int32_t* out_bij, float* out_score, void* ws, size_t ws_bytes, void* stream);
+/* out[n] = [ x[idx[n,0]] (zeros for the shadow index), skip[n] ]  (nearest_upsample + cat, backbone4.py:355-367) */
+int lcr_upsample_concat(const float* x, int64_t Nx, int C1, const void* idx, int idx_is_64, int H, const float* skip, int C2,
+                        int64_t N, float* out, void* stream);
+/* out[r] = src[idx[r]] (zeros where idx == pad): index_select on a zero-padded tensor */
+int lcr_gather_rows(const float* src, int64_t pad, int C, const int64_t* idx, int64_t R, float* out, void* stream);
+/* weighted_procrustes (modules/registration/procrustes.py:6-73), batched: problem p = correspondences [start[p],start[p+1]);
+ * 3x3 SVD on the device (one-sided Jacobi, fp64); T f32[P,4,4]. */
+int lcr_procrustes_batched(const float* src, const float* ref, const float* w, const int32_t* start, int P, float eps, float* T, void* stream);
+/* counts[p] = #{ |ref - T_p src| < radius } (-1 if the hypothesis came from < min_count correspondences); best = first argmax */
+int lcr_inlier_count(const float* T, int P, const float* src, const float* ref, int n, float radius, const int32_t* start,
+                     int min_count, int32_t* counts, int32_t* best, void* stream);
+/* w_out = score * [ |ref - T src| < radius ], T = T_all[sel ? *sel : 0]  (recompute_correspondence_scores, LGR :127-132) */
+int lcr_inlier_weights(const float* T_all, const int32_t* sel, const float* src, const float* ref, const float* score, int n,
+                       float radius, float* w_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

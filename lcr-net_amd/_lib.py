@@ -43,6 +43,21 @@ _SIGS = {
     "lcr_relu_inplace": (c_int, [c_vp, c_i64, c_vp]),
     "lcr_retrieval_ws_bytes": (c_int, [c_i64, c_i64, c_size_p]),
     "lcr_retrieval_topk": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "lcr_gemm_f32_strided_batched": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_int, c_vp]),
+    "lcr_vote_shift": (c_int, [c_vp, c_vp, c_i64, c_float, c_vp, c_vp]),
+    "lcr_greedy_nms": (c_int, [c_vp, c_vp, c_int, c_i64, c_float, c_vp, c_vp, c_vp, c_vp]),
+    "lcr_neighbor_mean": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_i64, c_vp, c_vp]),
+    "lcr_point_to_node_ws_bytes": (c_int, [c_i64, c_int, c_size_p]),
+    "lcr_point_to_node_partition": (c_int, [c_vp, c_i64, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "lcr_build_padded_scores": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_float, c_vp, c_float, c_vp, c_vp]),
+    "lcr_log_sinkhorn": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_float, c_vp, c_vp]),
+    "lcr_top1_matching_ws_bytes": (c_int, [c_i64, c_int, c_int, c_size_p]),
+    "lcr_top1_matching": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "lcr_upsample_concat": (c_int, [c_vp, c_i64, c_int, c_vp, c_int, c_int, c_vp, c_int, c_i64, c_vp, c_vp]),
+    "lcr_gather_rows": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_vp]),
+    "lcr_procrustes_batched": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_float, c_vp, c_vp]),
+    "lcr_inlier_count": (c_int, [c_vp, c_int, c_vp, c_vp, c_int, c_float, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "lcr_inlier_weights": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_float, c_vp, c_vp]),
     "lcr_netvlad_ws_bytes": (c_int, [c_i64, c_int, c_size_p]),
     "lcr_netvlad_forward": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
 }

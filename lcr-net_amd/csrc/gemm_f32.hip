@@ -25,6 +25,7 @@ constexpr int GM_T = 256;
 constexpr int GM_MAX_BATCH = 64;
 struct GemmBatch {
   int     count;                 // 0 = plain GEMM
+  int     strided;               // 1: entry z uses offsets z * {a,b,c}_off[0] and K = k[0] (uniform batch)
   int     k[GM_MAX_BATCH];
   int64_t a_off[GM_MAX_BATCH], b_off[GM_MAX_BATCH], c_off[GM_MAX_BATCH];
 };
@@ -136,10 +137,17 @@ __global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ 
   static_assert(WM * WN == 4 && BM == 32 * WM, "one 32-row MFMA tile per wavefront along M");
   if (batch.count) {
     const int z = blockIdx.z;
-    A += batch.a_off[z];
-    B += batch.b_off[z];
-    C += batch.c_off[z];
-    K = batch.k[z];
+    if (batch.strided) {
+      A += static_cast<int64_t>(z) * batch.a_off[0];
+      B += static_cast<int64_t>(z) * batch.b_off[0];
+      C += static_cast<int64_t>(z) * batch.c_off[0];
+      K = batch.k[0];
+    } else {
+      A += batch.a_off[z];
+      B += batch.b_off[z];
+      C += batch.c_off[z];
+      K = batch.k[z];
+    }
   }
   constexpr int LDA = TA ? BM + 4 : BM + 1;
   constexpr int LDB = TB ? BN + 1 : BN + 4;
@@ -405,4 +413,28 @@ extern "C" int lcr_gemm_f32_batched_ta(const float* A, const float* B, float* C,
   }
   GemmEpilogue ep{nullptr, nullptr, nullptr, 0, 0, nullptr};
   return launch_gemm<64, 64, 2, 2, true>(A, B, C, M, N, /*K (per entry)*/ 1, 1, 0, ep, static_cast<hipStream_t>(stream), &bt);
+}
+
+// Uniform batch: C_z[M,N] = op(A_z)·op(B_z), z < count (<= 65535), constant strides (in floats, multiples of 4) — the per-patch
+// feature products of the dense matching stage (LCRNet.py:237-238: einsum('bnd,bmd->bnm')).
+extern "C" int lcr_gemm_f32_strided_batched(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB,
+                                            int64_t strideA, int64_t strideB, int64_t strideC, int count, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || count < 1 || count > 65535 || (strideA % 4) || (strideB % 4)) {
+    set_error("lcr_gemm_f32_strided_batched: bad argument");
+    return LCR_EARG;
+  }
+  const int64_t lda = transA ? M : K, ldb = transB ? K : N;
+  if ((lda % 4) || (ldb % 4)) {
+    set_error("lcr_gemm_f32_strided_batched: leading dimensions must be multiples of 4");
+    return LCR_EARG;
+  }
+  GemmBatch bt = {};
+  bt.count = count;
+  bt.strided = 1;
+  bt.k[0] = K;
+  bt.a_off[0] = strideA;
+  bt.b_off[0] = strideB;
+  bt.c_off[0] = strideC;
+  GemmEpilogue ep{nullptr, nullptr, nullptr, 0, 0, nullptr};
+  return launch_gemm<64, 64, 2, 2, true>(A, B, C, M, N, K, transA, transB, ep, static_cast<hipStream_t>(stream), &bt);
 }

@@ -1,0 +1,764 @@
+// pose_tail.hip — a-10: device kernels of the registration tail (no host round trips between them).
+//
+// Reference (all PyTorch op chains, several with .cpu() hops and Python loops):
+//   vote offsets + clamp          modules/vote/vote.py:146-182
+//   greedy NMS                    modules/vote/vote.py:13-70   (Python loop over ~840 nodes, order dependent)
+//   node centres                  backbone4.py:161-175         (mean of the in-radius voted points)
+//   point-to-node partition       modules/ops/pointcloud_partition.py:60-107 (dense M x N distances + top-k 128)
+//   log-domain Sinkhorn           modules/sinkhorn/learnable_sinkhorn.py:5-66 (100 iterations)
+//   dustbin top-1 matching        geotransformer/superpoint_matching.py:130-162, local_global_registration.py:49-92
+//   nearest upsample + concat     modules/kpconv/functional.py:6-22, backbone4.py:355-367
+//   weighted Procrustes           modules/registration/procrustes.py:6-73 (torch.svd on the CPU) + LGR :134-200
+//
+// Everything here is small, integer / latency bound work; kernels are sized one workgroup per problem instance
+// (cloud, score matrix, hypothesis) so that batches of pairs fill the chip.
+#include <algorithm>
+#include <cmath>
+
+#include "common.h"
+
+namespace lcr {
+
+// ---- vote: shifted = xyz + off * min(1, max_range / |off|) ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_vote_shift(const float* __restrict__ xyz, const float* __restrict__ off, int64_t N, float max_range,
+                                                    float* __restrict__ out) {
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < N; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const float ox = off[3 * i], oy = off[3 * i + 1], oz = off[3 * i + 2];
+    const float d = sqrtf(ox * ox + oy * oy + oz * oz);
+    const float a = d > max_range ? max_range / d : 1.f;
+    out[3 * i + 0] = xyz[3 * i + 0] + ox * a;
+    out[3 * i + 1] = xyz[3 * i + 1] + oy * a;
+    out[3 * i + 2] = xyz[3 * i + 2] + oz * a;
+  }
+}
+
+// ---- greedy NMS: exact parallel replay of the sequential rule ------------------------------------------------------------
+// keep[i] <=> no kept j < i with ||p_i - p_j + 1e-6|| <= radius (nn.PairwiseDistance semantics, vote.py:48-54).  Each round,
+// an undecided node is dropped if a kept lower node is in range, kept if no lower node in range is still undecided.  Every
+// round decides at least the lowest undecided node, so the loop terminates; real clouds need ~10 rounds.
+constexpr int NMS_T = 1024;
+__global__ __launch_bounds__(NMS_T) void k_greedy_nms(const float* __restrict__ pts, const int64_t* __restrict__ len, int B, float radius,
+                                                      uint8_t* __restrict__ keep, int64_t* __restrict__ out_len, int8_t* __restrict__ state_ws) {
+  __shared__ int s_changed, s_undecided, s_cnt;
+  const int b = blockIdx.x;
+  int64_t o = 0;
+  for (int i = 0; i < b; ++i) o += len[i];
+  const int n = static_cast<int>(len[b]);
+  const float* p = pts + 3 * o;
+  int8_t* st = state_ws + o;   // 0 undecided, 1 kept, 2 dropped
+  for (int i = threadIdx.x; i < n; i += NMS_T) st[i] = i == 0 ? 1 : 0;
+  __syncthreads();
+  while (true) {
+    if (threadIdx.x == 0) {
+      s_changed = 0;
+      s_undecided = 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += NMS_T) {
+      if (st[i] != 0) continue;
+      const float x = p[3 * i], y = p[3 * i + 1], z = p[3 * i + 2];
+      bool blocked = false, dropped = false;
+      for (int j = 0; j < i; ++j) {
+        const int8_t sj = st[j];          // may be one round stale: only delays a decision, never changes it
+        if (sj == 2) continue;
+        const float dx = x - p[3 * j] + 1e-6f, dy = y - p[3 * j + 1] + 1e-6f, dz = z - p[3 * j + 2] + 1e-6f;
+        const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+        if (!(d > radius)) {
+          if (sj == 1) {
+            dropped = true;
+            break;
+          }
+          blocked = true;
+        }
+      }
+      if (dropped) {
+        st[i] = 2;
+        s_changed = 1;
+      } else if (!blocked) {
+        st[i] = 1;
+        s_changed = 1;
+      } else {
+        s_undecided = 1;
+      }
+    }
+    __syncthreads();
+    const bool done = !s_undecided;
+    __syncthreads();
+    if (done) break;
+  }
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  int c = 0;
+  for (int i = threadIdx.x; i < n; i += NMS_T) {
+    const bool k = st[i] == 1;
+    keep[o + i] = k ? 1 : 0;
+    c += k;
+  }
+  atomicAdd(&s_cnt, c);
+  __syncthreads();
+  if (threadIdx.x == 0) out_len[b] = s_cnt;
+}
+
+// ---- mean of the valid neighbours of every row (sequential in row order like the reference's sum) -------------------------
+template <typename IdxT>
+__global__ __launch_bounds__(256) void k_neighbor_mean(const float* __restrict__ pts, const IdxT* __restrict__ idx, int64_t M, int H, int64_t pad,
+                                                       float* __restrict__ out) {
+  for (int64_t m = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; m < M; m += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    int c = 0;
+    for (int h = 0; h < H; ++h) {
+      const int64_t j = static_cast<int64_t>(idx[m * H + h]);
+      if (j >= 0 && j < pad) {
+        sx += pts[3 * j];
+        sy += pts[3 * j + 1];
+        sz += pts[3 * j + 2];
+        ++c;
+      }
+    }
+    const float d = static_cast<float>(c);
+    out[3 * m] = sx / d;
+    out[3 * m + 1] = sy / d;
+    out[3 * m + 2] = sz / d;
+  }
+}
+
+// ---- point-to-node partition ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float p2n_dist(float nx, float ny, float nz, float n2, float px, float py, float pz, float p2) {
+  // pairwise_distance (modules/ops/pairwise_distance.py:18-31): x2 - 2*xy + y2, clamped at 1e-12
+  const float xy = nx * px + ny * py + nz * pz;
+  return fmaxf((n2 - 2.f * xy) + p2, 1e-12f);
+}
+
+// nearest node of every point (ties: lowest node index); per-node point counts
+__global__ __launch_bounds__(256) void k_point_to_node(const float* __restrict__ points, int64_t N, const float* __restrict__ nodes, int M,
+                                                       int32_t* __restrict__ p2n, int32_t* __restrict__ node_cnt) {
+  extern __shared__ float s_nodes[];   // [M][4] (x,y,z,|n|^2)
+  for (int i = threadIdx.x; i < M; i += blockDim.x) {
+    const float x = nodes[3 * i], y = nodes[3 * i + 1], z = nodes[3 * i + 2];
+    s_nodes[4 * i] = x;
+    s_nodes[4 * i + 1] = y;
+    s_nodes[4 * i + 2] = z;
+    s_nodes[4 * i + 3] = x * x + y * y + z * z;
+  }
+  __syncthreads();
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < N; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const float px = points[3 * i], py = points[3 * i + 1], pz = points[3 * i + 2];
+    const float p2 = px * px + py * py + pz * pz;
+    float best = INFINITY;
+    int bi = 0;
+    for (int m = 0; m < M; ++m) {
+      const float d = p2n_dist(s_nodes[4 * m], s_nodes[4 * m + 1], s_nodes[4 * m + 2], s_nodes[4 * m + 3], px, py, pz, p2);
+      if (d < best) {
+        best = d;
+        bi = m;
+      }
+    }
+    p2n[i] = bi;
+    atomicAdd(&node_cnt[bi], 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_p2n_scatter(const int32_t* __restrict__ p2n, int64_t N, const int32_t* __restrict__ node_start,
+                                                     int32_t* __restrict__ cursor, int32_t* __restrict__ members) {
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < N; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int m = p2n[i];
+    members[node_start[m] + atomicAdd(&cursor[m], 1)] = static_cast<int32_t>(i);
+  }
+}
+
+// per node: its K nearest own points, ascending (d2, index); padded with N.  One workgroup per node.
+constexpr int PT_CAP = 4096;   // own points held in LDS per node
+__global__ __launch_bounds__(256) void k_node_topk(const float* __restrict__ points, int64_t N, const float* __restrict__ nodes,
+                                                   const int32_t* __restrict__ node_start, const int32_t* __restrict__ members, int K,
+                                                   int64_t* __restrict__ knn, uint8_t* __restrict__ knn_mask, uint8_t* __restrict__ node_mask,
+                                                   uint32_t* __restrict__ status) {
+  __shared__ uint64_t s_key[PT_CAP];
+  const int m = blockIdx.x;
+  const int a = node_start[m], n_all = node_start[m + 1] - a;
+  const int n = n_all < PT_CAP ? n_all : PT_CAP;
+  if (n_all > PT_CAP && threadIdx.x == 0) atomicOr(status, LCR_STATUS_LEN_MISMATCH);
+  const float nx = nodes[3 * m], ny = nodes[3 * m + 1], nz = nodes[3 * m + 2];
+  const float n2 = nx * nx + ny * ny + nz * nz;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int32_t pi = members[a + i];
+    const float px = points[3 * pi], py = points[3 * pi + 1], pz = points[3 * pi + 2];
+    const float d = p2n_dist(nx, ny, nz, n2, px, py, pz, px * px + py * py + pz * pz);
+    s_key[i] = (static_cast<uint64_t>(__float_as_uint(d)) << 32) | static_cast<uint32_t>(pi);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    const uint64_t key = s_key[e];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += s_key[j] < key;
+    if (rank < K) {
+      knn[static_cast<int64_t>(m) * K + rank] = static_cast<int64_t>(static_cast<uint32_t>(key));
+      knn_mask[static_cast<int64_t>(m) * K + rank] = 1;
+    }
+  }
+  for (int c = n + threadIdx.x; c < K; c += blockDim.x) {
+    knn[static_cast<int64_t>(m) * K + c] = N;
+    knn_mask[static_cast<int64_t>(m) * K + c] = 0;
+  }
+  if (threadIdx.x == 0) node_mask[m] = n_all > 0 ? 1 : 0;
+}
+
+// ---- log-domain Sinkhorn with dustbins ---------------------------------------------------------------------------------------
+// S: [B, M+1, N+1] padded score matrices (dustbin row/column = alpha, masked entries = -inf_val), overwritten by the result
+// S + u + v - norm.  One workgroup per matrix; u, v live in global scratch (L2 resident).
+constexpr int SK_T = 512;
+__device__ __forceinline__ void online_lse(float x, float& m, float& s) {
+  if (x > m) {
+    s = s * expf(m - x) + 1.f;
+    m = x;
+  } else {
+    s += expf(x - m);
+  }
+}
+
+__global__ __launch_bounds__(SK_T) void k_log_sinkhorn(float* __restrict__ S, const uint8_t* __restrict__ row_mask, const uint8_t* __restrict__ col_mask,
+                                                       int M, int N, int iters, float inf_val, float* __restrict__ uv_ws) {
+  const int b = blockIdx.x;
+  const int M1 = M + 1, N1 = N + 1;
+  float* s = S + static_cast<int64_t>(b) * M1 * N1;
+  float* u = uv_ws + static_cast<int64_t>(b) * (M1 + N1) * 2;
+  float* v = u + M1;
+  float* log_mu = v + N1;
+  float* log_nu = log_mu + M1;
+  __shared__ float s_norm;
+  __shared__ int s_nr, s_nc;
+  if (threadIdx.x == 0) {
+    s_nr = 0;
+    s_nc = 0;
+  }
+  __syncthreads();
+  int cr = 0, cc = 0;
+  for (int i = threadIdx.x; i < M; i += SK_T) cr += row_mask[static_cast<int64_t>(b) * M + i] ? 1 : 0;
+  for (int j = threadIdx.x; j < N; j += SK_T) cc += col_mask[static_cast<int64_t>(b) * N + j] ? 1 : 0;
+  atomicAdd(&s_nr, cr);
+  atomicAdd(&s_nc, cc);
+  __syncthreads();
+  const float nr = static_cast<float>(s_nr), nc = static_cast<float>(s_nc);
+  const float norm = -logf(nr + nc);
+  if (threadIdx.x == 0) s_norm = norm;
+  for (int i = threadIdx.x; i < M1; i += SK_T) {
+    const bool masked = i < M && !row_mask[static_cast<int64_t>(b) * M + i];
+    log_mu[i] = masked ? -inf_val : (i < M ? norm : logf(nc) + norm);
+    u[i] = 0.f;
+  }
+  for (int j = threadIdx.x; j < N1; j += SK_T) {
+    const bool masked = j < N && !col_mask[static_cast<int64_t>(b) * N + j];
+    log_nu[j] = masked ? -inf_val : (j < N ? norm : logf(nr) + norm);
+    v[j] = 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int NW = SK_T / 64;
+  for (int it = 0; it < iters; ++it) {
+    // u = log_mu - logsumexp_j(S + v): one wavefront per row, lanes over columns
+    for (int i = w; i < M1; i += NW) {
+      float m = -INFINITY, sum = 0.f;
+      for (int j = lane; j < N1; j += 64) online_lse(s[i * N1 + j] + v[j], m, sum);
+      // combine the 64 partial (m, sum) pairs
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        const float m2 = __shfl_xor(m, d), s2 = __shfl_xor(sum, d);
+        const float mm = fmaxf(m, m2);
+        sum = (m == -INFINITY ? 0.f : sum * expf(m - mm)) + (m2 == -INFINITY ? 0.f : s2 * expf(m2 - mm));
+        m = mm;
+      }
+      if (lane == 0) u[i] = log_mu[i] - (m + logf(sum));
+    }
+    __syncthreads();
+    // v = log_nu - logsumexp_i(S + u): one thread per column, rows coalesced across the threads
+    for (int j = threadIdx.x; j < N1; j += SK_T) {
+      float m = -INFINITY, sum = 0.f;
+      for (int i = 0; i < M1; ++i) online_lse(s[i * N1 + j] + u[i], m, sum);
+      v[j] = log_nu[j] - (m + logf(sum));
+    }
+    __syncthreads();
+  }
+  for (int t = threadIdx.x; t < M1 * N1; t += SK_T) {
+    const int i = t / N1, j = t - i * N1;
+    s[t] = s[t] + u[i] + v[j] - s_norm;
+  }
+}
+
+// padded score matrix from raw products: S[b][i][j] = scale * raw[b][i][j]; dustbin row/col = alpha; masked -> -inf_val
+__global__ __launch_bounds__(256) void k_build_padded_scores(const float* __restrict__ raw, const uint8_t* __restrict__ row_mask,
+                                                             const uint8_t* __restrict__ col_mask, int64_t B, int M, int N, float scale,
+                                                             const float* __restrict__ alpha, float inf_val, float* __restrict__ S) {
+  const int M1 = M + 1, N1 = N + 1;
+  const int64_t total = B * M1 * N1;
+  const float a = alpha[0];
+  for (int64_t t = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; t < total; t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t b = t / (static_cast<int64_t>(M1) * N1);
+    const int r = static_cast<int>(t - b * M1 * N1);
+    const int i = r / N1, j = r - i * N1;
+    float val = (i < M && j < N) ? raw[(b * M + i) * N + j] * scale : a;
+    const bool masked = (i < M && !row_mask[b * M + i]) || (j < N && !col_mask[b * N + j]);
+    S[t] = masked ? -inf_val : val;
+  }
+}
+
+// ---- dustbin top-1 matching (exp domain): row / column maxima vs the dustbins -------------------------------------------------
+// rowarg[b][i] = argmax_j P[i][:], rowbeat = P[i][rowarg] > P[i][N];  colarg[b][j] = argmax_i P[:][j], colbeat = P[colarg][j] > P[M][j].
+__global__ __launch_bounds__(256) void k_top1_stats(const float* __restrict__ logS, int M, int N, int32_t* __restrict__ rowarg,
+                                                    uint8_t* __restrict__ rowbeat, int32_t* __restrict__ colarg, uint8_t* __restrict__ colbeat) {
+  const int b = blockIdx.x;
+  const int M1 = M + 1, N1 = N + 1;
+  const float* s = logS + static_cast<int64_t>(b) * M1 * N1;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int i = w; i < M1; i += 4) {
+    float best = -INFINITY;
+    int bj = 0;
+    for (int j = lane; j < N1; j += 64) {
+      const float p = expf(s[i * N1 + j]);
+      if (p > best) {
+        best = p;
+        bj = j;
+      }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const float ob = __shfl_xor(best, d);
+      const int oj = __shfl_xor(bj, d);
+      if (ob > best || (ob == best && oj < bj)) {
+        best = ob;
+        bj = oj;
+      }
+    }
+    if (lane == 0) {
+      rowarg[static_cast<int64_t>(b) * M1 + i] = bj;
+      rowbeat[static_cast<int64_t>(b) * M1 + i] = best > expf(s[i * N1 + N]) ? 1 : 0;
+    }
+  }
+  for (int j = threadIdx.x; j < N1; j += 256) {
+    float best = -INFINITY;
+    int bi = 0;
+    for (int i = 0; i < M1; ++i) {
+      const float p = expf(s[i * N1 + j]);
+      if (p > best) {
+        best = p;
+        bi = i;
+      }
+    }
+    colarg[static_cast<int64_t>(b) * N1 + j] = bi;
+    colbeat[static_cast<int64_t>(b) * N1 + j] = best > expf(s[M * N1 + j]) ? 1 : 0;
+  }
+}
+
+// count / emit the (i, j) pairs of every row in row-major order: (rowarg hit) OR (column hits with colarg == i), i < M, j < N,
+// optionally gated by validity masks.  PHASE 0 = count per (b, i); PHASE 1 = write at the scanned offsets.
+template <int PHASE>
+__global__ __launch_bounds__(256) void k_top1_emit(const float* __restrict__ logS, int64_t B, int M, int N, const int32_t* __restrict__ rowarg,
+                                                   const uint8_t* __restrict__ rowbeat, const int32_t* __restrict__ colarg,
+                                                   const uint8_t* __restrict__ colbeat, const uint8_t* __restrict__ row_mask,
+                                                   const uint8_t* __restrict__ col_mask, int32_t* __restrict__ counts,
+                                                   const int32_t* __restrict__ offsets, int32_t* __restrict__ out_bij, float* __restrict__ out_score) {
+  const int M1 = M + 1, N1 = N + 1;
+  const int64_t rows = B * M;
+  for (int64_t t = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; t < rows; t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t b = t / M;
+    const int i = static_cast<int>(t - b * M);
+    int c = 0;
+    const bool rvalid = !row_mask || row_mask[b * M + i];
+    if (rvalid) {
+      const int ra = rowarg[b * M1 + i];
+      const bool rb = rowbeat[b * M1 + i] != 0;
+      const int64_t o = PHASE ? offsets[t] : 0;
+      for (int j = 0; j < N; ++j) {
+        if (col_mask && !col_mask[b * N + j]) continue;
+        const bool hit = (rb && ra == j) || (colbeat[b * N1 + j] && colarg[b * N1 + j] == i);
+        if (hit) {
+          if (PHASE) {
+            out_bij[3 * (o + c) + 0] = static_cast<int32_t>(b);
+            out_bij[3 * (o + c) + 1] = i;
+            out_bij[3 * (o + c) + 2] = j;
+            out_score[o + c] = expf(logS[(b * M1 + i) * N1 + j]);
+          }
+          ++c;
+        }
+      }
+    }
+    if (!PHASE) counts[t] = c;
+  }
+}
+
+// ---- decoder: out[n] = [ x[idx[n][0]] (zeros for the shadow index) , skip[n] ] -------------------------------------------------
+template <typename IdxT>
+__global__ __launch_bounds__(256) void k_upsample_concat(const float* __restrict__ x, int64_t Nx, int C1, const IdxT* __restrict__ idx, int H,
+                                                         const float* __restrict__ skip, int C2, int64_t N, float* __restrict__ out) {
+  const int C = C1 + C2;
+  const int64_t total = N * C;
+  for (int64_t t = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; t < total; t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t n = t / C;
+    const int c = static_cast<int>(t - n * C);
+    float v;
+    if (c < C1) {
+      const int64_t j = static_cast<int64_t>(idx[n * H]);
+      v = (j >= 0 && j < Nx) ? x[j * C1 + c] : 0.f;
+    } else {
+      v = skip[n * C2 + (c - C1)];
+    }
+    out[t] = v;
+  }
+}
+
+// out[r][:] = src[idx[r]][:] with zeros for idx == pad (index_select on a zero-padded tensor)
+__global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ src, int64_t pad, int C, const int64_t* __restrict__ idx, int64_t R,
+                                                     float* __restrict__ out) {
+  const int64_t total = R * C;
+  for (int64_t t = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; t < total; t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t r = t / C;
+    const int c = static_cast<int>(t - r * C);
+    const int64_t j = idx[r];
+    out[t] = (j >= 0 && j < pad) ? src[j * C + c] : 0.f;
+  }
+}
+
+// ---- weighted Procrustes (batched) --------------------------------------------------------------------------------------------
+// 3x3 SVD by one-sided Jacobi (Hestenes) in fp64: A V = U S.  Returns R = V diag(1,1,sign det(V U^T)) U^T.
+__device__ void rotation_from_H(const double H[3][3], double R[3][3]) {
+  double A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) A[i][j] = H[i][j];
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int k = 0; k < 3; ++k) {
+          alpha += A[k][p] * A[k][p];
+          beta += A[k][q] * A[k][q];
+          gamma += A[k][p] * A[k][q];
+        }
+        off = fmax(off, fabs(gamma) / (sqrt(alpha * beta) + 1e-300));
+        if (fabs(gamma) < 1e-300) continue;
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        for (int k = 0; k < 3; ++k) {
+          const double ap = A[k][p], aq = A[k][q];
+          A[k][p] = c * ap - s * aq;
+          A[k][q] = s * ap + c * aq;
+          const double vp = V[k][p], vq = V[k][q];
+          V[k][p] = c * vp - s * vq;
+          V[k][q] = s * vp + c * vq;
+        }
+      }
+    if (off < 1e-15) break;
+  }
+  // singular values = column norms of A; U = A / sigma.  Order columns by decreasing sigma (like LAPACK) so that the
+  // reflection fix hits the smallest singular direction.
+  double sig[3];
+  int ord[3] = {0, 1, 2};
+  for (int j = 0; j < 3; ++j) sig[j] = sqrt(A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j]);
+  for (int a = 0; a < 2; ++a)
+    for (int b2 = a + 1; b2 < 3; ++b2)
+      if (sig[ord[b2]] > sig[ord[a]]) {
+        const int tmp = ord[a];
+        ord[a] = ord[b2];
+        ord[b2] = tmp;
+      }
+  double U[3][3], Vs[3][3];
+  for (int j = 0; j < 3; ++j) {
+    const int c = ord[j];
+    for (int k = 0; k < 3; ++k) {
+      Vs[k][j] = V[k][c];
+      U[k][j] = sig[c] > 1e-300 ? A[k][c] / sig[c] : 0.0;
+    }
+  }
+  // complete U if rank deficient: third column = u0 x u1 (and second from any orthogonal vector if needed)
+  if (sig[ord[1]] <= 1e-12 * sig[ord[0]] || sig[ord[1]] <= 1e-300) {
+    // pick an axis least aligned with u0
+    int ax = 0;
+    if (fabs(U[1][0]) < fabs(U[ax][0])) ax = 1;
+    if (fabs(U[2][0]) < fabs(U[ax][0])) ax = 2;
+    double e[3] = {0, 0, 0};
+    e[ax] = 1.0;
+    const double d = e[0] * U[0][0] + e[1] * U[1][0] + e[2] * U[2][0];
+    double nrm = 0;
+    for (int k = 0; k < 3; ++k) {
+      U[k][1] = e[k] - d * U[k][0];
+      nrm += U[k][1] * U[k][1];
+    }
+    nrm = sqrt(nrm);
+    for (int k = 0; k < 3; ++k) U[k][1] /= nrm;
+  }
+  if (sig[ord[2]] <= 1e-12 * sig[ord[0]] || sig[ord[2]] <= 1e-300) {
+    U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
+    U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
+    U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+  }
+  auto det3 = [](const double X[3][3]) {
+    return X[0][0] * (X[1][1] * X[2][2] - X[1][2] * X[2][1]) - X[0][1] * (X[1][0] * X[2][2] - X[1][2] * X[2][0]) +
+           X[0][2] * (X[1][0] * X[2][1] - X[1][1] * X[2][0]);
+  };
+  const double sgn = det3(Vs) * det3(U) >= 0 ? 1.0 : -1.0;   // det(V U^T) = det V * det U
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R[i][j] = Vs[i][0] * U[j][0] + Vs[i][1] * U[j][1] + sgn * Vs[i][2] * U[j][2];
+}
+
+// problem p uses correspondences [start[p], start[p+1]) of src/ref/w; one wavefront per problem; T out [P,4,4] row-major
+__global__ __launch_bounds__(64) void k_procrustes(const float* __restrict__ src, const float* __restrict__ ref, const float* __restrict__ w,
+                                                   const int32_t* __restrict__ start, float eps, float* __restrict__ T) {
+  const int p = blockIdx.x, lane = threadIdx.x;
+  const int a = start[p], b = start[p + 1];
+  double ws = 0;
+  for (int i = a + lane; i < b; i += 64) ws += fmaxf(w[i], 0.f);
+  ws = wave_sum(ws);
+  const double inv = 1.0 / (ws + static_cast<double>(eps));
+  double sc[3] = {0, 0, 0}, rc[3] = {0, 0, 0};
+  for (int i = a + lane; i < b; i += 64) {
+    const double wi = fmaxf(w[i], 0.f) * inv;
+    for (int d = 0; d < 3; ++d) {
+      sc[d] += wi * src[3 * i + d];
+      rc[d] += wi * ref[3 * i + d];
+    }
+  }
+  for (int d = 0; d < 3; ++d) {
+    sc[d] = wave_sum(sc[d]);
+    rc[d] = wave_sum(rc[d]);
+  }
+  double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (int i = a + lane; i < b; i += 64) {
+    const double wi = fmaxf(w[i], 0.f) * inv;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) H[r][c] += (src[3 * i + r] - sc[r]) * wi * (ref[3 * i + c] - rc[c]);
+  }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) H[r][c] = wave_sum(H[r][c]);
+  if (lane == 0) {
+    double R[3][3];
+    rotation_from_H(H, R);
+    float* t = T + 16 * p;
+    for (int r = 0; r < 3; ++r) {
+      double tr = rc[r];
+      for (int c = 0; c < 3; ++c) {
+        t[4 * r + c] = static_cast<float>(R[r][c]);
+        tr -= R[r][c] * sc[c];
+      }
+      t[4 * r + 3] = static_cast<float>(tr);
+    }
+    t[12] = t[13] = t[14] = 0.f;
+    t[15] = 1.f;
+  }
+}
+
+// inlier counts of every hypothesis over all correspondences; one workgroup per hypothesis
+__global__ __launch_bounds__(256) void k_inlier_count(const float* __restrict__ T, const float* __restrict__ src, const float* __restrict__ ref, int n,
+                                                      float radius, const int32_t* __restrict__ start, int min_count, int32_t* __restrict__ counts) {
+  __shared__ int s_c;
+  if (start && start[blockIdx.x + 1] - start[blockIdx.x] < min_count) {   // hypothesis from too few correspondences: never the best
+    if (threadIdx.x == 0) counts[blockIdx.x] = -1;
+    return;
+  }
+  const float* t = T + 16 * blockIdx.x;
+  if (threadIdx.x == 0) s_c = 0;
+  __syncthreads();
+  int c = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float x = src[3 * i], y = src[3 * i + 1], z = src[3 * i + 2];
+    const float dx = ref[3 * i] - (t[0] * x + t[1] * y + t[2] * z + t[3]);
+    const float dy = ref[3 * i + 1] - (t[4] * x + t[5] * y + t[6] * z + t[7]);
+    const float dz = ref[3 * i + 2] - (t[8] * x + t[9] * y + t[10] * z + t[11]);
+    c += sqrtf(dx * dx + dy * dy + dz * dz) < radius ? 1 : 0;
+  }
+  atomicAdd(&s_c, c);
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = s_c;
+}
+
+// w_out = score * [ |ref - T src| < radius ] with T = T_all[sel ? *sel : 0]
+__global__ __launch_bounds__(256) void k_inlier_weights(const float* __restrict__ T_all, const int32_t* __restrict__ sel, const float* __restrict__ src,
+                                                        const float* __restrict__ ref, const float* __restrict__ score, int n, float radius,
+                                                        float* __restrict__ w_out) {
+  const float* t = T_all + 16 * (sel ? sel[0] : 0);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float x = src[3 * i], y = src[3 * i + 1], z = src[3 * i + 2];
+    const float dx = ref[3 * i] - (t[0] * x + t[1] * y + t[2] * z + t[3]);
+    const float dy = ref[3 * i + 1] - (t[4] * x + t[5] * y + t[6] * z + t[7]);
+    const float dz = ref[3 * i + 2] - (t[8] * x + t[9] * y + t[10] * z + t[11]);
+    w_out[i] = sqrtf(dx * dx + dy * dy + dz * dz) < radius ? score[i] : 0.f;
+  }
+}
+
+// first index of the maximum (torch.argmax on equal values returns the first)
+__global__ void k_argmax_i32(const int32_t* __restrict__ v, int n, int32_t* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int best = 0;
+    for (int i = 1; i < n; ++i)
+      if (v[i] > v[best]) best = i;
+    out[0] = best;
+  }
+}
+
+}  // namespace lcr
+
+using namespace lcr;
+#define ST(s) static_cast<hipStream_t>(s)
+static int blocks_for(int64_t n, int per = 256, int cap = 4096) { return static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((n + per - 1) / per, cap))); }
+
+extern "C" int lcr_vote_shift(const float* xyz, const float* offsets, int64_t N, float max_range, float* out, void* stream) {
+  if (!xyz || !offsets || !out || N < 0) return LCR_EARG;
+  if (N) hipLaunchKernelGGL(k_vote_shift, dim3(blocks_for(N)), dim3(256), 0, ST(stream), xyz, offsets, N, max_range, out);
+  return check_launch("lcr_vote_shift");
+}
+
+extern "C" int lcr_greedy_nms(const float* pts, const int64_t* len, int B, int64_t n_total, float radius, uint8_t* keep, int64_t* out_len,
+                              void* ws /* n_total bytes */, void* stream) {
+  if (!pts || !len || !keep || !out_len || !ws || B < 1) return LCR_EARG;
+  (void)n_total;
+  hipLaunchKernelGGL(k_greedy_nms, dim3(B), dim3(NMS_T), 0, ST(stream), pts, len, B, radius, keep, out_len, static_cast<int8_t*>(ws));
+  return check_launch("lcr_greedy_nms");
+}
+
+extern "C" int lcr_neighbor_mean(const float* pts, const void* idx, int idx_is_64, int64_t M, int H, int64_t pad, float* out, void* stream) {
+  if (!pts || !idx || !out || M < 0 || H < 1) return LCR_EARG;
+  if (M == 0) return LCR_OK;
+  if (idx_is_64) hipLaunchKernelGGL((k_neighbor_mean<int64_t>), dim3(blocks_for(M)), dim3(256), 0, ST(stream), pts, static_cast<const int64_t*>(idx), M, H, pad, out);
+  else hipLaunchKernelGGL((k_neighbor_mean<int32_t>), dim3(blocks_for(M)), dim3(256), 0, ST(stream), pts, static_cast<const int32_t*>(idx), M, H, pad, out);
+  return check_launch("lcr_neighbor_mean");
+}
+
+extern "C" int lcr_point_to_node_ws_bytes(int64_t N, int M, size_t* bytes) {
+  if (!bytes || N < 0 || M < 1) return LCR_EARG;
+  Carver c(nullptr, ~size_t(0));
+  c.take<int32_t>(N + 1);      // p2n
+  c.take<int32_t>(M + 2);      // counts
+  c.take<int32_t>(M + 2);      // starts
+  c.take<int32_t>(M + 2);      // cursor
+  c.take<int32_t>(N + 1);      // members
+  c.take<char>(scan_ws_bytes(M + 2));
+  *bytes = c.off;
+  return LCR_OK;
+}
+
+// point_to_node_partition (pointcloud_partition.py:60-107): knn i64[M,K] (pad = N), knn_mask u8[M,K], node_mask u8[M], p2n i32[N]
+extern "C" int lcr_point_to_node_partition(const float* points, int64_t N, const float* nodes, int M, int K, int32_t* p2n_out, int64_t* knn,
+                                           uint8_t* knn_mask, uint8_t* node_mask, uint32_t* status, void* ws, size_t ws_bytes, void* stream) {
+  if (!points || !nodes || !knn || !knn_mask || !node_mask || !status || !ws || N < 1 || M < 1 || K < 1 || M > 4000) {
+    set_error("lcr_point_to_node_partition: bad argument (1 <= M <= 4000)");
+    return LCR_EARG;
+  }
+  size_t need = 0;
+  lcr_point_to_node_ws_bytes(N, M, &need);
+  if (need > ws_bytes) return LCR_ESPACE;
+  Carver c(ws, ws_bytes);
+  int32_t* p2n = c.take<int32_t>(N + 1);
+  int32_t* cnt = c.take<int32_t>(M + 2);
+  int32_t* start = c.take<int32_t>(M + 2);
+  int32_t* cursor = c.take<int32_t>(M + 2);
+  int32_t* members = c.take<int32_t>(N + 1);
+  void* sws = c.take<char>(scan_ws_bytes(M + 2));
+  hipStream_t st = ST(stream);
+  hipMemsetAsync(cnt, 0, sizeof(int32_t) * (M + 2), st);
+  hipMemsetAsync(cursor, 0, sizeof(int32_t) * (M + 2), st);
+  hipLaunchKernelGGL(k_point_to_node, dim3(blocks_for(N, 256, 2048)), dim3(256), sizeof(float) * 4 * M, st, points, N, nodes, M, p2n, cnt);
+  int rc = exclusive_scan_i32(cnt, start, M + 1, nullptr, sws, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_p2n_scatter, dim3(blocks_for(N)), dim3(256), 0, st, p2n, N, start, cursor, members);
+  hipLaunchKernelGGL(k_node_topk, dim3(M), dim3(256), 0, st, points, N, nodes, start, members, K, knn, knn_mask, node_mask, status);
+  if (p2n_out) hipMemcpyAsync(p2n_out, p2n, sizeof(int32_t) * N, hipMemcpyDeviceToDevice, st);
+  return check_launch("lcr_point_to_node_partition");
+}
+
+extern "C" int lcr_build_padded_scores(const float* raw, const uint8_t* row_mask, const uint8_t* col_mask, int64_t B, int M, int N, float scale,
+                                       const float* alpha, float inf_val, float* S, void* stream) {
+  if (!raw || !row_mask || !col_mask || !alpha || !S || B < 1 || M < 1 || N < 1) return LCR_EARG;
+  hipLaunchKernelGGL(k_build_padded_scores, dim3(blocks_for(B * (M + 1) * (N + 1), 256, 8192)), dim3(256), 0, ST(stream), raw, row_mask, col_mask, B, M, N,
+                     scale, alpha, inf_val, S);
+  return check_launch("lcr_build_padded_scores");
+}
+
+// in place on S [B, M+1, N+1]; uv_ws: B * 2 * (M + N + 2) floats
+extern "C" int lcr_log_sinkhorn(float* S, const uint8_t* row_mask, const uint8_t* col_mask, int64_t B, int M, int N, int iters, float inf_val,
+                                float* uv_ws, void* stream) {
+  if (!S || !row_mask || !col_mask || !uv_ws || B < 1 || M < 1 || N < 1 || iters < 0) return LCR_EARG;
+  hipLaunchKernelGGL(k_log_sinkhorn, dim3(static_cast<int>(B)), dim3(SK_T), 0, ST(stream), S, row_mask, col_mask, M, N, iters, inf_val, uv_ws);
+  return check_launch("lcr_log_sinkhorn");
+}
+
+extern "C" int lcr_top1_matching_ws_bytes(int64_t B, int M, int N, size_t* bytes) {
+  if (!bytes || B < 1 || M < 1 || N < 1) return LCR_EARG;
+  Carver c(nullptr, ~size_t(0));
+  c.take<int32_t>(B * (M + 1));
+  c.take<uint8_t>(B * (M + 1));
+  c.take<int32_t>(B * (N + 1));
+  c.take<uint8_t>(B * (N + 1));
+  c.take<int32_t>(B * M + 1);
+  c.take<int32_t>(B * M + 1);
+  c.take<char>(scan_ws_bytes(B * M + 1));
+  *bytes = c.off;
+  return LCR_OK;
+}
+
+// Two-phase: out_bij == NULL -> only *total (device i64) is produced (and the per-row offsets kept in ws);
+// then call again with buffers of `total` entries.  (b,i,j) triplets in row-major order; scores in the exp domain.
+extern "C" int lcr_top1_matching(const float* logS, int64_t B, int M, int N, const uint8_t* row_mask, const uint8_t* col_mask, int64_t* total,
+                                 int32_t* out_bij, float* out_score, void* ws, size_t ws_bytes, void* stream) {
+  if (!logS || !ws || B < 1 || M < 1 || N < 1 || (!out_bij && !total)) return LCR_EARG;
+  size_t need = 0;
+  lcr_top1_matching_ws_bytes(B, M, N, &need);
+  if (need > ws_bytes) return LCR_ESPACE;
+  Carver c(ws, ws_bytes);
+  int32_t* rowarg = c.take<int32_t>(B * (M + 1));
+  uint8_t* rowbeat = c.take<uint8_t>(B * (M + 1));
+  int32_t* colarg = c.take<int32_t>(B * (N + 1));
+  uint8_t* colbeat = c.take<uint8_t>(B * (N + 1));
+  int32_t* counts = c.take<int32_t>(B * M + 1);
+  int32_t* offsets = c.take<int32_t>(B * M + 1);
+  void* sws = c.take<char>(scan_ws_bytes(B * M + 1));
+  hipStream_t st = ST(stream);
+  if (!out_bij) {
+    hipLaunchKernelGGL(k_top1_stats, dim3(static_cast<int>(B)), dim3(256), 0, st, logS, M, N, rowarg, rowbeat, colarg, colbeat);
+    hipLaunchKernelGGL((k_top1_emit<0>), dim3(blocks_for(B * M)), dim3(256), 0, st, logS, B, M, N, rowarg, rowbeat, colarg, colbeat, row_mask, col_mask,
+                       counts, offsets, out_bij, out_score);
+    hipMemsetAsync(counts + B * M, 0, sizeof(int32_t), st);
+    int rc = exclusive_scan_i32(counts, offsets, B * M + 1, total, sws, st);
+    if (rc) return rc;
+  } else {
+    hipLaunchKernelGGL((k_top1_emit<1>), dim3(blocks_for(B * M)), dim3(256), 0, st, logS, B, M, N, rowarg, rowbeat, colarg, colbeat, row_mask, col_mask,
+                       counts, offsets, out_bij, out_score);
+  }
+  return check_launch("lcr_top1_matching");
+}
+
+extern "C" int lcr_upsample_concat(const float* x, int64_t Nx, int C1, const void* idx, int idx_is_64, int H, const float* skip, int C2, int64_t N,
+                                   float* out, void* stream) {
+  if (!x || !idx || !skip || !out || N < 0 || C1 < 1 || C2 < 1 || H < 1) return LCR_EARG;
+  if (N == 0) return LCR_OK;
+  const int nb = blocks_for(N * (C1 + C2), 256, 8192);
+  if (idx_is_64) hipLaunchKernelGGL((k_upsample_concat<int64_t>), dim3(nb), dim3(256), 0, ST(stream), x, Nx, C1, static_cast<const int64_t*>(idx), H, skip, C2, N, out);
+  else hipLaunchKernelGGL((k_upsample_concat<int32_t>), dim3(nb), dim3(256), 0, ST(stream), x, Nx, C1, static_cast<const int32_t*>(idx), H, skip, C2, N, out);
+  return check_launch("lcr_upsample_concat");
+}
+
+extern "C" int lcr_gather_rows(const float* src, int64_t pad, int C, const int64_t* idx, int64_t R, float* out, void* stream) {
+  if (!src || !idx || !out || R < 0 || C < 1) return LCR_EARG;
+  if (R == 0) return LCR_OK;
+  hipLaunchKernelGGL(k_gather_rows, dim3(blocks_for(R * C, 256, 8192)), dim3(256), 0, ST(stream), src, pad, C, idx, R, out);
+  return check_launch("lcr_gather_rows");
+}
+
+extern "C" int lcr_procrustes_batched(const float* src, const float* ref, const float* w, const int32_t* start, int P, float eps, float* T, void* stream) {
+  if (!src || !ref || !w || !start || !T || P < 1) return LCR_EARG;
+  hipLaunchKernelGGL(k_procrustes, dim3(P), dim3(64), 0, ST(stream), src, ref, w, start, eps, T);
+  return check_launch("lcr_procrustes_batched");
+}
+
+extern "C" int lcr_inlier_count(const float* T, int P, const float* src, const float* ref, int n, float radius, const int32_t* start, int min_count,
+                                int32_t* counts, int32_t* best, void* stream) {
+  if (!T || !src || !ref || !counts || P < 1 || n < 0) return LCR_EARG;
+  hipLaunchKernelGGL(k_inlier_count, dim3(P), dim3(256), 0, ST(stream), T, src, ref, n, radius, start, min_count, counts);
+  if (best) hipLaunchKernelGGL(k_argmax_i32, dim3(1), dim3(64), 0, ST(stream), counts, P, best);
+  return check_launch("lcr_inlier_count");
+}
+
+extern "C" int lcr_inlier_weights(const float* T_all, const int32_t* sel, const float* src, const float* ref, const float* score, int n, float radius,
+                                  float* w_out, void* stream) {
+  if (!T_all || !src || !ref || !score || !w_out || n < 0) return LCR_EARG;
+  if (n == 0) return LCR_OK;
+  hipLaunchKernelGGL(k_inlier_weights, dim3(blocks_for(n)), dim3(256), 0, ST(stream), T_all, sel, src, ref, score, n, radius, w_out);
+  return check_launch("lcr_inlier_weights");
+}

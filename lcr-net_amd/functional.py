@@ -186,6 +186,11 @@ def linear(x, weight, bias=None, relu=False):
     return y
 
 
+def relu_(x):
+    _lib.check(_lib.lib().lcr_relu_inplace(_lib.ptr(x), x.numel(), _lib.stream_ptr(x.device)), "lcr_relu_inplace")
+    return x
+
+
 def rotary_embed_(x, theta, heads):
     """In place rotary position embedding (rpetransformer.py:41-54): x [N, heads*32], theta [N, heads*16]."""
     assert x.is_contiguous() and theta.is_contiguous() and x.shape[1] == heads * 32 and theta.shape[1] == heads * 16
@@ -207,3 +212,148 @@ def add_layernorm(a, b, gamma, beta, eps=1e-5):
     _lib.check(_lib.lib().lcr_add_layernorm(_lib.ptr(a), _lib.ptr(b), _lib.ptr(gamma), _lib.ptr(beta), a.shape[0], a.shape[1], float(eps),
                                             _lib.ptr(y), _lib.stream_ptr(a.device)), "lcr_add_layernorm")
     return y
+
+
+# ------------------------------------------------------------------------------------------------ pose tail (a-10)
+def _L():
+    return _lib.lib()
+
+
+def _sp(t):
+    return _lib.stream_ptr(t.device)
+
+
+def vote_shift(xyz, offsets, max_range):
+    out = torch.empty_like(xyz)
+    _lib.check(_L().lcr_vote_shift(_lib.ptr(xyz.contiguous()), _lib.ptr(offsets.contiguous()), xyz.shape[0], float(max_range), _lib.ptr(out),
+                                   _sp(xyz)), "lcr_vote_shift")
+    return out
+
+
+def greedy_nms(points, lengths, radius):
+    """(keep mask uint8 [N], kept count per cloud i64 [B]) — modules/vote/vote.py:13-70."""
+    n, B = points.shape[0], lengths.numel()
+    keep = torch.empty((n,), dtype=torch.uint8, device=points.device)
+    out_len = torch.empty((B,), dtype=torch.int64, device=points.device)
+    ws = _lib.workspace(n, points.device)
+    _lib.check(_L().lcr_greedy_nms(_lib.ptr(points.contiguous()), _lib.ptr(lengths), B, n, float(radius), _lib.ptr(keep), _lib.ptr(out_len),
+                                   _lib.ptr(ws), _sp(points)), "lcr_greedy_nms")
+    return keep, out_len
+
+
+def neighbor_mean(points, idx, pad):
+    out = torch.empty((idx.shape[0], 3), dtype=torch.float32, device=points.device)
+    _lib.check(_L().lcr_neighbor_mean(_lib.ptr(points.contiguous()), _lib.ptr(idx.contiguous()), _idx_args(idx), idx.shape[0], idx.shape[1], int(pad),
+                                      _lib.ptr(out), _sp(points)), "lcr_neighbor_mean")
+    return out
+
+
+def point_to_node_partition(points, nodes, point_limit):
+    """(point_to_node i32[N], node_masks bool[M], node_knn_indices i64[M,K], node_knn_masks bool[M,K]) —
+    modules/ops/pointcloud_partition.py:60-107."""
+    N, M, dev = points.shape[0], nodes.shape[0], points.device
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(_L().lcr_point_to_node_ws_bytes(N, M, ctypes.byref(nbytes)), "lcr_point_to_node_ws_bytes")
+    ws = _lib.workspace(nbytes.value, dev)
+    p2n = torch.empty((N,), dtype=torch.int32, device=dev)
+    knn = torch.empty((M, point_limit), dtype=torch.int64, device=dev)
+    km = torch.empty((M, point_limit), dtype=torch.uint8, device=dev)
+    nm = torch.empty((M,), dtype=torch.uint8, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(_L().lcr_point_to_node_partition(_lib.ptr(points.contiguous()), N, _lib.ptr(nodes.contiguous()), M, int(point_limit), _lib.ptr(p2n),
+                                                _lib.ptr(knn), _lib.ptr(km), _lib.ptr(nm), _lib.ptr(status), _lib.ptr(ws), ws.numel(), _sp(points)),
+               "lcr_point_to_node_partition")
+    return p2n, nm.bool(), knn, km.bool()
+
+
+def log_optimal_transport(raw_scores, row_masks, col_masks, alpha, scale=1.0, iters=100, inf=1e12):
+    """LearnableLogOptimalTransport on raw products [B,M,N] (scaled by `scale`) -> log scores [B,M+1,N+1]."""
+    B, M, N = raw_scores.shape
+    dev = raw_scores.device
+    rm, cm = row_masks.to(torch.uint8).contiguous(), col_masks.to(torch.uint8).contiguous()
+    S = torch.empty((B, M + 1, N + 1), dtype=torch.float32, device=dev)
+    _lib.check(_L().lcr_build_padded_scores(_lib.ptr(raw_scores.contiguous()), _lib.ptr(rm), _lib.ptr(cm), B, M, N, float(scale),
+                                            _lib.ptr(alpha.reshape(1).float()), float(inf), _lib.ptr(S), _sp(S)), "lcr_build_padded_scores")
+    uv = torch.empty((B * 2 * (M + N + 2),), dtype=torch.float32, device=dev)
+    _lib.check(_L().lcr_log_sinkhorn(_lib.ptr(S), _lib.ptr(rm), _lib.ptr(cm), B, M, N, int(iters), float(inf), _lib.ptr(uv), _sp(S)),
+               "lcr_log_sinkhorn")
+    return S
+
+
+def top1_matching(log_scores, row_masks=None, col_masks=None):
+    """(bij int32 [C,3], scores f32 [C], per-row offsets are internal) — dustbin top-1 matching, row-major order.
+    One host sync for the (data-dependent) number of correspondences."""
+    B, M1, N1 = log_scores.shape
+    M, N, dev = M1 - 1, N1 - 1, log_scores.device
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(_L().lcr_top1_matching_ws_bytes(B, M, N, ctypes.byref(nbytes)), "lcr_top1_matching_ws_bytes")
+    ws = _lib.workspace(nbytes.value, dev)
+    rm = row_masks.to(torch.uint8).contiguous() if row_masks is not None else None
+    cm = col_masks.to(torch.uint8).contiguous() if col_masks is not None else None
+    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    args = (_lib.ptr(log_scores.contiguous()), B, M, N, _lib.ptr(rm), _lib.ptr(cm))
+    _lib.check(_L().lcr_top1_matching(*args, _lib.ptr(total), None, None, _lib.ptr(ws), ws.numel(), _sp(log_scores)), "lcr_top1_matching")
+    n = int(total.item())
+    bij = torch.empty((max(n, 1), 3), dtype=torch.int32, device=dev)
+    sc = torch.empty((max(n, 1),), dtype=torch.float32, device=dev)
+    if n:
+        _lib.check(_L().lcr_top1_matching(*args, _lib.ptr(total), _lib.ptr(bij), _lib.ptr(sc), _lib.ptr(ws), ws.numel(), _sp(log_scores)),
+                   "lcr_top1_matching")
+    return bij[:n], sc[:n]
+
+
+def upsample_concat(x, idx, skip):
+    out = torch.empty((skip.shape[0], x.shape[1] + skip.shape[1]), dtype=torch.float32, device=x.device)
+    _lib.check(_L().lcr_upsample_concat(_lib.ptr(x.contiguous()), x.shape[0], x.shape[1], _lib.ptr(idx.contiguous()), _idx_args(idx), idx.shape[1],
+                                        _lib.ptr(skip.contiguous()), skip.shape[1], skip.shape[0], _lib.ptr(out), _sp(x)), "lcr_upsample_concat")
+    return out
+
+
+def gather_rows(src, idx):
+    """src[idx] with zero rows where idx == src.shape[0] (index_select on the zero-padded tensor); idx int64 any shape."""
+    idx = idx.contiguous()
+    out = torch.empty(tuple(idx.shape) + (src.shape[1],), dtype=torch.float32, device=src.device)
+    _lib.check(_L().lcr_gather_rows(_lib.ptr(src.contiguous()), src.shape[0], src.shape[1], _lib.ptr(idx), idx.numel(), _lib.ptr(out), _sp(src)),
+               "lcr_gather_rows")
+    return out
+
+
+def bmm_nt(a, b):
+    """[P,M,K] x [P,N,K]^T -> [P,M,N] on the MFMA GEMM (einsum 'bnd,bmd->bnm')."""
+    P, M, K = a.shape
+    N = b.shape[1]
+    c = torch.empty((P, M, N), dtype=torch.float32, device=a.device)
+    a, b = a.contiguous(), b.contiguous()
+    for z0 in range(0, P, 65535):
+        cnt = min(65535, P - z0)
+        _lib.check(_L().lcr_gemm_f32_strided_batched(_lib.ptr(a[z0:]), _lib.ptr(b[z0:]), _lib.ptr(c[z0:]), M, N, K, 0, 1, M * K, N * K, M * N, cnt,
+                                                     _sp(a)), "lcr_gemm_f32_strided_batched")
+    return c
+
+
+def procrustes(src, ref, w, start=None):
+    """Batched weighted Procrustes: problems = ranges [start[p], start[p+1]) (int32 device) or one problem over all rows."""
+    dev = src.device
+    if start is None:
+        start = torch.tensor([0, src.shape[0]], dtype=torch.int32, device=dev)
+    P = start.numel() - 1
+    T = torch.empty((P, 4, 4), dtype=torch.float32, device=dev)
+    _lib.check(_L().lcr_procrustes_batched(_lib.ptr(src.contiguous()), _lib.ptr(ref.contiguous()), _lib.ptr(w.contiguous()), _lib.ptr(start), P, 1e-5,
+                                           _lib.ptr(T), _sp(src)), "lcr_procrustes_batched")
+    return T
+
+
+def inlier_count(T, src, ref, radius, start=None, min_count=0):
+    P, dev = T.shape[0], T.device
+    counts = torch.empty((P,), dtype=torch.int32, device=dev)
+    best = torch.empty((1,), dtype=torch.int32, device=dev)
+    _lib.check(_L().lcr_inlier_count(_lib.ptr(T), P, _lib.ptr(src), _lib.ptr(ref), src.shape[0], float(radius), _lib.ptr(start), int(min_count),
+                                     _lib.ptr(counts), _lib.ptr(best), _sp(T)), "lcr_inlier_count")
+    return counts, best
+
+
+def inlier_weights(T_all, sel, src, ref, score, radius):
+    w = torch.empty_like(score)
+    _lib.check(_L().lcr_inlier_weights(_lib.ptr(T_all), _lib.ptr(sel), _lib.ptr(src), _lib.ptr(ref), _lib.ptr(score), src.shape[0], float(radius),
+                                       _lib.ptr(w), _sp(T_all)), "lcr_inlier_weights")
+    return w

@@ -1,10 +1,11 @@
 """LCRNet — the pair model (experiments/lcrnet/model_family/LCRNet.py:25-321) with the reference's module tree, so
 `best-model-mixed.tar` loads unchanged (373 tensors).
 
-Implemented on the HIP path (this round): KeypointDetection up to the transformer (LCRNet.py:124-151: KPEncoder over the
-pair stack, 3D-RoFormer on the coarsest stage) and GlobalDescritionHEAD on the PRE-transformer features of each cloud
-(:115-122, :296-297).  The pose tail (Vote_Encoder forward, KPDecoder, Sinkhorn matching, LocalGlobalRegistration; :161-272)
-holds its parameters here — so checkpoints round-trip — but its forward is SURVEY §8f-2 "next" work and raises.
+Everything runs on the HIP path: KeypointDetection (LCRNet.py:124-159: KPEncoder over the pair stack, 3D-RoFormer on the
+coarsest stage, Vote_Encoder), GlobalDescritionHEAD on the PRE-transformer features of each cloud (:115-122, :296-297) and
+DenseMatchingHEAD (:161-272: point-to-node partition, node-level Sinkhorn + dustbin matching, KPDecoder, patch-level
+Sinkhorn, local-to-global registration with device-side 3x3 SVDs) — with no device->host->device tensor round trips (the
+reference has four); only a few scalar sizes are read back where output shapes depend on the data.
 """
 import torch
 import torch.nn as nn
@@ -12,12 +13,15 @@ import torch.nn as nn
 from ..backbone4 import KPEncoder
 from ..config import make_cfg
 from ..modules.kpconv import LastUnaryBlock, ResidualBlock, UnaryBlock
+from .. import functional as F
 from ..modules.netvlad import NetVLADLoupe2
+from ..modules.ops import radius_search
 from ..modules.thdroformer import ThDRoFormer
 
 
 class Vote_layer(nn.Module):
-    """Parameters of modules/vote/vote.py:112-140 (shared MLP 256->512->256 with LayerNorm+ReLU, ctr_reg 256->3)."""
+    """modules/vote/vote.py:112-182 (output_feats=False): shared MLP 256->512->256 (Linear, LayerNorm, ReLU), ctr_reg 256->3,
+    offsets clamped to MAX_TRANSLATE_RANGE."""
 
     def __init__(self, input_feats_dim=256, max_translate_range=4.2):
         super().__init__()
@@ -26,11 +30,21 @@ class Vote_layer(nn.Module):
         self.ctr_reg = nn.Linear(c, 3)
         self.max_translate_range = max_translate_range
 
+    def forward(self, xyz, features):
+        x = features
+        for i in (0, 3):
+            lin, ln = self.mlp_modules[i], self.mlp_modules[i + 1]
+            x = F.relu_(F.add_layernorm(F.linear(x, lin.weight, lin.bias), None, ln.weight, ln.bias, ln.eps))
+        off = F.linear(x, self.ctr_reg.weight, self.ctr_reg.bias)
+        return F.vote_shift(xyz, off, self.max_translate_range)
+
 
 class Vote_Encoder(nn.Module):
-    """Parameters of backbone4.py:92-118 (vote layer + encoder6_1..3 at radii 8x/16x/16x init_radius)."""
+    """backbone4.py:92-220: vote layer -> greedy NMS -> node centres (mean of in-radius votes) -> two radius searches ->
+    encoder6_1..3 (radii 8x/16x/16x init_radius).  All on the device: the reference's three `.cpu()` radius searches
+    (:149-157, :191-206) and its Python NMS loop are HIP kernels here."""
 
-    def __init__(self, init_dim, kernel_size, init_radius, init_sigma, group_norm, vote_cfg):
+    def __init__(self, init_dim, kernel_size, init_radius, init_sigma, group_norm, vote_cfg, neighbor_limits):
         super().__init__()
         self.vote = Vote_layer(256, vote_cfg["MAX_TRANSLATE_RANGE"])
         self.NMS_radius = vote_cfg["NMS_radius"]
@@ -38,19 +52,43 @@ class Vote_Encoder(nn.Module):
         self.encoder6_1 = ResidualBlock(d * 4, d * 4, k, r * 8, s * 8, g, strided=True)
         self.encoder6_2 = ResidualBlock(d * 4, d * 8, k, r * 16, s * 16, g)
         self.encoder6_3 = ResidualBlock(d * 8, d * 8, k, r * 16, s * 16, g)
+        self.init_radius = init_radius
+        self.neighbor_limits = list(neighbor_limits)
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("Vote_Encoder.forward (vote -> NMS -> radius searches -> encoder6_x) is SURVEY §8f-2 'next' work")
+    def forward(self, feats, data_dict, neighbor_limit=None):
+        limits = list(neighbor_limit) if neighbor_limit is not None else self.neighbor_limits
+        lens_c = data_dict["lengths"][-1]
+        points_c = data_dict["points"][-1].contiguous()
+        shifted = self.vote(points_c, feats)
+        keep, length = F.greedy_nms(shifted, lens_c, self.NMS_radius)
+        nms_pts = shifted[keep.bool()].contiguous()                       # compaction (host sync: output size is data dependent)
+        pad = shifted.shape[0]
+        knn = radius_search(nms_pts, shifted, length, lens_c, 2.4, limits[-1])                    # backbone4.py:149-156 (literal 2.4)
+        centers = F.neighbor_mean(shifted, knn, pad)
+        sub = radius_search(centers, points_c, length, lens_c, self.init_radius * 8, limits[-2])
+        nb = radius_search(centers, centers, length, length, self.init_radius * 16, limits[-1])
+        f = self.encoder6_1(feats, centers, points_c, sub)
+        f = self.encoder6_2(f, centers, centers, nb)
+        f = self.encoder6_3(f, centers, centers, nb)
+        return {"shifted_points_c": shifted, "nms_mask": keep, "length": length, "points_c": centers, "feats_c": f}
 
 
 class KPDecoder(nn.Module):
-    """Parameters of backbone4.py:333-343."""
+    """backbone4.py:333-373: nearest-upsample (column 0 of the upsampling lists) + concat + UnaryBlock, three levels."""
 
     def __init__(self, init_dim, group_norm):
         super().__init__()
         self.decoder3 = UnaryBlock(init_dim * 12, init_dim * 8, group_norm)
         self.decoder2 = UnaryBlock(init_dim * 12, init_dim * 4, group_norm)
         self.decoder1 = LastUnaryBlock(init_dim * 6, init_dim * 2)
+
+    def forward(self, feats, data_dict):
+        f1, f2, f3, f4 = feats
+        U = data_dict["upsampling"]
+        l3 = self.decoder3(F.upsample_concat(f4, U[2], f3))
+        l2 = self.decoder2(F.upsample_concat(l3, U[1], f2))
+        l1 = self.decoder1(F.upsample_concat(l2, U[0], f1))
+        return [l1, l2, l3]
 
 
 class LearnableLogOptimalTransport(nn.Module):
@@ -66,7 +104,13 @@ class LCRNet(nn.Module):
         cfg = cfg or make_cfg()
         b, g = cfg["backbone"], cfg["GAT"]
         self.encoder = KPEncoder(b["input_dim"], b["init_dim"], b["kernel_size"], b["init_radius"], b["init_sigma"], b["group_norm"])
-        self.vote_encoder = Vote_Encoder(b["init_dim"], b["kernel_size"], b["init_radius"], b["init_sigma"], b["group_norm"], cfg["Vote"])
+        self.vote_encoder = Vote_Encoder(b["init_dim"], b["kernel_size"], b["init_radius"], b["init_sigma"], b["group_norm"], cfg["Vote"],
+                                         cfg["neighbor_limits"])
+        self.num_points_in_patch = cfg["model"]["num_points_in_patch"]
+        fm = cfg.get("fine_matching", {})
+        self.acceptance_radius = fm.get("acceptance_radius", 0.45)
+        self.correspondence_threshold = fm.get("correspondence_threshold", 3)
+        self.num_refinement_steps = fm.get("num_refinement_steps", 5)
         self.proj_node_overlap_score = nn.Linear(g["output_dim"] * 2, 1)
         self.transformer = ThDRoFormer(g["input_dim"], g["output_dim"], g["hidden_dim"], g["num_heads"], g["num_layers"], g["k"])
         self.kpdecoder = KPDecoder(b["init_dim"], b["group_norm"])
@@ -74,10 +118,33 @@ class LCRNet(nn.Module):
         self.optimal_transport = LearnableLogOptimalTransport(cfg["model"]["num_sinkhorn_iterations"])
         self.netvlad = NetVLADLoupe2(feature_size=1024, cluster_size=64, output_dim=256, gating=True, add_norm=True, is_training=False)
 
-    def forward(self, data_dict):
-        """Pair stack [pos(ref), anc(src)] (data.py:110-113).  GroupNorm statistics span the pair unless
-        data_dict['segment_lengths'] says otherwise.  Needs lengths[-1] on the host: data_dict['lengths_c_host'] or a sync.
-        Returns the keys of the reference output_dict that this round implements."""
+    # ---- LocalGlobalRegistration (geotransformer/local_global_registration.py:134-246; k=1, mutual=False, dustbin) --------
+    def _local_global_registration(self, ref_knn_points, src_knn_points, ref_masks, src_masks, log_scores):
+        P, K = ref_masks.shape
+        bij, sc = F.top1_matching(log_scores, ref_masks, src_masks)
+        if bij.shape[0] == 0:
+            raise RuntimeError("no dense correspondences (the reference fails here as well)")
+        b, i, j = bij[:, 0].long(), bij[:, 1].long(), bij[:, 2].long()
+        rp = F.gather_rows(ref_knn_points.reshape(-1, 3), b * K + i)
+        sp = F.gather_rows(src_knn_points.reshape(-1, 3), b * K + j)
+        start = torch.zeros(P + 1, dtype=torch.int32, device=rp.device)
+        start[1:] = torch.cumsum(torch.bincount(b, minlength=P), 0).int()          # rows are patch-major: chunk p = [start[p], start[p+1])
+        hyp = F.procrustes(sp, rp, sc, start)                                         # one hypothesis per patch correspondence
+        counts, best = F.inlier_count(hyp, sp, rp, self.acceptance_radius, start, self.correspondence_threshold)
+        if bool((counts >= 0).any()):
+            cur = F.inlier_weights(hyp, best, sp, rp, sc, self.acceptance_radius)
+        else:                                                                          # degenerate: all correspondences at once (:186-190)
+            cur = F.inlier_weights(F.procrustes(sp, rp, sc), None, sp, rp, sc, self.acceptance_radius)
+        T = F.procrustes(sp, rp, cur)
+        for _ in range(self.num_refinement_steps - 1):
+            cur = F.inlier_weights(T, None, sp, rp, sc, self.acceptance_radius)
+            T = F.procrustes(sp, rp, cur)
+        return rp, sp, sc, T[0]
+
+    def forward(self, data_dict, pose=True):
+        """Pair stack [pos(ref), anc(src)] (data.py:110-113) -> the reference's output_dict (LCRNet.py:274-321).  GroupNorm
+        statistics span the pair unless data_dict['segment_lengths'] says otherwise.  pose=False stops after the transformer
+        and the global descriptors."""
         if self.training:
             raise RuntimeError("lcr-net_amd implements inference only; call .eval()")
         feats = data_dict["features"].detach()
@@ -91,9 +158,52 @@ class LCRNet(nn.Module):
         pos_c, anc_c = feats_c[:n0].contiguous(), feats_c[n0:n0 + n1].contiguous()
         e0, e1 = self.transformer(points_c[:n0].contiguous(), points_c[n0:n0 + n1].contiguous(), pos_c, anc_c)
         g = self.netvlad.describe(feats_c[:n0 + n1], [n0, n1])       # pre-transformer features (LCRNet.py:296-297)
-        return {"pos_feature_global": g[0:1], "anc_feature_global": g[1:2], "pos_points_c": points_c[:n0],
-                "anc_points_c": points_c[n0:n0 + n1], "pos_feats_c_enhanced": e0, "anc_feats_c_enhanced": e1,
-                "feats_list": feats_list}
+        out = {"pos_feature_global": g[0:1], "anc_feature_global": g[1:2], "ori_pos_points_c": points_c[:n0],
+               "ori_anc_points_c": points_c[n0:n0 + n1], "pos_feats_c_enhanced": e0, "anc_feats_c_enhanced": e1}
+        if not pose:
+            out["feats_list"] = feats_list
+            return out
+
+        # ---- KeypointDetection tail (LCRNet.py:152-159) and DenseMatchingHEAD (:161-272)
+        enhanced = torch.cat([e0, e1], 0)
+        vd = self.vote_encoder(enhanced, data_dict)
+        m = vd["length"].tolist()                                     # host sync (the reference does length[0] indexing too)
+        m0 = int(m[0])
+        L0 = data_dict["lengths"][0].tolist()
+        nf0, nf1 = int(L0[0]), int(L0[1])
+        pts_f = data_dict["points"][0]
+        pos_f, anc_f = pts_f[:nf0].contiguous(), pts_f[nf0:nf0 + nf1].contiguous()
+        pos_nodes, anc_nodes = vd["points_c"][:m0].contiguous(), vd["points_c"][m0:].contiguous()
+        pos_fc, anc_fc = vd["feats_c"][:m0].contiguous(), vd["feats_c"][m0:].contiguous()
+        K = self.num_points_in_patch
+        _, pos_nm, pos_knn, pos_km = F.point_to_node_partition(pos_f, pos_nodes, K)
+        _, anc_nm, anc_knn, anc_km = F.point_to_node_partition(anc_f, anc_nodes, K)
+        raw = F.gemm(pos_fc, anc_fc, trans_b=True)[0]
+        ns = F.log_optimal_transport(raw[None], pos_nm[None], anc_nm[None], self.node_optimal_transport.alpha,
+                                     scale=1.0 / pos_fc.shape[1] ** 0.5, iters=self.node_optimal_transport.num_iterations)
+        nbij, node_corr_scores = F.top1_matching(ns)                   # masks are not applied at this level (superpoint_matching.py:130-162)
+        pi, ai = nbij[:, 1].long(), nbij[:, 2].long()
+        fl = list(feats_list)
+        fl[-1] = enhanced                                              # LCRNet.py:154-155
+        feats_f = self.kpdecoder(fl, data_dict)[0]
+        pos_ff, anc_ff = feats_f[:nf0].contiguous(), feats_f[nf0:].contiguous()
+        pk, ak = pos_knn[pi].contiguous(), anc_knn[ai].contiguous()    # (P, K) point indices of the matched patches
+        pkm, akm = pos_km[pi].contiguous(), anc_km[ai].contiguous()
+        pkp, akp = F.gather_rows(pos_f, pk), F.gather_rows(anc_f, ak)
+        pkf, akf = F.gather_rows(pos_ff, pk), F.gather_rows(anc_ff, ak)
+        ms = F.log_optimal_transport(F.bmm_nt(pkf, akf), pkm, akm, self.optimal_transport.alpha,
+                                     scale=1.0 / feats_f.shape[1] ** 0.5, iters=self.optimal_transport.num_iterations)
+        rp, sp, sc, T = self._local_global_registration(pkp, akp, pkm, akm, ms)
+        out.update({
+            "shifted_pos_points_c": vd["shifted_points_c"][:n0], "shifted_anc_points_c": vd["shifted_points_c"][n0:n0 + n1],
+            "length": vd["length"], "pos_points_c": pos_nodes, "anc_points_c": anc_nodes, "feats_c": vd["feats_c"],
+            "pos_feats_c": pos_fc, "anc_feats_c": anc_fc, "pos_points_f": pos_f, "anc_points_f": anc_f,
+            "pos_node_knn_indices": pos_knn, "pos_node_knn_masks": pos_km, "anc_node_knn_indices": anc_knn, "anc_node_knn_masks": anc_km,
+            "pos_node_corr_indices": pi, "anc_node_corr_indices": ai, "node_corr_scores": node_corr_scores,
+            "pos_feats_f": pos_ff, "anc_feats_f": anc_ff, "pos_node_corr_knn_points": pkp, "anc_node_corr_knn_points": akp,
+            "pos_node_corr_knn_masks": pkm, "anc_node_corr_knn_masks": akm, "matching_scores": ms,
+            "pos_corr_points": rp, "anc_corr_points": sp, "corr_scores": sc, "estimated_transform": T})
+        return out
 
 
 def create_model(cfg=None):

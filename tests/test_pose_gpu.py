@@ -1,0 +1,151 @@
+"""GPU: the registration tail (a-10).  Every kernel against the torch oracle on well-posed random inputs, then the whole
+pair model against the golden tensors of the imported reference's LCRNet.forward (tests/golden/pose_golden.npz)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, LIMITS, NUM_STAGES, RADIUS, VOXEL, load_scan
+from oracle import ops as oracle_ops
+from oracle import torch_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def test_vote_shift_nms_and_neighbor_mean():
+    from lcrnet_amd import functional as F
+    g = torch.Generator().manual_seed(0)
+    xyz = torch.randn(1500, 3, generator=g) * 20
+    off = torch.randn(1500, 3, generator=g) * 4
+    dis = off.norm(dim=1)
+    want = xyz + off * torch.where(dis > 4.2, 4.2 / dis, torch.ones_like(dis))[:, None]
+    got = F.vote_shift(xyz.cuda(), off.cuda(), 4.2).cpu()
+    assert (got - want).abs().max().item() < 1e-5
+    # clustered points so that the greedy rule has long dependency chains
+    pts = (torch.rand(1700, 3, generator=g) * torch.tensor([60.0, 60.0, 4.0]))
+    lens = torch.tensor([900, 800])
+    wmask, wlen = torch_ref.greedy_nms(pts, lens, 2.4)
+    keep, klen = F.greedy_nms(pts.cuda(), lens.cuda(), 2.4)
+    assert torch.equal(keep.cpu().bool(), wmask) and klen.cpu().tolist() == wlen.tolist()
+    idx = torch.randint(0, 1701, (300, 20), generator=g)
+    sp = torch.cat([pts, torch.zeros(1, 3)])
+    want = sp[idx].sum(1) / (idx != 1700).sum(1, keepdim=True)
+    got = F.neighbor_mean(pts.cuda(), idx.cuda(), 1700).cpu()
+    ok = (idx != 1700).sum(1) > 0
+    assert (got[ok] - want[ok]).abs().max().item() < 1e-4
+
+
+def test_point_to_node_partition():
+    from lcrnet_amd import functional as F
+    pts = torch.from_numpy(load_scan("004481"))
+    g = torch.Generator().manual_seed(1)
+    nodes = pts[torch.randperm(len(pts), generator=g)[:300]] + 0.3 * torch.randn(300, 3, generator=g)
+    nodes[7] = torch.tensor([500.0, 500.0, 0.0])            # a node that owns no point
+    wp2n, wnm, wknn, wkm = torch_ref.point_to_node_partition(pts, nodes, 128)
+    p2n, nm, knn, km = F.point_to_node_partition(pts.cuda(), nodes.cuda(), 128)
+    assert (p2n.cpu().long() == wp2n).float().mean().item() > 0.999
+    assert torch.equal(nm.cpu(), wnm)
+    assert (knn.cpu() == wknn).float().mean().item() > 0.998 and (km.cpu() == wkm).float().mean().item() > 0.999
+
+
+def test_log_sinkhorn_and_top1_matching():
+    from lcrnet_amd import functional as F
+    g = torch.Generator().manual_seed(2)
+    for (B, M, N) in [(1, 350, 331), (37, 128, 128), (3, 5, 9)]:
+        raw = torch.randn(B, M, N, generator=g) * 3
+        if B == 1:                                          # planted matches so that some pairs beat the dustbins
+            perm = torch.randperm(N, generator=g)[:200]
+            raw[0, torch.arange(200), perm] += 40.0
+        rm = torch.rand(B, M, generator=g) > 0.15
+        cm = torch.rand(B, N, generator=g) > 0.15
+        rm[:, 0] = True
+        cm[:, 0] = True
+        alpha = torch.tensor(0.7)
+        want = torch_ref.log_optimal_transport(raw * 0.5, rm, cm, alpha, iters=100)
+        got = F.log_optimal_transport(raw.cuda(), rm.cuda(), cm.cuda(), alpha.cuda(), scale=0.5, iters=100).cpu()
+        valid = torch.ones(B, M + 1, N + 1, dtype=torch.bool)
+        valid[:, :M, :] &= rm[:, :, None]
+        valid[:, :, :N] &= cm[:, None, :]
+        assert (got[valid] - want[valid]).abs().max().item() < 2e-3, (B, M, N)
+        if B == 1:
+            wi, wj, ws = torch_ref.superpoint_matching_ot(want[0])
+            bij, sc = F.top1_matching(got.cuda())
+            assert set(zip(wi.tolist(), wj.tolist())) == set(zip(bij[:, 1].tolist(), bij[:, 2].tolist()))
+            assert bij[:, 1].tolist() == wi.tolist()                       # row-major order
+            assert (sc.cpu() - ws).abs().max().item() < 1e-3 * ws.abs().max().item() + 1e-6
+
+
+def test_procrustes_and_lgr_pieces():
+    from lcrnet_amd import functional as F
+    g = torch.Generator().manual_seed(3)
+    P, n = 20, 60
+    src = torch.randn(P * n, 3, generator=g) * 5
+    w = torch.rand(P * n, generator=g)
+    A = torch.randn(P, 3, 3, generator=g)
+    Q, _ = torch.linalg.qr(A)
+    Q = Q * torch.sign(torch.det(Q))[:, None, None]
+    t = torch.randn(P, 3, generator=g) * 3
+    ref = torch.cat([src[p * n:(p + 1) * n] @ Q[p].t() + t[p] for p in range(P)]) + 0.01 * torch.randn(P * n, 3, generator=g)
+    start = torch.arange(0, P * n + 1, n, dtype=torch.int32)
+    want = torch.stack([torch_ref.weighted_procrustes(src[p * n:(p + 1) * n], ref[p * n:(p + 1) * n], w[p * n:(p + 1) * n]) for p in range(P)])
+    got = F.procrustes(src.cuda(), ref.cuda(), w.cuda(), start.cuda()).cpu()
+    assert (got - want).abs().max().item() < 1e-4
+    # planar (rank-2) correspondences and a reflection-prone case still give a proper rotation
+    flat = src[:n].clone()
+    flat[:, 2] = 0
+    T = F.procrustes(flat.cuda(), (flat @ Q[0].t() + t[0]).cuda(), torch.ones(n).cuda()).cpu()[0]
+    assert abs(torch.det(T[:3, :3]).item() - 1) < 1e-4 and (T[:3, :3] - Q[0]).abs().max().item() < 1e-3
+    counts, best = F.inlier_count(got.cuda(), src.cuda(), ref.cuda(), 0.5, start.cuda(), 3)
+    res = torch.linalg.norm(ref[None] - (src[None] @ want[:, :3, :3].transpose(1, 2) + want[:, None, :3, 3]), dim=2)
+    assert counts.cpu().tolist() == (res < 0.5).sum(1).tolist()
+    assert int(best.item()) == int((res < 0.5).sum(1).argmax())
+
+
+@pytest.fixture(scope="module")
+def pair_run():
+    from lcrnet_amd.model_family import LCRNet
+    from lcrnet_amd.weights import seeded_state_dict
+    seed = json.load(open(os.path.join(GOLDEN, "model_manifest.json")))["seed"]
+    cfg_limits = LIMITS
+    from lcrnet_amd.config import make_cfg
+    cfg = make_cfg()
+    cfg["neighbor_limits"] = cfg_limits
+    m = LCRNet(cfg).eval()
+    m.load_state_dict(seeded_state_dict(m.state_dict(), seed), strict=True)
+    m = m.cuda()
+    a, b = load_scan("003854"), load_scan("000958")
+    st = oracle_ops.precompute_data_stack_mode(np.concatenate([a, b]), np.array([len(a), len(b)]), NUM_STAGES, VOXEL, RADIUS, LIMITS)
+    dd = {k: [torch.from_numpy(np.ascontiguousarray(t)).cuda() for t in v] for k, v in st.items()}
+    dd["features"] = torch.ones(len(a) + len(b), 1, device="cuda")
+    with torch.no_grad():
+        out = m(dd)
+    return {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in out.items()}
+
+
+def test_pair_model_pose_tail_vs_reference_golden(pair_run):
+    gold = np.load(os.path.join(GOLDEN, "pose_golden.npz"))
+    out = pair_run
+    assert np.allclose(out["shifted_pos_points_c"].numpy(), gold["shifted_pos_points_c"], atol=5e-4)
+    assert out["length"].tolist() == gold["length"].tolist()                       # greedy NMS keeps the same number of nodes
+    assert np.allclose(out["pos_points_c"].numpy(), gold["pos_points_c"], atol=5e-4)
+    assert np.allclose(out["anc_points_c"].numpy(), gold["anc_points_c"], atol=5e-4)
+    r = gold["feats_c_rows"]
+    assert np.allclose(out["feats_c"].numpy()[r], gold["feats_c_vals"], atol=2e-3, rtol=2e-3)
+    for k in ("pos_node_knn_indices", "anc_node_knn_indices"):
+        assert (out[k].numpy() == gold[k]).mean() > 0.995, k
+    got = set(zip(out["pos_node_corr_indices"].tolist(), out["anc_node_corr_indices"].tolist()))
+    want = set(zip(gold["pos_node_corr_indices"].tolist(), gold["anc_node_corr_indices"].tolist()))
+    assert len(got & want) >= 0.97 * len(want) and abs(len(got) - len(want)) <= 0.03 * len(want)
+    rr = gold["pos_feats_f_rows"]
+    assert np.allclose(out["pos_feats_f"].numpy()[rr], gold["pos_feats_f_vals"], atol=2e-3, rtol=2e-3)
+    n = gold["corr_scores"].shape[0]
+    assert abs(out["corr_scores"].shape[0] - n) <= 0.05 * n
+    T, Tw = out["estimated_transform"].numpy(), gold["estimated_transform"]
+    assert abs(np.linalg.det(T[:3, :3]) - 1) < 1e-4
+    # the pose of a RANDOM-weight model is a consensus over ~4 k near-uniform matches: compare loosely (exact-weight parity is
+    # pinned op by op above); rotation within 2 degrees, translation within 0.5 m of the reference's
+    cosang = (np.trace(T[:3, :3].T @ Tw[:3, :3]) - 1) / 2
+    assert np.degrees(np.arccos(np.clip(cosang, -1, 1))) < 2.0, (T, Tw)
+    assert np.linalg.norm(T[:3, 3] - Tw[:3, 3]) < 0.5, (T, Tw)
