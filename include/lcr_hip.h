@@ -175,7 +175,8 @@ int lcr_gemm_f32_strided_batched(const float* A, const float* B, float* C, int64
 /* out = xyz + off * min(1, max_range/|off|)  (modules/vote/vote.py:166-175) */
 int lcr_vote_shift(const float* xyz, const float* offsets, int64_t N, float max_range, float* out, void* stream);
 /* Greedy NMS of modules/vote/vote.py:13-70, exact (order-dependent rule replayed in parallel rounds), one cloud per
- * workgroup.  keep u8[n_total], out_len i64[B]; ws: n_total bytes. */
+ * workgroup.  keep u8[n_total], out_len i64[B]; ws: lcr_greedy_nms_ws_bytes(n_total). */
+int lcr_greedy_nms_ws_bytes(int64_t n_total, size_t* bytes);
 int lcr_greedy_nms(const float* pts, const int64_t* len, int B, int64_t n_total, float radius, uint8_t* keep,
                    int64_t* out_len, void* ws, void* stream);
 /* out[m] = mean of pts[idx[m,h]] over the valid (0 <= idx < pad) neighbours (backbone4.py:161-175). */
@@ -188,7 +189,7 @@ int lcr_point_to_node_partition(const float* points, int64_t N, const float* nod
 /* S[B,M+1,N+1] = scale*raw with dustbin row/col = alpha[0] and masked rows/cols = -inf_val (learnable_sinkhorn.py:36-45). */
 int lcr_build_padded_scores(const float* raw, const uint8_t* row_mask, const uint8_t* col_mask, int64_t B, int M, int N,
                             float scale, const float* alpha, float inf_val, float* S, void* stream);
-/* LearnableLogOptimalTransport.forward (learnable_sinkhorn.py:13-66) in place on S; uv_ws: B*2*(M+N+2) floats. */
+/* LearnableLogOptimalTransport.forward (learnable_sinkhorn.py:13-66) in place on S; uv_ws: B*(2*(M+N+2)+1) floats. */
 int lcr_log_sinkhorn(float* S, const uint8_t* row_mask, const uint8_t* col_mask, int64_t B, int M, int N, int iters,
                      float inf_val, float* uv_ws, void* stream);
 /* Dustbin top-1 matching in the exp domain (superpoint_matching.py:130-162; local_global_registration.py:49-92 with k=1,

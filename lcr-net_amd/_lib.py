@@ -45,6 +45,7 @@ _SIGS = {
     "lcr_retrieval_topk": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "lcr_gemm_f32_strided_batched": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_int, c_vp]),
     "lcr_vote_shift": (c_int, [c_vp, c_vp, c_i64, c_float, c_vp, c_vp]),
+    "lcr_greedy_nms_ws_bytes": (c_int, [c_i64, c_size_p]),
     "lcr_greedy_nms": (c_int, [c_vp, c_vp, c_int, c_i64, c_float, c_vp, c_vp, c_vp, c_vp]),
     "lcr_neighbor_mean": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_i64, c_vp, c_vp]),
     "lcr_point_to_node_ws_bytes": (c_int, [c_i64, c_int, c_size_p]),

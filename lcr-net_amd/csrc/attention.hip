@@ -41,6 +41,31 @@ __global__ __launch_bounds__(256) void k_rotary(float* __restrict__ x, const flo
   }
 }
 
+// register-staged variant: global -> registers (issued one tile ahead), registers -> LDS
+__device__ __forceinline__ void tile_to_regs(const float* __restrict__ src, int64_t rows, int64_t r0, int ld_src, int col0, float4 (&reg)[4]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = lane + 64 * i;
+    const int r = f >> 3, c4 = f & 7;
+    const int64_t rr = r0 + r < rows ? r0 + r : rows - 1;          // clamped, branch-free; rows past the end are masked by the caller
+    reg[i] = *reinterpret_cast<const float4*>(src + rr * ld_src + col0 + c4 * 4);
+  }
+}
+__device__ __forceinline__ void regs_to_lds(const float4 (&reg)[4], float* __restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = lane + 64 * i;
+    const int r = f >> 3, c4 = f & 7;
+    float* d = dst + r * AT_LD + c4 * 4;
+    d[0] = reg[i].x;
+    d[1] = reg[i].y;
+    d[2] = reg[i].z;
+    d[3] = reg[i].w;
+  }
+}
+
 __device__ __forceinline__ void load_tile(const float* __restrict__ src, int64_t rows, int64_t r0, int ld_src, int col0, float* __restrict__ dst) {
   // 32 x 32 tile (rows r0.., columns col0..col0+31) of a row-major matrix -> dst[32][AT_LD]; rows beyond `rows` -> 0
   const int lane = threadIdx.x & 63;
@@ -80,13 +105,21 @@ __global__ __launch_bounds__(64) void k_attention(const float* __restrict__ q, c
   for (int r = 0; r < 16; ++r) o[r] = 0.f;
   float m = -INFINITY, l = 0.f;
 
+  float4 kreg[4], vreg[4];
+  tile_to_regs(k, Nk, 0, ld, head * AT_D, kreg);
+  tile_to_regs(v, Nk, 0, ld, head * AT_D, vreg);
   for (int64_t k0 = 0; k0 < Nk; k0 += 32) {
-    __builtin_amdgcn_wave_barrier();
-    load_tile(k, Nk, k0, ld, head * AT_D, s_k);
-    load_tile(v, Nk, k0, ld, head * AT_D, s_v);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                      // everyone is done reading the previous tile
+    regs_to_lds(kreg, s_k);
+    regs_to_lds(vreg, s_v);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (k0 + 32 < Nk) {                                   // next tile's loads fly while this tile's 32 MFMAs run
+      tile_to_regs(k, Nk, k0 + 32, ld, head * AT_D, kreg);
+      tile_to_regs(v, Nk, k0 + 32, ld, head * AT_D, vreg);
+    }
     // S^T[key][query] = sum_d K[key][d] * Q[query][d]
     floatx16 s;
 #pragma unroll

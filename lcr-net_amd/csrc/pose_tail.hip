@@ -37,49 +37,57 @@ __global__ __launch_bounds__(256) void k_vote_shift(const float* __restrict__ xy
 // an undecided node is dropped if a kept lower node is in range, kept if no lower node in range is still undecided.  Every
 // round decides at least the lowest undecided node, so the loop terminates; real clouds need ~10 rounds.
 constexpr int NMS_T = 1024;
+constexpr int NMS_NB = 24;   // lower-index in-range neighbours cached per node (more -> that node rescans)
 __global__ __launch_bounds__(NMS_T) void k_greedy_nms(const float* __restrict__ pts, const int64_t* __restrict__ len, int B, float radius,
-                                                      uint8_t* __restrict__ keep, int64_t* __restrict__ out_len, int8_t* __restrict__ state_ws) {
-  __shared__ int s_changed, s_undecided, s_cnt;
+                                                      uint8_t* __restrict__ keep, int64_t* __restrict__ out_len, int8_t* __restrict__ state_ws,
+                                                      int32_t* __restrict__ nbr_ws) {
+  __shared__ int s_undecided, s_cnt;
   const int b = blockIdx.x;
   int64_t o = 0;
   for (int i = 0; i < b; ++i) o += len[i];
   const int n = static_cast<int>(len[b]);
   const float* p = pts + 3 * o;
-  int8_t* st = state_ws + o;   // 0 undecided, 1 kept, 2 dropped
-  for (int i = threadIdx.x; i < n; i += NMS_T) st[i] = i == 0 ? 1 : 0;
+  int8_t* st = state_ws + o;                       // 0 undecided, 1 kept, 2 dropped
+  int32_t* nbr = nbr_ws + o * (NMS_NB + 1);        // [n][1 + NMS_NB]: count (or -1 = overflow), then indices
+  auto in_range = [&](int i, int j) {
+    const float dx = p[3 * i] - p[3 * j] + 1e-6f, dy = p[3 * i + 1] - p[3 * j + 1] + 1e-6f, dz = p[3 * i + 2] - p[3 * j + 2] + 1e-6f;
+    return !(sqrtf(dx * dx + dy * dy + dz * dz) > radius);
+  };
+  for (int i = threadIdx.x; i < n; i += NMS_T) {
+    st[i] = i == 0 ? 1 : 0;
+    int c = 0;
+    for (int j = 0; j < i; ++j)
+      if (in_range(i, j)) {
+        if (c < NMS_NB) nbr[i * (NMS_NB + 1) + 1 + c] = j;
+        ++c;
+      }
+    nbr[i * (NMS_NB + 1)] = c <= NMS_NB ? c : -1;
+  }
   __syncthreads();
   while (true) {
-    if (threadIdx.x == 0) {
-      s_changed = 0;
-      s_undecided = 0;
-    }
+    if (threadIdx.x == 0) s_undecided = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += NMS_T) {
       if (st[i] != 0) continue;
-      const float x = p[3 * i], y = p[3 * i + 1], z = p[3 * i + 2];
       bool blocked = false, dropped = false;
-      for (int j = 0; j < i; ++j) {
-        const int8_t sj = st[j];          // may be one round stale: only delays a decision, never changes it
-        if (sj == 2) continue;
-        const float dx = x - p[3 * j] + 1e-6f, dy = y - p[3 * j + 1] + 1e-6f, dz = z - p[3 * j + 2] + 1e-6f;
-        const float d = sqrtf(dx * dx + dy * dy + dz * dz);
-        if (!(d > radius)) {
-          if (sj == 1) {
-            dropped = true;
-            break;
-          }
-          blocked = true;
+      const int c = nbr[i * (NMS_NB + 1)];
+      if (c >= 0) {
+        for (int q = 0; q < c && !dropped; ++q) {
+          const int8_t sj = st[nbr[i * (NMS_NB + 1) + 1 + q]];   // may be one round stale: only delays a decision
+          dropped = sj == 1;
+          blocked |= sj == 0;
+        }
+      } else {
+        for (int j = 0; j < i && !dropped; ++j) {
+          const int8_t sj = st[j];
+          if (sj == 2 || !in_range(i, j)) continue;
+          dropped = sj == 1;
+          blocked |= sj == 0;
         }
       }
-      if (dropped) {
-        st[i] = 2;
-        s_changed = 1;
-      } else if (!blocked) {
-        st[i] = 1;
-        s_changed = 1;
-      } else {
-        s_undecided = 1;
-      }
+      if (dropped) st[i] = 2;
+      else if (!blocked) st[i] = 1;
+      else s_undecided = 1;
     }
     __syncthreads();
     const bool done = !s_undecided;
@@ -206,25 +214,14 @@ __global__ __launch_bounds__(256) void k_node_topk(const float* __restrict__ poi
 // S: [B, M+1, N+1] padded score matrices (dustbin row/column = alpha, masked entries = -inf_val), overwritten by the result
 // S + u + v - norm.  One workgroup per matrix; u, v live in global scratch (L2 resident).
 constexpr int SK_T = 512;
-__device__ __forceinline__ void online_lse(float x, float& m, float& s) {
-  if (x > m) {
-    s = s * expf(m - x) + 1.f;
-    m = x;
-  } else {
-    s += expf(x - m);
-  }
-}
 
-__global__ __launch_bounds__(SK_T) void k_log_sinkhorn(float* __restrict__ S, const uint8_t* __restrict__ row_mask, const uint8_t* __restrict__ col_mask,
-                                                       int M, int N, int iters, float inf_val, float* __restrict__ uv_ws) {
-  const int b = blockIdx.x;
-  const int M1 = M + 1, N1 = N + 1;
-  float* s = S + static_cast<int64_t>(b) * M1 * N1;
-  float* u = uv_ws + static_cast<int64_t>(b) * (M1 + N1) * 2;
-  float* v = u + M1;
-  float* log_mu = v + N1;
-  float* log_nu = log_mu + M1;
-  __shared__ float s_norm;
+// log-sum-exp over a strided vector with hardware exp/log (v_exp_f32 / v_log_f32 based; ~1e-6 relative) in two branch-free
+// passes (max, then sum of exp(x - max)); `add` is the dual vector added on the fly.
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float fast_log(float x) { return __logf(x); }
+
+__device__ __forceinline__ void sk_setup(const uint8_t* __restrict__ row_mask, const uint8_t* __restrict__ col_mask, int64_t b, int M, int N,
+                                         float inf_val, float* u, float* v, float* log_mu, float* log_nu, float* norm_out) {
   __shared__ int s_nr, s_nc;
   if (threadIdx.x == 0) {
     s_nr = 0;
@@ -232,54 +229,192 @@ __global__ __launch_bounds__(SK_T) void k_log_sinkhorn(float* __restrict__ S, co
   }
   __syncthreads();
   int cr = 0, cc = 0;
-  for (int i = threadIdx.x; i < M; i += SK_T) cr += row_mask[static_cast<int64_t>(b) * M + i] ? 1 : 0;
-  for (int j = threadIdx.x; j < N; j += SK_T) cc += col_mask[static_cast<int64_t>(b) * N + j] ? 1 : 0;
+  for (int i = threadIdx.x; i < M; i += blockDim.x) cr += row_mask[b * M + i] ? 1 : 0;
+  for (int j = threadIdx.x; j < N; j += blockDim.x) cc += col_mask[b * N + j] ? 1 : 0;
   atomicAdd(&s_nr, cr);
   atomicAdd(&s_nc, cc);
   __syncthreads();
   const float nr = static_cast<float>(s_nr), nc = static_cast<float>(s_nc);
   const float norm = -logf(nr + nc);
-  if (threadIdx.x == 0) s_norm = norm;
-  for (int i = threadIdx.x; i < M1; i += SK_T) {
-    const bool masked = i < M && !row_mask[static_cast<int64_t>(b) * M + i];
+  for (int i = threadIdx.x; i <= M; i += blockDim.x) {
+    const bool masked = i < M && !row_mask[b * M + i];
     log_mu[i] = masked ? -inf_val : (i < M ? norm : logf(nc) + norm);
     u[i] = 0.f;
   }
-  for (int j = threadIdx.x; j < N1; j += SK_T) {
-    const bool masked = j < N && !col_mask[static_cast<int64_t>(b) * N + j];
+  for (int j = threadIdx.x; j <= N; j += blockDim.x) {
+    const bool masked = j < N && !col_mask[b * N + j];
     log_nu[j] = masked ? -inf_val : (j < N ? norm : logf(nr) + norm);
     v[j] = 0.f;
   }
+  if (threadIdx.x == 0) *norm_out = norm;
   __syncthreads();
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  constexpr int NW = SK_T / 64;
-  for (int it = 0; it < iters; ++it) {
-    // u = log_mu - logsumexp_j(S + v): one wavefront per row, lanes over columns
-    for (int i = w; i < M1; i += NW) {
-      float m = -INFINITY, sum = 0.f;
-      for (int j = lane; j < N1; j += 64) online_lse(s[i * N1 + j] + v[j], m, sum);
-      // combine the 64 partial (m, sum) pairs
+}
+
+// u[i] = log_mu[i] - LSE_j(s[i][j] + v[j]) for the rows owned by this wavefront (lanes over columns)
+__device__ __forceinline__ void sk_row(const float* __restrict__ s, int N1, int i, const float* __restrict__ v, const float* __restrict__ log_mu,
+                                       float* __restrict__ u) {
+  const int lane = threadIdx.x & 63;
+  float mx = -INFINITY;
+  for (int j = lane; j < N1; j += 64) mx = fmaxf(mx, s[i * N1 + j] + v[j]);
 #pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) {
-        const float m2 = __shfl_xor(m, d), s2 = __shfl_xor(sum, d);
-        const float mm = fmaxf(m, m2);
-        sum = (m == -INFINITY ? 0.f : sum * expf(m - mm)) + (m2 == -INFINITY ? 0.f : s2 * expf(m2 - mm));
-        m = mm;
-      }
-      if (lane == 0) u[i] = log_mu[i] - (m + logf(sum));
+  for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+  float sum = 0.f;
+  for (int j = lane; j < N1; j += 64) sum += fast_exp(s[i * N1 + j] + v[j] - mx);
+  sum = wave_sum(sum);
+  if (lane == 0) u[i] = log_mu[i] - (mx + fast_log(sum));
+}
+
+// v[j] = log_nu[j] - LSE_i(s[i][j] + u[i]) for one column (one thread; rows coalesced across threads)
+__device__ __forceinline__ void sk_col(const float* __restrict__ s, int M1, int N1, int j, const float* __restrict__ u,
+                                       const float* __restrict__ log_nu, float* __restrict__ v) {
+  float mx = -INFINITY;
+  for (int i0 = 0; i0 < M1; i0 += 8) {
+    float x[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) x[q] = i0 + q < M1 ? s[(i0 + q) * N1 + j] + u[i0 + q] : -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mx = fmaxf(mx, x[q]);
+  }
+  float sum = 0.f;
+  for (int i0 = 0; i0 < M1; i0 += 8) {
+    float x[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) x[q] = i0 + q < M1 ? s[(i0 + q) * N1 + j] + u[i0 + q] : -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sum += fast_exp(x[q] - mx);
+  }
+  v[j] = log_nu[j] - (mx + fast_log(sum));
+}
+
+// (a) whole problem in one workgroup, matrix AND dual vectors resident in LDS (patch level: 129 x 129 floats = 66.5 KB; from L2
+//     every one of the 200 passes would be a chain of dependent ~1 us loads).  Four threads share a row (column): each takes
+//     every 4th element, partials are folded with two quad shuffles.
+__device__ __forceinline__ float quad_max(float x) {
+  x = fmaxf(x, __shfl_xor(x, 1));
+  return fmaxf(x, __shfl_xor(x, 2));
+}
+__device__ __forceinline__ float quad_sum(float x) {
+  x += __shfl_xor(x, 1);
+  return x + __shfl_xor(x, 2);
+}
+
+__global__ __launch_bounds__(SK_T) void k_log_sinkhorn_lds(float* __restrict__ S, const uint8_t* __restrict__ row_mask,
+                                                           const uint8_t* __restrict__ col_mask, int M, int N, int iters, float inf_val,
+                                                           float* __restrict__ uv_ws) {
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  __shared__ float s_norm;
+  const int64_t b = blockIdx.x;
+  const int M1 = M + 1, N1 = N + 1;
+  float* s_mat = s_dyn;
+  float* u = s_dyn + M1 * N1;
+  float* v = u + M1;
+  float* log_mu = v + N1;
+  float* log_nu = log_mu + M1;
+  float* sg = S + b * M1 * N1;
+  for (int t = threadIdx.x; t < M1 * N1; t += SK_T) s_mat[t] = sg[t];
+  sk_setup(row_mask, col_mask, b, M, N, inf_val, u, v, log_mu, log_nu, &s_norm);
+  const int part = threadIdx.x & 3, line0 = threadIdx.x >> 2;
+  for (int it = 0; it < iters; ++it) {
+    for (int i = line0; i < ((M1 + 15) & ~15); i += SK_T / 4) {     // padded so that whole quads stay converged for the shuffles
+      const bool live = i < M1;
+      const float* row = s_mat + (live ? i : 0) * N1;
+      float mx = -INFINITY;
+      for (int j = part; j < N1; j += 4) mx = fmaxf(mx, row[j] + v[j]);
+      mx = quad_max(mx);
+      float sum = 0.f;
+      for (int j = part; j < N1; j += 4) sum += fast_exp(row[j] + v[j] - mx);
+      sum = quad_sum(sum);
+      if (live && part == 0) u[i] = log_mu[i] - (mx + fast_log(sum));
     }
     __syncthreads();
-    // v = log_nu - logsumexp_i(S + u): one thread per column, rows coalesced across the threads
-    for (int j = threadIdx.x; j < N1; j += SK_T) {
-      float m = -INFINITY, sum = 0.f;
-      for (int i = 0; i < M1; ++i) online_lse(s[i * N1 + j] + u[i], m, sum);
-      v[j] = log_nu[j] - (m + logf(sum));
+    for (int j = line0; j < ((N1 + 15) & ~15); j += SK_T / 4) {
+      const bool live = j < N1;
+      const float* colp = s_mat + (live ? j : 0);
+      float mx = -INFINITY;
+      for (int i = part; i < M1; i += 4) mx = fmaxf(mx, colp[i * N1] + u[i]);
+      mx = quad_max(mx);
+      float sum = 0.f;
+      for (int i = part; i < M1; i += 4) sum += fast_exp(colp[i * N1] + u[i] - mx);
+      sum = quad_sum(sum);
+      if (live && part == 0) v[j] = log_nu[j] - (mx + fast_log(sum));
     }
     __syncthreads();
   }
   for (int t = threadIdx.x; t < M1 * N1; t += SK_T) {
     const int i = t / N1, j = t - i * N1;
-    s[t] = s[t] + u[i] + v[j] - s_norm;
+    sg[t] = s_mat[t] + u[i] + v[j] - s_norm;
+  }
+}
+
+// (b) matrices that do not fit LDS (node level, ~350 x 330): one launch per half-iteration so that every row / column gets its
+//     own wavefront / thread across the whole chip instead of one CU grinding through 200 passes
+__global__ __launch_bounds__(SK_T) void k_sk_init(const uint8_t* __restrict__ row_mask, const uint8_t* __restrict__ col_mask, int M, int N,
+                                                  float inf_val, float* __restrict__ uv_ws, float* __restrict__ norm_ws) {
+  const int64_t b = blockIdx.x;
+  const int M1 = M + 1, N1 = N + 1;
+  float* u = uv_ws + b * (M1 + N1) * 2;
+  float* v = u + M1;
+  __shared__ float s_norm;
+  sk_setup(row_mask, col_mask, b, M, N, inf_val, u, v, v + N1, v + N1 + M1, &s_norm);
+  if (threadIdx.x == 0) norm_ws[b] = s_norm;
+}
+__global__ __launch_bounds__(256) void k_sk_rows(const float* __restrict__ S, int M, int N, float* __restrict__ uv_ws) {
+  const int64_t b = blockIdx.y;
+  const int M1 = M + 1, N1 = N + 1;
+  float* u = uv_ws + b * (M1 + N1) * 2;
+  const float* v = u + M1;
+  const float* log_mu = v + N1;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i < M1) sk_row(S + b * M1 * N1, N1, i, v, log_mu, u);
+}
+// 64 columns per workgroup, 16 row-slices x 64 columns = 1024 threads: loads are coalesced along the columns and only
+// ceil(M1/16) deep per thread; slices are folded through LDS
+__global__ __launch_bounds__(1024) void k_sk_cols(const float* __restrict__ S, int M, int N, float* __restrict__ uv_ws) {
+  __shared__ float s_part[16][64];
+  const int64_t b = blockIdx.y;
+  const int M1 = M + 1, N1 = N + 1;
+  float* u = uv_ws + b * (M1 + N1) * 2;
+  float* v = u + M1;
+  const float* log_nu = v + N1 + M1;
+  const float* s = S + b * M1 * N1;
+  const int c = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
+  const bool live = j < N1;
+  float x[24];
+  int cnt = 0;
+  float mx = -INFINITY;
+  for (int i = slice; i < M1 && cnt < 24; i += 16, ++cnt) {
+    x[cnt] = live ? s[i * N1 + j] + u[i] : -INFINITY;
+    mx = fmaxf(mx, x[cnt]);
+  }
+  for (int i = slice + 16 * 24; i < M1; i += 16) mx = fmaxf(mx, live ? s[i * N1 + j] + u[i] : -INFINITY);   // very tall matrices
+  s_part[slice][c] = mx;
+  __syncthreads();
+  float m = s_part[0][c];
+#pragma unroll
+  for (int q = 1; q < 16; ++q) m = fmaxf(m, s_part[q][c]);
+  __syncthreads();
+  float sum = 0.f;
+  for (int q = 0; q < cnt; ++q) sum += fast_exp(x[q] - m);
+  for (int i = slice + 16 * 24; i < M1; i += 16) sum += live ? fast_exp(s[i * N1 + j] + u[i] - m) : 0.f;
+  s_part[slice][c] = sum;
+  __syncthreads();
+  if (slice == 0 && live) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += s_part[q][c];
+    v[j] = log_nu[j] - (m + fast_log(t));
+  }
+}
+__global__ __launch_bounds__(256) void k_sk_final(float* __restrict__ S, int M, int N, const float* __restrict__ uv_ws, const float* __restrict__ norm_ws) {
+  const int64_t b = blockIdx.y;
+  const int M1 = M + 1, N1 = N + 1;
+  const float* u = uv_ws + b * (M1 + N1) * 2;
+  const float* v = u + M1;
+  float* s = S + b * M1 * N1;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < M1 * N1; t += gridDim.x * blockDim.x) {
+    const int i = t / N1, j = t - i * N1;
+    s[t] = s[t] + u[i] + v[j] - norm_ws[b];
   }
 }
 
@@ -605,11 +740,18 @@ extern "C" int lcr_vote_shift(const float* xyz, const float* offsets, int64_t N,
   return check_launch("lcr_vote_shift");
 }
 
+extern "C" int lcr_greedy_nms_ws_bytes(int64_t n_total, size_t* bytes) {
+  if (!bytes || n_total < 0) return LCR_EARG;
+  *bytes = align_up(static_cast<size_t>(n_total) + 16) + sizeof(int32_t) * static_cast<size_t>(n_total + 1) * (NMS_NB + 1);
+  return LCR_OK;
+}
+
 extern "C" int lcr_greedy_nms(const float* pts, const int64_t* len, int B, int64_t n_total, float radius, uint8_t* keep, int64_t* out_len,
-                              void* ws /* n_total bytes */, void* stream) {
+                              void* ws, void* stream) {
   if (!pts || !len || !keep || !out_len || !ws || B < 1) return LCR_EARG;
-  (void)n_total;
-  hipLaunchKernelGGL(k_greedy_nms, dim3(B), dim3(NMS_T), 0, ST(stream), pts, len, B, radius, keep, out_len, static_cast<int8_t*>(ws));
+  int8_t* st = static_cast<int8_t*>(ws);
+  int32_t* nbr = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + align_up(static_cast<size_t>(n_total) + 16));
+  hipLaunchKernelGGL(k_greedy_nms, dim3(B), dim3(NMS_T), 0, ST(stream), pts, len, B, radius, keep, out_len, st, nbr);
   return check_launch("lcr_greedy_nms");
 }
 
@@ -671,11 +813,31 @@ extern "C" int lcr_build_padded_scores(const float* raw, const uint8_t* row_mask
   return check_launch("lcr_build_padded_scores");
 }
 
-// in place on S [B, M+1, N+1]; uv_ws: B * 2 * (M + N + 2) floats
+// in place on S [B, M+1, N+1]; uv_ws: B * (2 * (M + N + 2) + 1) floats
 extern "C" int lcr_log_sinkhorn(float* S, const uint8_t* row_mask, const uint8_t* col_mask, int64_t B, int M, int N, int iters, float inf_val,
                                 float* uv_ws, void* stream) {
   if (!S || !row_mask || !col_mask || !uv_ws || B < 1 || M < 1 || N < 1 || iters < 0) return LCR_EARG;
-  hipLaunchKernelGGL(k_log_sinkhorn, dim3(static_cast<int>(B)), dim3(SK_T), 0, ST(stream), S, row_mask, col_mask, M, N, iters, inf_val, uv_ws);
+  const size_t mat_bytes = sizeof(float) * (static_cast<size_t>(M + 1) * (N + 1) + 2 * (M + N + 2));   // matrix + u, v, log_mu, log_nu
+  if (mat_bytes <= 150 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {   // > 64 KB of dynamic LDS needs an explicit opt-in
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_log_sinkhorn_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(k_log_sinkhorn_lds, dim3(static_cast<int>(B)), dim3(SK_T), mat_bytes, ST(stream), S, row_mask, col_mask, M, N, iters, inf_val,
+                       uv_ws);
+  } else {
+    if (B > 65535) return LCR_EARG;
+    // the last B floats of uv_ws's per-problem blocks are not spare, so norms live after all of them (caller sizes uv_ws with +B)
+    float* norm_ws = uv_ws + B * 2 * (static_cast<int64_t>(M) + N + 2);
+    hipLaunchKernelGGL(k_sk_init, dim3(static_cast<int>(B)), dim3(SK_T), 0, ST(stream), row_mask, col_mask, M, N, inf_val, uv_ws, norm_ws);
+    const dim3 grow((M + 1 + 3) / 4, static_cast<int>(B)), gcol((N + 1 + 63) / 64, static_cast<int>(B));
+    for (int it = 0; it < iters; ++it) {
+      hipLaunchKernelGGL(k_sk_rows, grow, dim3(256), 0, ST(stream), S, M, N, uv_ws);
+      hipLaunchKernelGGL(k_sk_cols, gcol, dim3(1024), 0, ST(stream), S, M, N, uv_ws);
+    }
+    hipLaunchKernelGGL(k_sk_final, dim3(64, static_cast<int>(B)), dim3(256), 0, ST(stream), S, M, N, uv_ws, norm_ws);
+  }
   return check_launch("lcr_log_sinkhorn");
 }
 

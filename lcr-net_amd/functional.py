@@ -235,7 +235,9 @@ def greedy_nms(points, lengths, radius):
     n, B = points.shape[0], lengths.numel()
     keep = torch.empty((n,), dtype=torch.uint8, device=points.device)
     out_len = torch.empty((B,), dtype=torch.int64, device=points.device)
-    ws = _lib.workspace(n, points.device)
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(_L().lcr_greedy_nms_ws_bytes(n, ctypes.byref(nbytes)), "lcr_greedy_nms_ws_bytes")
+    ws = _lib.workspace(nbytes.value, points.device)
     _lib.check(_L().lcr_greedy_nms(_lib.ptr(points.contiguous()), _lib.ptr(lengths), B, n, float(radius), _lib.ptr(keep), _lib.ptr(out_len),
                                    _lib.ptr(ws), _sp(points)), "lcr_greedy_nms")
     return keep, out_len
@@ -274,7 +276,7 @@ def log_optimal_transport(raw_scores, row_masks, col_masks, alpha, scale=1.0, it
     S = torch.empty((B, M + 1, N + 1), dtype=torch.float32, device=dev)
     _lib.check(_L().lcr_build_padded_scores(_lib.ptr(raw_scores.contiguous()), _lib.ptr(rm), _lib.ptr(cm), B, M, N, float(scale),
                                             _lib.ptr(alpha.reshape(1).float()), float(inf), _lib.ptr(S), _sp(S)), "lcr_build_padded_scores")
-    uv = torch.empty((B * 2 * (M + N + 2),), dtype=torch.float32, device=dev)
+    uv = torch.empty((B * (2 * (M + N + 2) + 1),), dtype=torch.float32, device=dev)
     _lib.check(_L().lcr_log_sinkhorn(_lib.ptr(S), _lib.ptr(rm), _lib.ptr(cm), B, M, N, int(iters), float(inf), _lib.ptr(uv), _sp(S)),
                "lcr_log_sinkhorn")
     return S
