@@ -77,6 +77,8 @@ int lcr_support_grid_build(const float* s, const int64_t* slen, int B, int64_t n
 int lcr_radius_query(const float* q, const int64_t* qlen, int B, int64_t nq_cap,
                      const void* grid_ws, int64_t ns_cap /* as passed to the build */, float radius, int limit,
                      int64_t* out_idx64, int32_t* out_idx32, int32_t* out_cnt, void* stream);
+/* order[i] = stacked row of the i-th support in cell-sorted order (a spatially coherent processing order for gather kernels). */
+int lcr_support_grid_order(const void* grid_ws, int64_t ns_cap, int B, int32_t* order, void* stream);
 int lcr_radius_search_ws_bytes(int64_t nq_cap, int64_t ns_cap, int B, size_t* bytes);
 int lcr_radius_search(const float* q, const float* s, const int64_t* qlen, const int64_t* slen, int B,
                       int64_t nq_cap, int64_t ns_cap, float radius, int limit,
@@ -105,13 +107,15 @@ int lcr_gemm_f32_batched_ta(const float* A, const float* B, float* C, int64_t M,
  * (kpconv.py:113-116).  kernel_points_host: 15x3 floats in HOST memory.  C in {32,64,128,256}, H <= 128. */
 int lcr_kpconv_aggregate(const float* s_feats, const uint8_t* s_pos, const float* q_pts, const float* s_pts,
                          const void* idx, int idx_is_64, int64_t M, int64_t Ns, int H, int C,
-                         const float* kernel_points_host, float sigma, float* A, float* nn, void* stream);
+                         const float* kernel_points_host, float sigma, float* A, float* nn,
+                         const int32_t* order /* optional i32[M]: processing order, e.g. lcr_support_grid_order */, void* stream);
 /* Whole KPConv for C_in = 1 (encoder1_1, backbone4.py:15): out[M,Cout] incl. count normalisation and bias. W: [15,Cout]. */
 int lcr_kpconv_cin1(const float* s_feats, const float* q_pts, const float* s_pts, const void* idx, int idx_is_64,
                     int64_t M, int64_t Ns, int H, const float* kernel_points_host, float sigma, const float* W,
-                    const float* bias, int Cout, float* out, void* stream);
+                    const float* bias, int Cout, float* out, const int32_t* order, void* stream);
 /* maxpool over neighbours, zero shadow row (modules/kpconv/functional.py:54-67). */
-int lcr_maxpool(const float* x, const void* idx, int idx_is_64, int64_t M, int64_t Ns, int H, int C, float* out, void* stream);
+int lcr_maxpool(const float* x, const void* idx, int idx_is_64, int64_t M, int64_t Ns, int H, int C, float* out,
+                const int32_t* order, void* stream);
 /* pos[n] = (sum_c x[n][c] > 0) — the flag behind KPConv's neighbour count. */
 int lcr_row_positive(const float* x, int64_t N, int C, uint8_t* pos, void* stream);
 /* Segmented GroupNorm statistics (sum, sumsq per segment and group, fp64, [LCR_GN_REPLICAS,S,groups,2]) of x[N,C]. */

@@ -25,7 +25,8 @@ class KPEncoder(nn.Module):
         int64 GroupNorm segment lengths; absent => one segment = whole stack, the reference's semantics)."""
         P, N, S = data_dict["points"], data_dict["neighbors"], data_dict["subsampling"]
         seg = data_dict.get("segment_lengths")
-        ctx = [StageContext(None if seg is None else seg[i]) for i in range(4)]
+        order = data_dict.get("order")
+        ctx = [StageContext(None if seg is None else seg[i], None if order is None else order[i]) for i in range(4)]
         f1 = self.encoder1_1(feats, P[0], P[0], N[0], ctx[0], ctx[0])
         f1 = self.encoder1_2(f1, P[0], P[0], N[0], ctx[0], ctx[0])
         f2 = self.encoder2_1(f1, P[1], P[0], S[0], ctx[1], ctx[0])

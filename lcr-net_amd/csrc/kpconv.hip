@@ -13,6 +13,7 @@
 // Only the (M, 15*C) aggregate goes through HBM/Infinity-Cache between the two halves (fusing it away is the next step).
 // encoder1_1 (C_in = 1, backbone4.py:15) is fully fused in k_kpconv_cin1.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -53,8 +54,14 @@ __device__ __forceinline__ int gather_neighbours(const IdxT* __restrict__ row, i
         const float d2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
         l_w[slot * 16 + k] = fmaxf(1.f - __builtin_amdgcn_sqrtf(d2) * inv_sigma, 0.f);
       }
+      l_w[slot * 16 + 15] = 0.f;
     }
     n += __popcll(m);
+  }
+  // rows n .. round_up(n, 4) - 1 are read by the MFMA aggregation as zero-weight neighbours
+  if (lane < 48 && (n & 3)) {
+    const int slot = n + (lane >> 4);
+    if (slot < ((n + 3) & ~3)) l_w[slot * 16 + (lane & 15)] = 0.f;
   }
   return n;
 }
@@ -83,12 +90,14 @@ template <typename IdxT, int CPL, bool HALF>
 __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate(const float* __restrict__ s_feats, const uint8_t* __restrict__ s_pos,
                                                                     const float* __restrict__ q_pts, const float* __restrict__ s_pts,
                                                                     const IdxT* __restrict__ idx, int64_t M, int64_t Ns, int H, KPoints kp,
-                                                                    float sigma, float* __restrict__ A, float* __restrict__ nn) {
+                                                                    float sigma, float* __restrict__ A, float* __restrict__ nn,
+                                                                    const int32_t* __restrict__ order) {
   constexpr int C = HALF ? 32 : 64 * CPL;
-  __shared__ int32_t s_idx[KP_WAVES][KP_HMAX];
-  __shared__ __attribute__((aligned(16))) float s_w[KP_WAVES][KP_HMAX * 16];
+  __shared__ int32_t s_idx[KP_WAVES][KP_HMAX + 4];
+  __shared__ __attribute__((aligned(16))) float s_w[KP_WAVES][(KP_HMAX + 4) * 16];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int64_t m = static_cast<int64_t>(blockIdx.x) * KP_WAVES + w; m < M; m += static_cast<int64_t>(gridDim.x) * KP_WAVES) {
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * KP_WAVES + w; t < M; t += static_cast<int64_t>(gridDim.x) * KP_WAVES) {
+    const int64_t m = order ? order[t] : t;     // spatially coherent processing order (results land at their own row)
     const float q[3] = {q_pts[3 * m], q_pts[3 * m + 1], q_pts[3 * m + 2]};
     const int n = gather_neighbours(idx + m * H, H, Ns, s_pts, q, kp, sigma, s_idx[w], s_w[w]);
     wave_lds_sync();
@@ -167,15 +176,113 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate(const float*
   }
 }
 
+// MFMA variant of the aggregation (default): per query, D[16 kernel points x C channels] += W[16 x 4 neighbours] * F[4 x C] with
+// v_mfma_f32_16x16x4_f32 (exact fp32).  The influence matrix W is never stored: lane l evaluates the ONE entry it feeds to the
+// matrix core — neighbour h0 + (l>>4), kernel point l&15 — from the neighbour's relative position (16 B in LDS, broadcast to
+// its 16 lanes) and its own kernel point (3 registers).  That leaves ~2.6 KB of LDS per wavefront (index + relative position
+// per neighbour), so a CU holds its full 32 wavefronts: the kernel is bound by the latency of the row gathers, and occupancy
+// is what hides it.  B operand: lane l <- feature[idx[h0 + (l>>4)]][c0 + (l&15)] straight from global/L2 (64-B row segments).
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <typename IdxT, int C>
+__global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate_mfma(const float* __restrict__ s_feats, const uint8_t* __restrict__ s_pos,
+                                                                         const float* __restrict__ q_pts, const float* __restrict__ s_pts,
+                                                                         const IdxT* __restrict__ idx, int64_t M, int64_t Ns, int H, KPoints kp,
+                                                                         float sigma, float* __restrict__ A, float* __restrict__ nn,
+                                                                         const int32_t* __restrict__ order) {
+  constexpr int NTILE = C / 16;
+  __shared__ __attribute__((aligned(16))) float4 s_rel[KP_WAVES][KP_HMAX + 8];   // (dx, dy, dz, bits(index)) per valid neighbour
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int sub = lane >> 4, col = lane & 15;
+  const float inv_sigma = 1.f / sigma;
+  // this lane's kernel point (row `col` of the 16-row operand; row 15 is padding)
+  float kx = 0.f, ky = 0.f, kz = 0.f;
+#pragma unroll
+  for (int k = 0; k < KP_K; ++k)
+    if (col == k) {
+      kx = kp.p[k][0];
+      ky = kp.p[k][1];
+      kz = kp.p[k][2];
+    }
+  const bool real_k = col < KP_K;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * KP_WAVES + w; t < M; t += static_cast<int64_t>(gridDim.x) * KP_WAVES) {
+    const int64_t m = order ? order[t] : t;
+    const float qx = q_pts[3 * m], qy = q_pts[3 * m + 1], qz = q_pts[3 * m + 2];
+    // phase 1: lanes = neighbours; compact the valid ones (in order) with their relative positions; count the "positive" ones
+    int n = 0, cnt = 0;
+    for (int h0 = 0; h0 < H; h0 += 64) {
+      const int h = h0 + lane;
+      int64_t j = Ns;
+      if (h < H) j = static_cast<int64_t>(idx[m * H + h]);
+      const bool ok = j >= 0 && j < Ns;
+      const uint64_t mk = __ballot(ok);
+      if (ok) {
+        const int slot = n + __popcll(mk & lanemask_lt());
+        s_rel[w][slot] = make_float4(s_pts[3 * j] - qx, s_pts[3 * j + 1] - qy, s_pts[3 * j + 2] - qz, __uint_as_float(static_cast<uint32_t>(j)));
+        cnt += s_pos[j] ? 1 : 0;
+      }
+      n += __popcll(mk);
+    }
+    cnt = wave_sum(cnt);
+    wave_lds_sync();
+
+    floatx4 acc[NTILE];
+#pragma unroll
+    for (int tt = 0; tt < NTILE; ++tt) acc[tt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int n4 = (n + 3) & ~3;
+    for (int h0 = 0; h0 < n4; h0 += 8) {           // two 4-neighbour steps per iteration: 2 * NTILE gathers in flight per lane
+      const int ha = h0 + sub, hb = h0 + 4 + sub;
+      const bool second = h0 + 4 < n4;             // wave-uniform
+      const float4 pa = s_rel[w][ha < n ? ha : n - 1];
+      const float4 pb = s_rel[w][hb < n ? hb : n - 1];
+      const float* ra = s_feats + static_cast<int64_t>(__float_as_uint(pa.w)) * C + col;
+      const float* rb = s_feats + static_cast<int64_t>(__float_as_uint(pb.w)) * C + col;
+      float fa[NTILE], fb[NTILE];
+#pragma unroll
+      for (int tt = 0; tt < NTILE; ++tt) {
+        fa[tt] = ra[tt * 16];
+        fb[tt] = rb[tt * 16];
+      }
+      // influence of neighbour ha / hb on this lane's kernel point (kpconv.py:96-99), zero for padding rows / neighbours
+      float ex = pa.x - kx, ey = pa.y - ky, ez = pa.z - kz;
+      float wa = fmaxf(1.f - __builtin_amdgcn_sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * inv_sigma, 0.f);
+      wa = (real_k && ha < n) ? wa : 0.f;
+      ex = pb.x - kx, ey = pb.y - ky, ez = pb.z - kz;
+      float wb = fmaxf(1.f - __builtin_amdgcn_sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * inv_sigma, 0.f);
+      wb = (real_k && hb < n) ? wb : 0.f;
+#pragma unroll
+      for (int tt = 0; tt < NTILE; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, fa[tt], acc[tt], 0, 0, 0);
+      if (second) {
+#pragma unroll
+        for (int tt = 0; tt < NTILE; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb, fb[tt], acc[tt], 0, 0, 0);
+      }
+    }
+    // D[row = kernel point 4*sub + r][col]: rows of 16 consecutive channels -> 64-B segments of the (15*C) output row
+    float* out = A + m * (KP_K * C);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 4 * sub + r;
+      if (k < KP_K) {
+#pragma unroll
+        for (int tt = 0; tt < NTILE; ++tt) out[k * C + tt * 16 + col] = acc[tt][r];
+      }
+    }
+    if (lane == 0) nn[m] = static_cast<float>(cnt > 1 ? cnt : 1);
+    wave_lds_sync();
+  }
+}
+
 // encoder1_1: scalar input feature per point; out[m][o] = (sum_k (sum_h w[k][h] f[h]) W[k][o]) / count + bias[o]
 template <typename IdxT>
 __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_cin1(const float* __restrict__ s_feats, const float* __restrict__ q_pts,
                                                                const float* __restrict__ s_pts, const IdxT* __restrict__ idx, int64_t M,
                                                                int64_t Ns, int H, KPoints kp, float sigma, const float* __restrict__ W,
-                                                               const float* __restrict__ bias, int Cout, float* __restrict__ out) {
+                                                               const float* __restrict__ bias, int Cout, float* __restrict__ out,
+                                                               const int32_t* __restrict__ order) {
   __shared__ float s_a[KP_WAVES][16];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int64_t m = static_cast<int64_t>(blockIdx.x) * KP_WAVES + w; m < M; m += static_cast<int64_t>(gridDim.x) * KP_WAVES) {
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * KP_WAVES + w; t < M; t += static_cast<int64_t>(gridDim.x) * KP_WAVES) {
+    const int64_t m = order ? order[t] : t;
     const float qx = q_pts[3 * m], qy = q_pts[3 * m + 1], qz = q_pts[3 * m + 2];
     const float inv_sigma = 1.f / sigma;
     float a[KP_K];
@@ -218,10 +325,11 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_cin1(const float* __re
 // maxpool over neighbours with a zero shadow row (kpconv/functional.py:54-67)
 template <typename IdxT>
 __global__ __launch_bounds__(256) void k_maxpool(const float* __restrict__ x, const IdxT* __restrict__ idx, int64_t M, int64_t Ns, int H, int C,
-                                                 float* __restrict__ out) {
+                                                 float* __restrict__ out, const int32_t* __restrict__ order) {
   __shared__ int32_t s_idx[4][KP_HMAX];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int64_t m = static_cast<int64_t>(blockIdx.x) * 4 + w; m < M; m += static_cast<int64_t>(gridDim.x) * 4) {
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * 4 + w; t < M; t += static_cast<int64_t>(gridDim.x) * 4) {
+    const int64_t m = order ? order[t] : t;
     int n = 0;
     bool any_shadow = false;
     for (int h0 = 0; h0 < H; h0 += 64) {
@@ -272,13 +380,24 @@ static int grid_for(int64_t rows, int per_block) { return static_cast<int>(std::
 
 template <typename IdxT>
 static int launch_aggregate(const float* s_feats, const uint8_t* s_pos, const float* q_pts, const float* s_pts, const IdxT* idx, int64_t M,
-                            int64_t Ns, int H, int C, const KPoints& kp, float sigma, float* A, float* nn, hipStream_t st) {
+                            int64_t Ns, int H, int C, const KPoints& kp, float sigma, float* A, float* nn, const int32_t* order, hipStream_t st) {
   dim3 grid(grid_for(M, KP_WAVES)), block(KP_WAVES * 64);
+  static const bool use_valu = getenv("LCR_KPCONV_VALU") != nullptr;   // A/B switch for profiling; the MFMA path is the default
+  if (!use_valu) {
+    switch (C) {
+      case 32: hipLaunchKernelGGL((k_kpconv_aggregate_mfma<IdxT, 32>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
+      case 64: hipLaunchKernelGGL((k_kpconv_aggregate_mfma<IdxT, 64>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
+      case 128: hipLaunchKernelGGL((k_kpconv_aggregate_mfma<IdxT, 128>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
+      case 256: hipLaunchKernelGGL((k_kpconv_aggregate_mfma<IdxT, 256>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
+      default: set_error("lcr_kpconv_aggregate: C must be 32, 64, 128 or 256 (got %d)", C); return LCR_EARG;
+    }
+    return check_launch("lcr_kpconv_aggregate");
+  }
   switch (C) {
-    case 32: hipLaunchKernelGGL((k_kpconv_aggregate<IdxT, 1, true>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn); break;
-    case 64: hipLaunchKernelGGL((k_kpconv_aggregate<IdxT, 1, false>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn); break;
-    case 128: hipLaunchKernelGGL((k_kpconv_aggregate<IdxT, 2, false>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn); break;
-    case 256: hipLaunchKernelGGL((k_kpconv_aggregate<IdxT, 4, false>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn); break;
+    case 32: hipLaunchKernelGGL((k_kpconv_aggregate<IdxT, 1, true>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
+    case 64: hipLaunchKernelGGL((k_kpconv_aggregate<IdxT, 1, false>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
+    case 128: hipLaunchKernelGGL((k_kpconv_aggregate<IdxT, 2, false>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
+    case 256: hipLaunchKernelGGL((k_kpconv_aggregate<IdxT, 4, false>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
     default: set_error("lcr_kpconv_aggregate: C must be 32, 64, 128 or 256 (got %d)", C); return LCR_EARG;
   }
   return check_launch("lcr_kpconv_aggregate");
@@ -290,7 +409,7 @@ using namespace lcr;
 
 extern "C" int lcr_kpconv_aggregate(const float* s_feats, const uint8_t* s_pos, const float* q_pts, const float* s_pts, const void* idx,
                                     int idx_is_64, int64_t M, int64_t Ns, int H, int C, const float* kernel_points_host, float sigma,
-                                    float* A, float* nn, void* stream) {
+                                    float* A, float* nn, const int32_t* order, void* stream) {
   if (!s_feats || !s_pos || !q_pts || !s_pts || !idx || !kernel_points_host || !A || !nn || M < 0 || Ns < 0 || H < 1 || H > KP_HMAX ||
       !(sigma > 0.f)) {
     set_error("lcr_kpconv_aggregate: bad argument (H must be in [1,%d])", KP_HMAX);
@@ -299,13 +418,13 @@ extern "C" int lcr_kpconv_aggregate(const float* s_feats, const uint8_t* s_pos, 
   if (M == 0) return LCR_OK;
   const KPoints kp = load_kp(kernel_points_host);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  return idx_is_64 ? launch_aggregate(s_feats, s_pos, q_pts, s_pts, static_cast<const int64_t*>(idx), M, Ns, H, C, kp, sigma, A, nn, st)
-                   : launch_aggregate(s_feats, s_pos, q_pts, s_pts, static_cast<const int32_t*>(idx), M, Ns, H, C, kp, sigma, A, nn, st);
+  return idx_is_64 ? launch_aggregate(s_feats, s_pos, q_pts, s_pts, static_cast<const int64_t*>(idx), M, Ns, H, C, kp, sigma, A, nn, order, st)
+                   : launch_aggregate(s_feats, s_pos, q_pts, s_pts, static_cast<const int32_t*>(idx), M, Ns, H, C, kp, sigma, A, nn, order, st);
 }
 
 extern "C" int lcr_kpconv_cin1(const float* s_feats, const float* q_pts, const float* s_pts, const void* idx, int idx_is_64, int64_t M,
                                int64_t Ns, int H, const float* kernel_points_host, float sigma, const float* W, const float* bias, int Cout,
-                               float* out, void* stream) {
+                               float* out, const int32_t* order, void* stream) {
   if (!s_feats || !q_pts || !s_pts || !idx || !kernel_points_host || !W || !out || M < 0 || H < 1 || Cout < 1 || !(sigma > 0.f)) {
     set_error("lcr_kpconv_cin1: bad argument");
     return LCR_EARG;
@@ -315,13 +434,14 @@ extern "C" int lcr_kpconv_cin1(const float* s_feats, const float* q_pts, const f
   hipStream_t st = static_cast<hipStream_t>(stream);
   dim3 grid(grid_for(M, KP_WAVES)), block(KP_WAVES * 64);
   if (idx_is_64)
-    hipLaunchKernelGGL((k_kpconv_cin1<int64_t>), grid, block, 0, st, s_feats, q_pts, s_pts, static_cast<const int64_t*>(idx), M, Ns, H, kp, sigma, W, bias, Cout, out);
+    hipLaunchKernelGGL((k_kpconv_cin1<int64_t>), grid, block, 0, st, s_feats, q_pts, s_pts, static_cast<const int64_t*>(idx), M, Ns, H, kp, sigma, W, bias, Cout, out, order);
   else
-    hipLaunchKernelGGL((k_kpconv_cin1<int32_t>), grid, block, 0, st, s_feats, q_pts, s_pts, static_cast<const int32_t*>(idx), M, Ns, H, kp, sigma, W, bias, Cout, out);
+    hipLaunchKernelGGL((k_kpconv_cin1<int32_t>), grid, block, 0, st, s_feats, q_pts, s_pts, static_cast<const int32_t*>(idx), M, Ns, H, kp, sigma, W, bias, Cout, out, order);
   return check_launch("lcr_kpconv_cin1");
 }
 
-extern "C" int lcr_maxpool(const float* x, const void* idx, int idx_is_64, int64_t M, int64_t Ns, int H, int C, float* out, void* stream) {
+extern "C" int lcr_maxpool(const float* x, const void* idx, int idx_is_64, int64_t M, int64_t Ns, int H, int C, float* out,
+                           const int32_t* order, void* stream) {
   if (!x || !idx || !out || M < 0 || H < 1 || H > KP_HMAX || C < 1) {
     set_error("lcr_maxpool: bad argument");
     return LCR_EARG;
@@ -329,8 +449,8 @@ extern "C" int lcr_maxpool(const float* x, const void* idx, int idx_is_64, int64
   if (M == 0) return LCR_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
   dim3 grid(grid_for(M, 4)), block(256);
-  if (idx_is_64) hipLaunchKernelGGL((k_maxpool<int64_t>), grid, block, 0, st, x, static_cast<const int64_t*>(idx), M, Ns, H, C, out);
-  else hipLaunchKernelGGL((k_maxpool<int32_t>), grid, block, 0, st, x, static_cast<const int32_t*>(idx), M, Ns, H, C, out);
+  if (idx_is_64) hipLaunchKernelGGL((k_maxpool<int64_t>), grid, block, 0, st, x, static_cast<const int64_t*>(idx), M, Ns, H, C, out, order);
+  else hipLaunchKernelGGL((k_maxpool<int32_t>), grid, block, 0, st, x, static_cast<const int32_t*>(idx), M, Ns, H, C, out, order);
   return check_launch("lcr_maxpool");
 }
 

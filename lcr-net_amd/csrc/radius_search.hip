@@ -392,6 +392,22 @@ extern "C" int lcr_radius_query(const float* q, const int64_t* qlen, int B, int6
   return check_launch("lcr_radius_query");
 }
 
+// order[i] = stacked row index of the i-th support in cell-sorted order: a spatially coherent processing order for any kernel
+// that gathers neighbourhoods (consecutive entries share most of their neighbours, so gathered rows are re-used from L2).
+__global__ __launch_bounds__(256) void k_grid_order(const GridHeader* __restrict__ h, const float4* __restrict__ sorted, int32_t* __restrict__ order) {
+  const int64_t n = h->ns_total < h->ns_cap ? h->ns_total : h->ns_cap;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    order[i] = static_cast<int32_t>(__float_as_uint(sorted[i].w));
+}
+
+extern "C" int lcr_support_grid_order(const void* grid_ws, int64_t ns_cap, int B, int32_t* order, void* stream) {
+  if (!grid_ws || !order || ns_cap < 0 || B < 1 || B > GRID_MAX_B) return LCR_EARG;
+  if (ns_cap == 0) return LCR_OK;
+  GridLayout L = grid_layout(const_cast<void*>(grid_ws), ns_cap, B);
+  hipLaunchKernelGGL(k_grid_order, dim3(min(div_up(ns_cap, 256), 2048)), dim3(256), 0, static_cast<hipStream_t>(stream), L.hdr, L.sorted, order);
+  return check_launch("lcr_support_grid_order");
+}
+
 extern "C" int lcr_radius_search_ws_bytes(int64_t nq_cap, int64_t ns_cap, int B, size_t* bytes) {
   (void)nq_cap;
   return lcr_support_grid_ws_bytes(ns_cap, B, bytes);

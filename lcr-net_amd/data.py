@@ -61,6 +61,7 @@ def precompute_batch(points, lengths, num_stages, voxel_size, radius, neighbor_l
     for i in range(num_stages):
         grids.append(SupportGrid(pts[i], lens[i], r))
         r *= 2
+    orders = [g.order() for g in grids]          # spatially coherent processing order of every stage's points
     neighbors, subsampling, upsamp = [], [], []
     for i in range(num_stages):
         neighbors.append(grids[i].query(pts[i], lens[i], neighbor_limits[i], dtype=index_dtype))
@@ -80,7 +81,8 @@ def precompute_batch(points, lengths, num_stages, voxel_size, radius, neighbor_l
     neighbors = [neighbors[i][:tot[i]] for i in range(num_stages)]
     subsampling = [subsampling[i][:tot[i + 1]] for i in range(num_stages - 1)]
     upsamp = [upsamp[i][:tot[i]] for i in range(len(upsamp))]
-    return {"points": pts, "lengths": lens, "neighbors": neighbors, "subsampling": subsampling, "upsampling": upsamp,
+    orders = [orders[i][:tot[i]] for i in range(num_stages)]
+    return {"order": orders, "points": pts, "lengths": lens, "neighbors": neighbors, "subsampling": subsampling, "upsampling": upsamp,
             "lengths_host": lengths_host, "segment_lengths": lens}
 
 

@@ -119,7 +119,7 @@ def _kp_host(kernel_points):
     return kp
 
 
-def kpconv_aggregate(s_feats, s_pos, q_points, s_points, idx, kernel_points_host, sigma):
+def kpconv_aggregate(s_feats, s_pos, q_points, s_points, idx, kernel_points_host, sigma, order=None):
     """(A [M, 15*C], nn [M]) — the gather/influence/aggregate half of KPConv.forward."""
     _lib.require_cuda(s_feats, q_points, s_points, idx)
     M, H = idx.shape
@@ -130,12 +130,12 @@ def kpconv_aggregate(s_feats, s_pos, q_points, s_points, idx, kernel_points_host
     kp = _kp_host(kernel_points_host)
     _timed("kpconv_aggregate", lambda: _lib.check(_lib.lib().lcr_kpconv_aggregate(
         _lib.ptr(s_feats), _lib.ptr(s_pos), _lib.ptr(q_points), _lib.ptr(s_points), _lib.ptr(idx), _idx_args(idx), M, Ns, H, C,
-        ctypes.c_void_p(kp.ctypes.data), float(sigma), _lib.ptr(A), _lib.ptr(nn), _lib.stream_ptr(s_feats.device)),
+        ctypes.c_void_p(kp.ctypes.data), float(sigma), _lib.ptr(A), _lib.ptr(nn), _lib.ptr(order), _lib.stream_ptr(s_feats.device)),
         "lcr_kpconv_aggregate"), meta=(M, Ns, H, C, idx.element_size()))
     return A, nn
 
 
-def kpconv_cin1(s_feats, q_points, s_points, idx, kernel_points_host, sigma, weights, bias):
+def kpconv_cin1(s_feats, q_points, s_points, idx, kernel_points_host, sigma, weights, bias, order=None):
     """Whole KPConv for one input channel: weights (15,1,Cout) -> out [M,Cout]."""
     M, H = idx.shape
     Ns = s_feats.shape[0]
@@ -144,15 +144,15 @@ def kpconv_cin1(s_feats, q_points, s_points, idx, kernel_points_host, sigma, wei
     kp = _kp_host(kernel_points_host)
     _lib.check(_lib.lib().lcr_kpconv_cin1(_lib.ptr(s_feats), _lib.ptr(q_points), _lib.ptr(s_points), _lib.ptr(idx), _idx_args(idx), M, Ns, H,
                                           ctypes.c_void_p(kp.ctypes.data), float(sigma), _lib.ptr(weights), _lib.ptr(bias), Cout,
-                                          _lib.ptr(out), _lib.stream_ptr(s_feats.device)), "lcr_kpconv_cin1")
+                                          _lib.ptr(out), _lib.ptr(order), _lib.stream_ptr(s_feats.device)), "lcr_kpconv_cin1")
     return out
 
 
-def maxpool(x, idx):
+def maxpool(x, idx, order=None):
     M, H = idx.shape
     out = torch.empty((M, x.shape[1]), dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().lcr_maxpool(_lib.ptr(x), _lib.ptr(idx), _idx_args(idx), M, x.shape[0], H, x.shape[1], _lib.ptr(out),
-                                      _lib.stream_ptr(x.device)), "lcr_maxpool")
+                                      _lib.ptr(order), _lib.stream_ptr(x.device)), "lcr_maxpool")
     return out
 
 

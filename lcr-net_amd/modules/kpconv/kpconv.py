@@ -40,17 +40,17 @@ class KPConv(nn.Module):
             self._kp_cache = (key, kp.detach().cpu().numpy().copy())   # one D2H per weight load, not per forward
         return self._kp_cache[1]
 
-    def forward_raw(self, s_feats, q_points, s_points, neighbor_indices, s_pos=None, seg_len=None, groups=0):
+    def forward_raw(self, s_feats, q_points, s_points, neighbor_indices, s_pos=None, seg_len=None, groups=0, order=None):
         """Returns (q_feats (M,Cout), stats) — stats = GroupNorm sums of the output when groups > 0."""
         kp = self.kernel_points_host()
         if self.in_channels == 1:
             out = F.kpconv_cin1(s_feats.contiguous().view(-1), q_points, s_points, neighbor_indices, kp, self.sigma,
-                                self.weights, self.bias)
+                                self.weights, self.bias, order=order)
             stats = F.groupnorm_stats(out, groups, seg_len) if groups else None
             return out, stats
         if s_pos is None:
             s_pos = F.row_positive(s_feats)
-        A, nn_cnt = F.kpconv_aggregate(s_feats, s_pos, q_points, s_points, neighbor_indices, kp, self.sigma)
+        A, nn_cnt = F.kpconv_aggregate(s_feats, s_pos, q_points, s_points, neighbor_indices, kp, self.sigma, order=order)
         W = self.weights.view(self.kernel_size * self.in_channels, self.out_channels)
         return F.gemm(A, W, bias=self.bias, rowdiv=nn_cnt, seg_len=seg_len, groups=groups)
 

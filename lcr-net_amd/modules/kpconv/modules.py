@@ -17,10 +17,12 @@ from .kpconv import KPConv
 
 
 class StageContext:
-    """Per-stage execution context: GroupNorm segment lengths (device int64 [S]) or None."""
+    """Per-stage execution context: GroupNorm segment lengths (device int64 [S]) or None, and an optional spatially coherent
+    processing order of the stage's points (device int32 [N]; data.precompute_batch provides the support grid's cell order)."""
 
-    def __init__(self, seg_len=None):
+    def __init__(self, seg_len=None, order=None):
         self.seg_len = seg_len
+        self.order = order
 
 
 _WHOLE = StageContext(None)
@@ -76,7 +78,8 @@ class ConvBlock(nn.Module):
         self.negative_slope = negative_slope
 
     def forward(self, s_feats, q_points, s_points, neighbor_indices, q_ctx=_WHOLE, s_ctx=_WHOLE):
-        x, stats = self.KPConv.forward_raw(s_feats, q_points, s_points, neighbor_indices, seg_len=q_ctx.seg_len, groups=self.group_norm)
+        x, stats = self.KPConv.forward_raw(s_feats, q_points, s_points, neighbor_indices, seg_len=q_ctx.seg_len, groups=self.group_norm,
+                                           order=q_ctx.order)
         return F.groupnorm_apply(x, stats, self.norm.norm.weight, self.norm.norm.bias, self.group_norm, q_ctx.seg_len,
                                  act=True, slope=self.negative_slope)
 
@@ -102,10 +105,11 @@ class ResidualBlock(nn.Module):
             x, pos = s_feats, None
         else:
             x, pos = self.unary1(s_feats, s_ctx, want_pos=True)                       # Linear+GN+LeakyReLU, pos flags for the count
-        x, stats = self.KPConv.forward_raw(x, q_points, s_points, neighbor_indices, s_pos=pos, seg_len=q_ctx.seg_len, groups=g)
+        x, stats = self.KPConv.forward_raw(x, q_points, s_points, neighbor_indices, s_pos=pos, seg_len=q_ctx.seg_len, groups=g,
+                                           order=q_ctx.order)
         x = F.groupnorm_apply(x, stats, self.norm_conv.norm.weight, self.norm_conv.norm.bias, g, q_ctx.seg_len, act=True)
         y, ystats = self.unary2.raw(x, q_ctx)                                          # normalised below, fused with the shortcut
-        shortcut = F.maxpool(s_feats, neighbor_indices) if self.strided else s_feats
+        shortcut = F.maxpool(s_feats, neighbor_indices, order=q_ctx.order) if self.strided else s_feats
         if isinstance(self.unary_shortcut, nn.Identity):
             res, res_norm = shortcut, None
         else:

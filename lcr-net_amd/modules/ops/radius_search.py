@@ -91,6 +91,13 @@ class SupportGrid:
                                             _lib.ptr(self.status), _lib.ptr(self.ws), self.ws.numel(), _lib.stream_ptr(dev)),
                    "lcr_support_grid_build")
 
+    def order(self):
+        """int32 [ns_cap]: stacked support rows in cell-sorted order (first sum(s_lengths) entries valid)."""
+        out = torch.empty((self.ns_cap,), dtype=torch.int32, device=self.s_points.device)
+        _lib.check(_lib.lib().lcr_support_grid_order(_lib.ptr(self.ws), self.ns_cap, self.B, _lib.ptr(out), _lib.stream_ptr(out.device)),
+                   "lcr_support_grid_order")
+        return out
+
     def query(self, q_points, q_lengths, neighbor_limit, dtype=torch.int32, want_counts=False):
         """[nq_cap, limit] indices (rows beyond sum(q_lengths) are left unwritten) and optionally the in-radius counts."""
         assert q_points.dtype == torch.float32 and q_points.is_contiguous() and q_lengths.numel() == self.B
