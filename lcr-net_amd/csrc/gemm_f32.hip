@@ -12,6 +12,8 @@
 // only thing that matters is never exposing a latency: global loads are branch-free 16-B vectors issued one K-step ahead
 // into registers (double-buffered LDS, one barrier per K-step), LDS fragments are prefetched one MFMA group ahead, and the
 // tile shape is chosen so that >= ~400 workgroups exist (two per CU) even for the short-M stages.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace lcr {
@@ -26,6 +28,7 @@ constexpr int GM_MAX_BATCH = 64;
 struct GemmBatch {
   int     count;                 // 0 = plain GEMM
   int     strided;               // 1: entry z uses offsets z * {a,b,c}_off[0] and K = k[0] (uniform batch)
+                                 // 2: split-K: entry z reduces k in [z*k[0], min((z+1)*k[0], K)) into the partial C + z*c_off[0]
   int     k[GM_MAX_BATCH];
   int64_t a_off[GM_MAX_BATCH], b_off[GM_MAX_BATCH], c_off[GM_MAX_BATCH];
 };
@@ -135,7 +138,12 @@ template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                                        int64_t M, int N, int K, GemmEpilogue ep, GemmBatch batch) {
   static_assert(WM * WN == 4 && BM == 32 * WM, "one 32-row MFMA tile per wavefront along M");
-  if (batch.count) {
+  int k_begin = 0, k_end = K;
+  if (batch.count && batch.strided == 2) {
+    k_begin = blockIdx.z * batch.k[0];
+    k_end = min(k_begin + batch.k[0], K);
+    C += static_cast<int64_t>(blockIdx.z) * batch.c_off[0];
+  } else if (batch.count) {
     const int z = blockIdx.z;
     if (batch.strided) {
       A += static_cast<int64_t>(z) * batch.a_off[0];
@@ -160,59 +168,108 @@ __global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ 
   const int64_t m0 = static_cast<int64_t>(blockIdx.x) * BM;
   const int n0 = blockIdx.y * BN;
 
-  LoaderT<BM, LDA, VEC> la_t;
-  LoaderN<BM, LDA, VEC> la_n;
-  LoaderT<BN, LDB, VEC> lb_t;
-  LoaderN<BN, LDB, VEC> lb_n;
+  // two register stages: the tile for K-step t+2 is requested while step t computes and step t+1 already sits in registers,
+  // so a global load has two full MFMA phases (~2 x 1024 cycles) to land before it is needed for the LDS store
+  LoaderT<BM, LDA, VEC> la_t[2];
+  LoaderN<BM, LDA, VEC> la_n[2];
+  LoaderT<BN, LDB, VEC> lb_t[2];
+  LoaderN<BN, LDB, VEC> lb_n[2];
 
-  auto gload = [&](int k0) {
-    if (TA) la_n.load(A, M, K, m0, k0);
-    else la_t.load(A, M, K, m0, k0);
-    if (TB) lb_t.load(B, N, K, n0, k0);
-    else lb_n.load(B, N, K, n0, k0);
+  auto gload = [&](int k0, int r) {
+    if (TA) la_n[r].load(A, M, K, m0, k0);
+    else la_t[r].load(A, M, K, m0, k0);
+    if (TB) lb_t[r].load(B, N, K, n0, k0);
+    else lb_n[r].load(B, N, K, n0, k0);
   };
-  auto sstore = [&](int buf) {
-    if (TA) la_n.store(As[buf]);
-    else la_t.store(As[buf]);
-    if (TB) lb_t.store(Bs[buf]);
-    else lb_n.store(Bs[buf]);
+  auto sstore = [&](int buf, int r) {
+    if (TA) la_n[r].store(As[buf]);
+    else la_t[r].store(As[buf]);
+    if (TB) lb_t[r].store(Bs[buf]);
+    else lb_n[r].store(Bs[buf]);
   };
 
-  floatx16 acc[NT];
+  // The 128x32 tile (N = 32: the stage-1 KPConv contraction) chains every MFMA on one accumulator, where any issue bubble
+  // costs a full 64-cycle latency: it alternates between two accumulator sets (even / odd K pairs), +10 % measured.  The
+  // 64x64 tile measured slower with the extra registers, so it keeps one.
+  constexpr int NACC = (NT == 1 && BM == 128) ? 2 : 1;
+  floatx16 acc[NT], acc2[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int r = 0; r < 16; ++r) {
+      acc[j][r] = 0.f;
+      acc2[j][r] = 0.f;
+    }
 
-  const int nk = (K + GM_BK - 1) / GM_BK;
-  gload(0);
-  sstore(0);
+  if (!(batch.count && batch.strided == 2)) k_end = K;   // K may have been replaced by a per-entry value above
+  const int nk = (k_end - k_begin + GM_BK - 1) / GM_BK;   // split-K chunks are multiples of GM_BK, so loaders only need the global bound K
+  gload(k_begin, 0);
+  sstore(0, 0);
+  if (nk > 1) gload(k_begin + GM_BK, 1);
   __syncthreads();
   const int a_off = (lane >> 5) * LDA + wm * 32 + (lane & 31);
   const int b_off = (lane >> 5) * LDB + wn * (32 * NT) + (lane & 31);
-  for (int t = 0; t < nk; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < nk) gload((t + 1) * GM_BK);     // lands in registers while this K-step's MFMAs run
-    const float* as = As[buf] + a_off;
-    const float* bs = Bs[buf] + b_off;
-    // fragments prefetched one MFMA group ahead (explicit register double buffer)
-    float af[2], bf[2][NT];
-    af[0] = as[0];
+  for (int t = 0; t < nk; t += 2) {
+    // ---- even step: compute buffer 0; registers[1] hold tile t+1; request tile t+2 into registers[0]
+    {
+      if (t + 2 < nk) gload(k_begin + (t + 2) * GM_BK, 0);
+      const float* as = As[0] + a_off;
+      const float* bs = Bs[0] + b_off;
+      float af[2], bf[2][NT];
+      af[0] = as[0];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) bf[0][j] = bs[j * 32];
+      for (int j = 0; j < NT; ++j) bf[0][j] = bs[j * 32];
 #pragma unroll
-    for (int kk = 0; kk < GM_BK / 2; ++kk) {
-      const int cur = kk & 1, nxt = cur ^ 1;
-      if (kk + 1 < GM_BK / 2) {
-        af[nxt] = as[(kk + 1) * 2 * LDA];
+      for (int kk = 0; kk < GM_BK / 2; ++kk) {
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk + 1 < GM_BK / 2) {
+          af[nxt] = as[(kk + 1) * 2 * LDA];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bf[nxt][j] = bs[(kk + 1) * 2 * LDB + j * 32];
+          for (int j = 0; j < NT; ++j) bf[nxt][j] = bs[(kk + 1) * 2 * LDB + j * 32];
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          if (NACC == 2 && (kk & 1)) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur], bf[cur][j], acc2[j], 0, 0, 0);
+          else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur], bf[cur][j], acc[j], 0, 0, 0);
+        }
       }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur], bf[cur][j], acc[j], 0, 0, 0);
+      if (t + 1 < nk) sstore(1, 1);
+      __syncthreads();
     }
-    if (t + 1 < nk) sstore(buf ^ 1);
-    __syncthreads();
+    if (t + 1 >= nk) break;
+    // ---- odd step: compute buffer 1; registers[0] hold tile t+2; request tile t+3 into registers[1]
+    {
+      if (t + 3 < nk) gload(k_begin + (t + 3) * GM_BK, 1);
+      const float* as = As[1] + a_off;
+      const float* bs = Bs[1] + b_off;
+      float af[2], bf[2][NT];
+      af[0] = as[0];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bf[0][j] = bs[j * 32];
+#pragma unroll
+      for (int kk = 0; kk < GM_BK / 2; ++kk) {
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk + 1 < GM_BK / 2) {
+          af[nxt] = as[(kk + 1) * 2 * LDA];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) bf[nxt][j] = bs[(kk + 1) * 2 * LDB + j * 32];
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          if (NACC == 2 && (kk & 1)) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur], bf[cur][j], acc2[j], 0, 0, 0);
+          else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur], bf[cur][j], acc[j], 0, 0, 0);
+        }
+      }
+      if (t + 2 < nk) sstore(0, 0);
+      __syncthreads();
+    }
+  }
+
+  if (NACC == 2) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] += acc2[j][r];
   }
 
   // ---- epilogue -------------------------------------------------------------------------------------------------
@@ -337,6 +394,102 @@ static int launch_gemm(const float* A, const float* B, float* C, int64_t M, int 
   return check_launch("lcr_gemm_f32");
 }
 
+// Split-K finish: C = (sum_z P[z]) / rowdiv + bias, plus the GroupNorm sums of C.  One workgroup per 32 rows.
+__global__ __launch_bounds__(256) void k_splitk_finish(const float* __restrict__ P, int splits, float* __restrict__ C, int64_t M, int N,
+                                                       GemmEpilogue ep) {
+  __shared__ double s_red[64][2];          // up to 64 groups
+  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * 32;
+  const int c4n = N >> 2;                  // float4 columns
+  const bool want_stats = ep.stats != nullptr;
+  const int gs = want_stats ? N / ep.groups : 1;
+  int seg = 0;
+  bool uniform = true;
+  if (want_stats) {
+    int64_t end = ep.seg_len[0];
+    while (seg + 1 < ep.S && r0 >= end) {
+      ++seg;
+      end += ep.seg_len[seg];
+    }
+    uniform = min(r0 + 31, M - 1) < end;
+    for (int i = threadIdx.x; i < 64 * 2; i += 256) (&s_red[0][0])[i] = 0.0;
+    __syncthreads();
+  }
+  double* rep = want_stats ? ep.stats + static_cast<int64_t>(blockIdx.x % GN_REPLICAS) * ep.S * ep.groups * 2 : nullptr;
+  // thread -> fixed float4 column (c4n divides 256 for the encoder's N), a subset of the 32 rows: column sums stay in registers
+  const int colq = threadIdx.x % c4n, rsub = threadIdx.x / c4n, rstep = 256 / c4n;
+  const int c0 = colq * 4;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f}, css[4] = {0.f, 0.f, 0.f, 0.f};
+  if (rsub < rstep)
+    for (int r = rsub; r < 32; r += rstep) {
+      const int64_t row = r0 + r;
+      if (row >= M) break;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int z = 0; z < splits; ++z) {
+        const float4 v = *reinterpret_cast<const float4*>(P + (static_cast<int64_t>(z) * M + row) * N + c0);
+        acc.x += v.x;
+        acc.y += v.y;
+        acc.z += v.z;
+        acc.w += v.w;
+      }
+      float o[4] = {acc.x, acc.y, acc.z, acc.w};
+      const float d = ep.rowdiv ? ep.rowdiv[row] : 1.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (ep.rowdiv) o[u] = o[u] / d;
+        if (ep.bias) o[u] += ep.bias[c0 + u];
+      }
+      *reinterpret_cast<float4*>(C + row * N + c0) = make_float4(o[0], o[1], o[2], o[3]);
+      if (want_stats) {
+        if (uniform) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            cs[u] += o[u];
+            css[u] = fmaf(o[u], o[u], css[u]);
+          }
+        } else {
+          const int sg = seg_of_row(ep.seg_len, ep.S, row);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int g = (c0 + u) / gs;
+            atomicAdd(rep + (static_cast<int64_t>(sg) * ep.groups + g) * 2, static_cast<double>(o[u]));
+            atomicAdd(rep + (static_cast<int64_t>(sg) * ep.groups + g) * 2 + 1, static_cast<double>(o[u]) * o[u]);
+          }
+        }
+      }
+    }
+  if (want_stats && uniform && rsub < rstep) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int g = (c0 + u) / gs;
+      atomicAdd(&s_red[g][0], static_cast<double>(cs[u]));
+      atomicAdd(&s_red[g][1], static_cast<double>(css[u]));
+    }
+  }
+  if (want_stats && uniform) {
+    __syncthreads();
+    for (int g = threadIdx.x; g < ep.groups; g += 256) {
+      atomicAdd(rep + (static_cast<int64_t>(seg) * ep.groups + g) * 2, s_red[g][0]);
+      atomicAdd(rep + (static_cast<int64_t>(seg) * ep.groups + g) * 2 + 1, s_red[g][1]);
+    }
+  }
+}
+
+// split-K plan for deep, short problems (the stage-3/4 KPConv contractions: M = 6-19 k, K = 1920-3840): big tiles for reuse,
+// K split so that >= ~512 workgroups exist.  Returns the number of splits (1 = do not split).
+static int splitk_plan(int64_t M, int N, int K, int transA, int transB, int* bn_out) {
+  if (transA || transB || K < 960 || (K % GM_BK) || (N % 64) || (256 % (N / 4)) != 0) return 1;   // finish kernel: N/4 divides 256
+  const int bn = N >= 128 ? 128 : 64;
+  const int64_t tiles = ((M + 127) / 128) * ((N + bn - 1) / bn);
+  if (tiles >= 384) return 1;
+  int splits = static_cast<int>((512 + tiles - 1) / tiles);
+  const int kmax = K / 256;                      // keep >= 8 K-steps per split
+  if (splits > kmax) splits = kmax;
+  if (splits > 16) splits = 16;
+  if (splits < 2) return 1;
+  *bn_out = bn;
+  return splits;
+}
+
 }  // namespace lcr
 
 using namespace lcr;
@@ -345,8 +498,31 @@ using namespace lcr;
 static int g_force_tile = 0;
 extern "C" void lcr_gemm_debug_force_tile(int t) { g_force_tile = t; }
 
+extern "C" int lcr_gemm_f32_ws_bytes(int64_t M, int N, int K, int transA, int transB, size_t* bytes) {
+  if (!bytes) return LCR_EARG;
+  int bn = 0;
+  const int splits = getenv("LCR_GEMM_SPLITK") ? splitk_plan(M, N, K, transA, transB, &bn) : 1;   // measured slower than 64x64 tiles on MI355X; opt-in
+  *bytes = splits > 1 ? sizeof(float) * static_cast<size_t>(splits) * M * N : 0;
+  return LCR_OK;
+}
+
+static int gemm_impl(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB, const float* bias,
+                     const float* rowdiv, const int64_t* seg_len, int S, int groups, double* stats, void* ws, size_t ws_bytes, void* stream);
+
 extern "C" int lcr_gemm_f32(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB, const float* bias,
                             const float* rowdiv, const int64_t* seg_len, int S, int groups, double* stats, void* stream) {
+  return gemm_impl(A, B, C, M, N, K, transA, transB, bias, rowdiv, seg_len, S, groups, stats, nullptr, 0, stream);
+}
+
+// Same, with an optional workspace (lcr_gemm_f32_ws_bytes) that enables the split-K path for deep, short problems.
+extern "C" int lcr_gemm_f32_ex(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB, const float* bias,
+                               const float* rowdiv, const int64_t* seg_len, int S, int groups, double* stats, void* ws, size_t ws_bytes,
+                               void* stream) {
+  return gemm_impl(A, B, C, M, N, K, transA, transB, bias, rowdiv, seg_len, S, groups, stats, ws, ws_bytes, stream);
+}
+
+static int gemm_impl(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB, const float* bias,
+                     const float* rowdiv, const int64_t* seg_len, int S, int groups, double* stats, void* ws, size_t ws_bytes, void* stream) {
   if (!A || !B || !C || M < 0 || N <= 0 || K <= 0) {
     set_error("lcr_gemm_f32: bad argument");
     return LCR_EARG;
@@ -366,6 +542,25 @@ extern "C" int lcr_gemm_f32(const float* A, const float* B, float* C, int64_t M,
   if (stats) hipMemsetAsync(stats, 0, sizeof(double) * 2 * S * groups * GN_REPLICAS, st);
   if (M == 0) return LCR_OK;
   GemmEpilogue ep{bias, rowdiv, seg_len, S, groups, stats};
+  {
+    int bn = 0;
+    const int splits = (ws && getenv("LCR_GEMM_SPLITK") && !g_force_tile) ? splitk_plan(M, N, K, transA, transB, &bn) : 1;
+    if (splits > 1 && ws_bytes >= sizeof(float) * static_cast<size_t>(splits) * M * N && (groups == 0 || groups <= 64) &&
+        reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(B) % 16 == 0) {
+      GemmBatch bt = {};
+      bt.count = splits;
+      bt.strided = 2;
+      bt.k[0] = ((K / GM_BK + splits - 1) / splits) * GM_BK;     // K-steps per split, in elements
+      bt.c_off[0] = M * N;
+      GemmEpilogue none{nullptr, nullptr, nullptr, 0, 0, nullptr};
+      float* P = static_cast<float*>(ws);
+      int rc = bn == 128 ? launch_gemm<128, 128, 4, 1, true>(A, B, P, M, N, K, 0, 0, none, st, &bt)
+                         : launch_gemm<128, 64, 4, 1, true>(A, B, P, M, N, K, 0, 0, none, st, &bt);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_splitk_finish, dim3(static_cast<int>((M + 31) / 32)), dim3(256), 0, st, P, splits, C, M, N, ep);
+      return check_launch("lcr_gemm_f32 (split-K)");
+    }
+  }
   // 16-byte vector loads need leading dimensions that are multiples of 4 floats (bases: torch allocations are >= 256-B aligned,
   // row offsets inside them are multiples of the leading dimension)
   const int64_t lda = transA ? M : K, ldb = transB ? K : N;
