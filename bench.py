@@ -89,8 +89,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("LCR_BENCH_BACKEND", "nccl")         # "nccl" is RCCL on ROCm; "gloo" only for dry runs
+        if os.environ.get("LCR_BENCH_SINGLE_DEVICE"):                  # dry run of the N>1 code path on a 1-GPU box
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
