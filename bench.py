@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-upsampling", action="store_true", help="skip the 3 decoder-only upsampling searches")
     ap.add_argument("--no-overlap", action="store_true", help="run pre-processing and encoder on one stream (no pipelining)")
+    ap.add_argument("--no-thread", action="store_true", help="two streams but a single host thread")
     return ap.parse_args()
 
 
@@ -115,7 +116,7 @@ def main():
 
     from lcrnet_amd.pipeline import DescriptorPipeline
     pipe = DescriptorPipeline(model, VOXEL, RADIUS, NUM_STAGES, LIMITS, upsampling=not args.no_upsampling, raw_voxel=VOXEL,
-                              overlap=not args.no_overlap)
+                              overlap=not args.no_overlap, producer_thread=not args.no_thread)
 
     def run_steps(n):
         """n steps = n batches, each fully processed (voxelise .. descriptors [+ all-gather]); the pre-processing of step

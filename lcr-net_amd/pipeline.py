@@ -13,7 +13,7 @@ from .data import precompute_batch, voxelize_raw_scans
 
 class DescriptorPipeline:
     def __init__(self, model, voxel_size=0.3, radius=1.275, num_stages=4, neighbor_limits=(64, 65, 74, 80), upsampling=False,
-                 raw_voxel=None, overlap=True):
+                 raw_voxel=None, overlap=True, producer_thread=True, depth=2):
         """raw_voxel: voxel size of the raw-scan ingest step (None = inputs are already voxelised like the reference's
         downsampled .npy scans; 0.3 = BASELINE configs[1]).  upsampling: also compute the 3 decoder-only upsampling lists."""
         self.model = model
@@ -23,6 +23,7 @@ class DescriptorPipeline:
         dev = next(model.parameters()).device
         self.device = dev
         self.pre_stream = torch.cuda.Stream(dev) if overlap else None
+        self.producer_thread, self.depth = producer_thread, depth
 
     # ---- stages -----------------------------------------------------------------------------------------------------
     def preprocess(self, points, lengths):
@@ -46,6 +47,9 @@ class DescriptorPipeline:
         if not self.overlap:
             for pts, lens in batches:
                 yield self.encode(self.preprocess(pts, lens))
+            return
+        if self.producer_thread:
+            yield from self._run_threaded(batches)
             return
         main = torch.cuda.current_stream(self.device)
         pre = self.pre_stream
@@ -74,3 +78,45 @@ class DescriptorPipeline:
             dd, ready = pending
             main.wait_event(ready)
             yield self.encode(dd)
+
+    def _run_threaded(self, batches):
+        """Same overlap, but the pre-processing (whose two length read-backs block the host) runs in its own host thread,
+        `depth` batches ahead, so the encoder stream never waits for the host to come back from a synchronisation.  ctypes
+        releases the GIL during every kernel launch / synchronisation, so the two threads do interleave."""
+        import queue
+        import threading
+        main = torch.cuda.current_stream(self.device)
+        pre = self.pre_stream
+        pre.wait_stream(main)
+        q = queue.Queue(maxsize=self.depth)
+        dev = self.device
+
+        def producer():
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(pre):
+                    for pts, lens in batches:
+                        dd = self.preprocess(pts, lens)
+                        ev = torch.cuda.Event()
+                        ev.record(pre)
+                        q.put((dd, ev))
+                q.put(None)
+            except BaseException as e:   # surface errors in the consumer
+                q.put(e)
+
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            dd, ev = item
+            for v in dd.values():
+                for t in (v if isinstance(v, (list, tuple)) else [v]):
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(main)
+            main.wait_event(ev)
+            yield self.encode(dd)
+        th.join()

@@ -28,8 +28,8 @@ def test_overlapped_pipeline_matches_sequential():
                         torch.tensor([len(s) for s in scans], dtype=torch.int64, device="cuda")))
     limits = [74, 68, 70, 67]
     seq = [d.clone() for d in DescriptorPipeline(m, neighbor_limits=limits, overlap=False).run(batches)]
-    for _ in range(3):                                   # repeat: stream races would show up as run-to-run differences
-        ovl = [d.clone() for d in DescriptorPipeline(m, neighbor_limits=limits, overlap=True).run(batches)]
+    for rep in range(4):                                 # repeat: stream races would show up as run-to-run differences
+        ovl = [d.clone() for d in DescriptorPipeline(m, neighbor_limits=limits, overlap=True, producer_thread=rep % 2 == 0).run(batches)]
         torch.cuda.synchronize()
         assert len(ovl) == len(seq)
         for a, b in zip(seq, ovl):
