@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-upsampling", action="store_true", help="skip the 3 decoder-only upsampling searches")
     ap.add_argument("--no-overlap", action="store_true", help="run pre-processing and encoder on one stream (no pipelining)")
     ap.add_argument("--no-thread", action="store_true", help="two streams but a single host thread")
+    ap.add_argument("--single-encoder", action="store_true", help="one encoder stream (default: consecutive batches alternate between two)")
     return ap.parse_args()
 
 
@@ -117,6 +118,8 @@ def main():
     from lcrnet_amd.pipeline import DescriptorPipeline
     pipe = DescriptorPipeline(model, VOXEL, RADIUS, NUM_STAGES, LIMITS, upsampling=not args.no_upsampling, raw_voxel=VOXEL,
                               overlap=not args.no_overlap, producer_thread=not args.no_thread)
+    if not (args.single_encoder or args.no_overlap or args.no_thread):
+        pipe.enable_dual_encoder()
 
     def run_steps(n):
         """n steps = n batches, each fully processed (voxelise .. descriptors [+ all-gather]); the pre-processing of step
@@ -186,7 +189,8 @@ def main():
                                    % (7 if args.no_upsampling else 10),
                        "scans_per_step_per_gpu": BATCH, "raw_points_per_scan": int(raw_pts.shape[0] // BATCH),
                        "stage_points_per_batch": stage_points, "neighbor_limits": LIMITS,
-                       "streams": "1" if args.no_overlap else "2 (pre-processing of step k+1 overlaps encoder of step k)",
+                       "streams": "1" if args.no_overlap else ("pre-processing stream (own host thread, 2 batches ahead) + %d encoder stream(s)"
+                                                               % (1 if (args.single_encoder or args.no_thread) else 2)),
                        "parallelism": "scan-parallel x%d, all-gather of descriptors" % world},
             "roofline": roof,
         }

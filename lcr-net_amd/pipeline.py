@@ -24,6 +24,13 @@ class DescriptorPipeline:
         self.device = dev
         self.pre_stream = torch.cuda.Stream(dev) if overlap else None
         self.producer_thread, self.depth = producer_thread, depth
+        self.enc_streams = None      # set by enable_dual_encoder(): consecutive batches' encoders on alternating streams
+
+    def enable_dual_encoder(self):
+        """Run the encoders of consecutive batches on two alternating streams so that the small-grid kernels of one (stage-3/4
+        GEMMs, GroupNorm, NetVLAD) fill the gaps of the other.  Results are handed back in order on the caller's stream."""
+        self.enc_streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
+        return self
 
     # ---- stages -----------------------------------------------------------------------------------------------------
     def preprocess(self, points, lengths):
@@ -106,6 +113,8 @@ class DescriptorPipeline:
 
         th = threading.Thread(target=producer, daemon=True)
         th.start()
+        k = 0
+        pending = None       # (descriptors, done event) of the previous batch when two encoder streams are used
         while True:
             item = q.get()
             if item is None:
@@ -113,10 +122,28 @@ class DescriptorPipeline:
             if isinstance(item, BaseException):
                 raise item
             dd, ev = item
+            es = main if self.enc_streams is None else self.enc_streams[k % 2]
             for v in dd.values():
                 for t in (v if isinstance(v, (list, tuple)) else [v]):
                     if torch.is_tensor(t) and t.is_cuda:
-                        t.record_stream(main)
-            main.wait_event(ev)
-            yield self.encode(dd)
+                        t.record_stream(es)
+            es.wait_event(ev)
+            if self.enc_streams is None:
+                yield self.encode(dd)
+            else:
+                if k < 2:
+                    es.wait_stream(main)                    # weights / inputs prepared on the caller's stream
+                with torch.cuda.stream(es):
+                    desc = self.encode(dd)
+                    done = torch.cuda.Event()
+                    done.record(es)
+                desc.record_stream(main)
+                if pending is not None:
+                    main.wait_event(pending[1])
+                    yield pending[0]
+                pending = (desc, done)
+            k += 1
+        if pending is not None:
+            main.wait_event(pending[1])
+            yield pending[0]
         th.join()

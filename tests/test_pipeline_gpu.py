@@ -29,7 +29,10 @@ def test_overlapped_pipeline_matches_sequential():
     limits = [74, 68, 70, 67]
     seq = [d.clone() for d in DescriptorPipeline(m, neighbor_limits=limits, overlap=False).run(batches)]
     for rep in range(4):                                 # repeat: stream races would show up as run-to-run differences
-        ovl = [d.clone() for d in DescriptorPipeline(m, neighbor_limits=limits, overlap=True, producer_thread=rep % 2 == 0).run(batches)]
+        pipe = DescriptorPipeline(m, neighbor_limits=limits, overlap=True, producer_thread=rep % 2 == 0)
+        if rep == 2:
+            pipe.enable_dual_encoder()                   # encoders of consecutive batches on alternating streams
+        ovl = [d.clone() for d in pipe.run(batches * (3 if rep == 2 else 1))][:len(batches)]
         torch.cuda.synchronize()
         assert len(ovl) == len(seq)
         for a, b in zip(seq, ovl):
