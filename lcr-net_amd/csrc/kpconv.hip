@@ -272,6 +272,115 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate_mfma(const f
   }
 }
 
+// Vector-gather form of the MFMA aggregation (default).  Same math as k_kpconv_aggregate_mfma, but a lane fetches V = 4 (C >= 64)
+// or 2 (C = 32) CONSECUTIVE channels of its neighbour's row with one 16-B / 8-B load, so a 4-neighbour step of C = 64 is one
+// load instruction per lane (4 full 256-B rows per wavefront instruction) instead of four, and the V components feed V MFMA tiles
+// whose column `col` is channel q*16V + V*col + v: the output row is then written with V-wide stores.  Loads run D steps ahead
+// of the matrix core in a register ring (the kernel is bound by the L2 latency of the row gathers).
+template <int V> struct VecOf;
+template <> struct VecOf<4> { typedef float4 type; };
+template <> struct VecOf<2> { typedef float2 type; };
+__device__ __forceinline__ float vget(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+__device__ __forceinline__ float vget(const float2& v, int i) { return i == 0 ? v.x : v.y; }
+__device__ __forceinline__ float4 vmake(const float (&a)[4]) { return make_float4(a[0], a[1], a[2], a[3]); }
+__device__ __forceinline__ float2 vmake(const float (&a)[2]) { return make_float2(a[0], a[1]); }
+
+template <typename IdxT, int C>
+__global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate_vec(const float* __restrict__ s_feats, const uint8_t* __restrict__ s_pos,
+                                                                        const float* __restrict__ q_pts, const float* __restrict__ s_pts,
+                                                                        const IdxT* __restrict__ idx, int64_t M, int64_t Ns, int H, KPoints kp,
+                                                                        float sigma, float* __restrict__ A, float* __restrict__ nn,
+                                                                        const int32_t* __restrict__ order) {
+  constexpr int V = C >= 64 ? 4 : 2;
+  constexpr int NL = C / (16 * V);           // vector loads per lane per 4-neighbour step
+  constexpr int D = NL == 1 ? 4 : 2;         // steps in flight
+  typedef typename VecOf<V>::type VecT;
+  __shared__ __attribute__((aligned(16))) float4 s_rel[KP_WAVES][KP_HMAX + 8];   // (dx, dy, dz, bits(index)) per valid neighbour
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int sub = lane >> 4, col = lane & 15;
+  const float inv_sigma = 1.f / sigma;
+  float kx = 0.f, ky = 0.f, kz = 0.f;
+#pragma unroll
+  for (int k = 0; k < KP_K; ++k)
+    if (col == k) {
+      kx = kp.p[k][0];
+      ky = kp.p[k][1];
+      kz = kp.p[k][2];
+    }
+  const bool real_k = col < KP_K;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * KP_WAVES + w; t < M; t += static_cast<int64_t>(gridDim.x) * KP_WAVES) {
+    const int64_t m = order ? order[t] : t;
+    const float qx = q_pts[3 * m], qy = q_pts[3 * m + 1], qz = q_pts[3 * m + 2];
+    int n = 0, cnt = 0;
+    for (int h0 = 0; h0 < H; h0 += 64) {
+      const int h = h0 + lane;
+      int64_t j = Ns;
+      if (h < H) j = static_cast<int64_t>(idx[m * H + h]);
+      const bool ok = j >= 0 && j < Ns;
+      const uint64_t mk = __ballot(ok);
+      if (ok) {
+        const int slot = n + __popcll(mk & lanemask_lt());
+        s_rel[w][slot] = make_float4(s_pts[3 * j] - qx, s_pts[3 * j + 1] - qy, s_pts[3 * j + 2] - qz, __uint_as_float(static_cast<uint32_t>(j)));
+        cnt += s_pos[j] ? 1 : 0;
+      }
+      n += __popcll(mk);
+    }
+    cnt = wave_sum(cnt);
+    wave_lds_sync();
+
+    floatx4 acc[NL][V];
+#pragma unroll
+    for (int q = 0; q < NL; ++q)
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[q][v] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int steps = (n + 3) >> 2;
+    float4 p[D];
+    VecT f[D][NL];
+    auto fetch = [&](int s, float4& pp, VecT (&ff)[NL]) {
+      const int h = 4 * s + sub;
+      pp = s_rel[w][h < n ? h : n - 1];
+      const float* r = s_feats + static_cast<int64_t>(__float_as_uint(pp.w)) * C + V * col;
+#pragma unroll
+      for (int q = 0; q < NL; ++q) ff[q] = *reinterpret_cast<const VecT*>(r + q * 16 * V);
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (d < steps) fetch(d, p[d], f[d]);
+    for (int s0 = 0; s0 < steps; s0 += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int s = s0 + d;
+        if (s < steps) {                                     // wave-uniform
+          const float ex = p[d].x - kx, ey = p[d].y - ky, ez = p[d].z - kz;
+          float wv = fmaxf(1.f - __builtin_amdgcn_sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * inv_sigma, 0.f);
+          wv = (real_k && 4 * s + sub < n) ? wv : 0.f;
+#pragma unroll
+          for (int q = 0; q < NL; ++q)
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[q][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, vget(f[d][q], v), acc[q][v], 0, 0, 0);
+          if (s + D < steps) fetch(s + D, p[d], f[d]);
+        }
+      }
+    }
+    float* out = A + m * (KP_K * C) + V * col;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 4 * sub + r;
+      if (k < KP_K) {
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+          float a[V];
+#pragma unroll
+          for (int v = 0; v < V; ++v) a[v] = acc[q][v][r];
+          *reinterpret_cast<VecT*>(out + k * C + q * 16 * V) = vmake(a);
+        }
+      }
+    }
+    if (lane == 0) nn[m] = static_cast<float>(cnt > 1 ? cnt : 1);
+    wave_lds_sync();
+  }
+}
+
 // encoder1_1: scalar input feature per point; out[m][o] = (sum_k (sum_h w[k][h] f[h]) W[k][o]) / count + bias[o]
 template <typename IdxT>
 __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_cin1(const float* __restrict__ s_feats, const float* __restrict__ q_pts,
@@ -383,6 +492,17 @@ static int launch_aggregate(const float* s_feats, const uint8_t* s_pos, const fl
                             int64_t Ns, int H, int C, const KPoints& kp, float sigma, float* A, float* nn, const int32_t* order, hipStream_t st) {
   dim3 grid(grid_for(M, KP_WAVES)), block(KP_WAVES * 64);
   static const bool use_valu = getenv("LCR_KPCONV_VALU") != nullptr;   // A/B switch for profiling; the MFMA path is the default
+  static const bool use_scalar_gather = getenv("LCR_KPCONV_SCALAR_GATHER") != nullptr;   // previous MFMA variant, kept for A/B profiling
+  if (!use_valu && !use_scalar_gather) {
+    switch (C) {
+      case 32: hipLaunchKernelGGL((k_kpconv_aggregate_vec<IdxT, 32>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
+      case 64: hipLaunchKernelGGL((k_kpconv_aggregate_vec<IdxT, 64>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
+      case 128: hipLaunchKernelGGL((k_kpconv_aggregate_vec<IdxT, 128>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
+      case 256: hipLaunchKernelGGL((k_kpconv_aggregate_vec<IdxT, 256>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
+      default: set_error("lcr_kpconv_aggregate: C must be 32, 64, 128 or 256 (got %d)", C); return LCR_EARG;
+    }
+    return check_launch("lcr_kpconv_aggregate");
+  }
   if (!use_valu) {
     switch (C) {
       case 32: hipLaunchKernelGGL((k_kpconv_aggregate_mfma<IdxT, 32>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;

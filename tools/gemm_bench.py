@@ -33,6 +33,8 @@ def main():
         bias = torch.randn(N, device=dev)
         div = torch.rand(M, device=dev) + 1 if rd else None
         seg = torch.tensor([M // 8 - 3] * 7 + [M - 7 * (M // 8 - 3)], dtype=torch.int64, device=dev)
+        if "--nostats" in sys.argv:
+            stats = 0
         kw = dict(trans_b=bool(tb), bias=bias, rowdiv=div, seg_len=seg if stats else None, groups=32 if stats else 0)
         for _ in range(3):
             F.gemm(a, b, **kw)

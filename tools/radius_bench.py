@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the 10 radius searches of one bench batch (8 synthetic scans): µs per query launch, HIP events.
+    python tools/radius_bench.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import bench
+    from lcrnet_amd.data import voxelize_raw_scans
+    from lcrnet_amd.modules.ops import grid_subsample_device, SupportGrid
+    dev = torch.device("cuda:0")
+    scans = bench.make_batch(0)
+    pts = torch.from_numpy(np.concatenate(scans)).to(dev)
+    lens = torch.tensor([len(s) for s in scans], dtype=torch.int64, device=dev)
+    p, l, lh = voxelize_raw_scans(pts, lens, bench.VOXEL)
+    P, L = [p.contiguous()], [l]
+    v = bench.VOXEL
+    for i in range(1, bench.NUM_STAGES):
+        v *= 2
+        q, ql, _ = grid_subsample_device(P[-1], L[-1], v)
+        n = int(ql.sum())
+        P.append(q[:n].contiguous())
+        L.append(ql)
+    r = bench.RADIUS
+    grids = []
+    for i in range(bench.NUM_STAGES):
+        grids.append(SupportGrid(P[i], L[i], r))
+        r *= 2
+    total = 0.0
+
+    def timed(tag, fn):
+        nonlocal total
+        for _ in range(3):
+            out = fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(20):
+            out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / 20 * 1e3
+        total += t
+        nq, H = out.shape
+        print("%-16s nq=%7d limit=%3d  %8.1f us  %6.1f GB/s out   sum %d" % (tag, nq, H, t, nq * H * 4 / t / 1e3, int(out.long().sum())))
+
+    for i in range(bench.NUM_STAGES):
+        timed("neighbors[%d]" % i, lambda: grids[i].query(P[i], L[i], bench.LIMITS[i]))
+        if i < bench.NUM_STAGES - 1:
+            timed("subsampling[%d]" % i, lambda: grids[i].query(P[i + 1], L[i + 1], bench.LIMITS[i]))
+            timed("upsampling[%d]" % i, lambda: grids[i + 1].query(P[i], L[i], bench.LIMITS[i + 1]))
+    print("total %.1f us" % total)
+
+
+if __name__ == "__main__":
+    main()
