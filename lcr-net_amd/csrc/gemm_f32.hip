@@ -12,7 +12,9 @@
 // only thing that matters is never exposing a latency: global loads are branch-free 16-B vectors issued one K-step ahead
 // into registers (double-buffered LDS, one barrier per K-step), LDS fragments are prefetched one MFMA group ahead, and the
 // tile shape is chosen so that >= ~400 workgroups exist (two per CU) even for the short-M stages.
+#include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -50,6 +52,8 @@ template <int R, int LD, bool VEC>
 struct LoaderT {
   static constexpr int PIECES = R * 8 / GM_T;   // float4 pieces per thread
   float4 reg[PIECES];
+  unsigned okmask;                              // bit j: piece j is inside K (zeroing is deferred to the LDS store, so that
+                                                // nothing waits on the load between its issue and its use one K-step later)
   __device__ __forceinline__ void load(const float* __restrict__ src, int64_t rows_total, int K, int64_t r0, int k0) {
 #pragma unroll
     for (int j = 0; j < PIECES; ++j) {
@@ -60,8 +64,8 @@ struct LoaderT {
       const int gk = k0 + c4 * 4;
       if (VEC) {
         const bool ok = gk < K;                               // K % 4 == 0: a piece is entirely in or out
-        float4 v = ld4(src + gr * K + (ok ? gk : 0));
-        reg[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        reg[j] = ld4(src + gr * K + (ok ? gk : 0));
+        okmask = j == 0 ? (ok ? 1u : 0u) : (okmask | (ok ? (1u << j) : 0u));
       } else {
         const float* p = src + gr * K;
         float4 v;
@@ -70,19 +74,22 @@ struct LoaderT {
         v.z = gk + 2 < K ? p[gk + 2] : 0.f;
         v.w = gk + 3 < K ? p[gk + 3] : 0.f;
         reg[j] = v;
+        okmask = ~0u;
       }
     }
   }
+  __device__ __forceinline__ void store_piece(float* __restrict__ S, int j) const {
+    const int f = threadIdx.x + GM_T * j;
+    const int row = f >> 3, c4 = f & 7;
+    const bool ok = (okmask >> j) & 1u;
+    S[(c4 * 4 + 0) * LD + row] = ok ? reg[j].x : 0.f;
+    S[(c4 * 4 + 1) * LD + row] = ok ? reg[j].y : 0.f;
+    S[(c4 * 4 + 2) * LD + row] = ok ? reg[j].z : 0.f;
+    S[(c4 * 4 + 3) * LD + row] = ok ? reg[j].w : 0.f;
+  }
   __device__ __forceinline__ void store(float* __restrict__ S) const {
 #pragma unroll
-    for (int j = 0; j < PIECES; ++j) {
-      const int f = threadIdx.x + GM_T * j;
-      const int row = f >> 3, c4 = f & 7;
-      S[(c4 * 4 + 0) * LD + row] = reg[j].x;
-      S[(c4 * 4 + 1) * LD + row] = reg[j].y;
-      S[(c4 * 4 + 2) * LD + row] = reg[j].z;
-      S[(c4 * 4 + 3) * LD + row] = reg[j].w;
-    }
+    for (int j = 0; j < PIECES; ++j) store_piece(S, j);
   }
 };
 
@@ -91,6 +98,7 @@ template <int W, int LD, bool VEC>
 struct LoaderN {
   static constexpr int PIECES = 8 * W / GM_T;
   float4 reg[PIECES];
+  unsigned okmask;
   __device__ __forceinline__ void load(const float* __restrict__ src, int64_t cols_total, int K, int64_t c0, int k0) {
 #pragma unroll
     for (int j = 0; j < PIECES; ++j) {
@@ -102,8 +110,8 @@ struct LoaderN {
       const float* p = src + static_cast<int64_t>(kok ? gk : 0) * cols_total;
       if (VEC) {
         const bool ok = kok && gc < cols_total;              // cols_total % 4 == 0
-        float4 v = ld4(p + (gc < cols_total ? gc : 0));
-        reg[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        reg[j] = ld4(p + (gc < cols_total ? gc : 0));
+        okmask = j == 0 ? (ok ? 1u : 0u) : (okmask | (ok ? (1u << j) : 0u));
       } else {
         float4 v;
         v.x = (kok && gc + 0 < cols_total) ? p[gc + 0] : 0.f;
@@ -111,16 +119,19 @@ struct LoaderN {
         v.z = (kok && gc + 2 < cols_total) ? p[gc + 2] : 0.f;
         v.w = (kok && gc + 3 < cols_total) ? p[gc + 3] : 0.f;
         reg[j] = v;
+        okmask = ~0u;
       }
     }
   }
+  __device__ __forceinline__ void store_piece(float* __restrict__ S, int j) const {
+    const int f = threadIdx.x + GM_T * j;
+    const int kr = f / (W / 4), c4 = f % (W / 4);
+    const bool ok = (okmask >> j) & 1u;
+    *reinterpret_cast<float4*>(&S[kr * LD + c4 * 4]) = ok ? reg[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   __device__ __forceinline__ void store(float* __restrict__ S) const {
 #pragma unroll
-    for (int j = 0; j < PIECES; ++j) {
-      const int f = threadIdx.x + GM_T * j;
-      const int kr = f / (W / 4), c4 = f % (W / 4);
-      *reinterpret_cast<float4*>(&S[kr * LD + c4 * 4]) = reg[j];
-    }
+    for (int j = 0; j < PIECES; ++j) store_piece(S, j);
   }
 };
 
@@ -209,60 +220,67 @@ __global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ 
   __syncthreads();
   const int a_off = (lane >> 5) * LDA + wm * 32 + (lane & 31);
   const int b_off = (lane >> 5) * LDB + wn * (32 * NT) + (lane & 31);
-  for (int t = 0; t < nk; t += 2) {
-    // ---- even step: compute buffer 0; registers[1] hold tile t+1; request tile t+2 into registers[0]
-    {
-      if (t + 2 < nk) gload(k_begin + (t + 2) * GM_BK, 0);
-      const float* as = As[0] + a_off;
-      const float* bs = Bs[0] + b_off;
-      float af[2], bf[2][NT];
-      af[0] = as[0];
+  // One K-step: compute LDS buffer BUF while (a) the tile for step t+2 is requested into register set BUF and (b) the tile
+  // for step t+1 (register set 1-BUF) is written to LDS buffer 1-BUF — its ds_writes are issued BETWEEN the MFMAs, and the
+  // MFMA operand fragments are read PF K-pairs ahead: LDS latency (~100+ cycles) exceeds one 64-cycle MFMA, so a one-deep
+  // prefetch exposes a bubble on every MFMA when a SIMD holds a single wavefront (measured: the loop skeleton, the MFMAs and
+  // the global-load stalls simply added up).
+  constexpr int KK = GM_BK / 2;
+  constexpr int PF = NT == 1 ? KK : (NT == 2 ? 8 : 4);           // fragment prefetch depth (registers: PF * (1 + NT))
+  constexpr int PA = BM * 8 / GM_T, PB = BN * 8 / GM_T;           // LDS-store pieces per thread for the A / B tile
+  constexpr int ST0 = KK - (PA + PB) - 1 > 2 ? (KK - (PA + PB)) / 2 : 1;   // first K-pair that carries a store piece
+  // FULL = steps t+1 and t+2 exist: no branches in the body, which keeps the whole K-step one basic block (the waitcnt
+  // insertion is only exact inside a block: with the conditional stores it waited for the loads it had just issued).
+  auto step = [&](auto buf_c, auto full_c, int t) {
+    constexpr int BUF = decltype(buf_c)::value;
+    constexpr bool FULL = decltype(full_c)::value;
+    if (FULL || t + 2 < nk) gload(k_begin + (t + 2) * GM_BK, BUF);
+    const bool do_store = FULL || t + 1 < nk;                     // block-uniform
+    const float* as = As[BUF] + a_off;
+    const float* bs = Bs[BUF] + b_off;
+    float af[PF], bf[PF][NT];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bf[0][j] = bs[j * 32];
+    for (int d = 0; d < PF; ++d) {
+      af[d] = as[d * 2 * LDA];
 #pragma unroll
-      for (int kk = 0; kk < GM_BK / 2; ++kk) {
-        const int cur = kk & 1, nxt = cur ^ 1;
-        if (kk + 1 < GM_BK / 2) {
-          af[nxt] = as[(kk + 1) * 2 * LDA];
+      for (int j = 0; j < NT; ++j) bf[d][j] = bs[d * 2 * LDB + j * 32];
+    }
+    __builtin_amdgcn_sched_barrier(0);                            // keep the fragment reads ahead of the MFMA chain
 #pragma unroll
-          for (int j = 0; j < NT; ++j) bf[nxt][j] = bs[(kk + 1) * 2 * LDB + j * 32];
-        }
+    for (int kk = 0; kk < KK; ++kk) {
+      const int sl = kk % PF;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          if (NACC == 2 && (kk & 1)) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur], bf[cur][j], acc2[j], 0, 0, 0);
-          else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur], bf[cur][j], acc[j], 0, 0, 0);
+      for (int j = 0; j < NT; ++j) {
+        if (NACC == 2 && (kk & 1)) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[sl], bf[sl][j], acc2[j], 0, 0, 0);
+        else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[sl], bf[sl][j], acc[j], 0, 0, 0);
+      }
+      if (kk + PF < KK) {
+        af[sl] = as[(kk + PF) * 2 * LDA];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[sl][j] = bs[(kk + PF) * 2 * LDB + j * 32];
+      }
+      const int piece = kk - ST0;                                 // compile-time after unrolling
+      if (do_store && piece >= 0 && piece < PA + PB) {
+        if (piece < PA) {
+          if (TA) la_n[1 - BUF].store_piece(As[1 - BUF], piece);
+          else la_t[1 - BUF].store_piece(As[1 - BUF], piece);
+        } else {
+          if (TB) lb_t[1 - BUF].store_piece(Bs[1 - BUF], piece - PA);
+          else lb_n[1 - BUF].store_piece(Bs[1 - BUF], piece - PA);
         }
       }
-      if (t + 1 < nk) sstore(1, 1);
-      __syncthreads();
     }
+    __syncthreads();
+  };
+  int t = 0;
+  for (; t + 3 < nk; t += 2) {
+    step(std::integral_constant<int, 0>{}, std::true_type{}, t);
+    step(std::integral_constant<int, 1>{}, std::true_type{}, t + 1);
+  }
+  for (; t < nk; t += 2) {
+    step(std::integral_constant<int, 0>{}, std::false_type{}, t);
     if (t + 1 >= nk) break;
-    // ---- odd step: compute buffer 1; registers[0] hold tile t+2; request tile t+3 into registers[1]
-    {
-      if (t + 3 < nk) gload(k_begin + (t + 3) * GM_BK, 1);
-      const float* as = As[1] + a_off;
-      const float* bs = Bs[1] + b_off;
-      float af[2], bf[2][NT];
-      af[0] = as[0];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) bf[0][j] = bs[j * 32];
-#pragma unroll
-      for (int kk = 0; kk < GM_BK / 2; ++kk) {
-        const int cur = kk & 1, nxt = cur ^ 1;
-        if (kk + 1 < GM_BK / 2) {
-          af[nxt] = as[(kk + 1) * 2 * LDA];
-#pragma unroll
-          for (int j = 0; j < NT; ++j) bf[nxt][j] = bs[(kk + 1) * 2 * LDB + j * 32];
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          if (NACC == 2 && (kk & 1)) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur], bf[cur][j], acc2[j], 0, 0, 0);
-          else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur], bf[cur][j], acc[j], 0, 0, 0);
-        }
-      }
-      if (t + 2 < nk) sstore(0, 0);
-      __syncthreads();
-    }
+    step(std::integral_constant<int, 1>{}, std::false_type{}, t + 1);
   }
 
   if (NACC == 2) {
@@ -478,6 +496,24 @@ __global__ __launch_bounds__(256) void k_splitk_finish(const float* __restrict__
 // K split so that >= ~512 workgroups exist.  Returns the number of splits (1 = do not split).
 static int splitk_plan(int64_t M, int N, int K, int transA, int transB, int* bn_out) {
   if (transA || transB || K < 960 || (K % GM_BK) || (N % 64) || (256 % (N / 4)) != 0) return 1;   // finish kernel: N/4 divides 256
+  // experiment hook: LCR_GEMM_SPLITK="tile,splits" (tile 64 or 128; splits 0 = auto)
+  static int cfg_tile = 128, cfg_splits = 0;
+  static bool parsed = false;
+  if (!parsed) {
+    const char* e = getenv("LCR_GEMM_SPLITK");
+    if (e) sscanf(e, "%d,%d", &cfg_tile, &cfg_splits);
+    parsed = true;
+  }
+  if (cfg_tile == 64) {
+    const int64_t tiles = ((M + 63) / 64) * ((N + 63) / 64);
+    if (tiles >= 1024) return 1;
+    int splits = cfg_splits > 0 ? cfg_splits : static_cast<int>((1024 + tiles - 1) / tiles);
+    const int kmax = K / 256;
+    if (splits > kmax) splits = kmax;
+    if (splits < 2) return 1;
+    *bn_out = 64;
+    return splits;
+  }
   const int bn = N >= 128 ? 128 : 64;
   const int64_t tiles = ((M + 127) / 128) * ((N + bn - 1) / bn);
   if (tiles >= 384) return 1;
@@ -554,8 +590,10 @@ static int gemm_impl(const float* A, const float* B, float* C, int64_t M, int N,
       bt.c_off[0] = M * N;
       GemmEpilogue none{nullptr, nullptr, nullptr, 0, 0, nullptr};
       float* P = static_cast<float*>(ws);
-      int rc = bn == 128 ? launch_gemm<128, 128, 4, 1, true>(A, B, P, M, N, K, 0, 0, none, st, &bt)
-                         : launch_gemm<128, 64, 4, 1, true>(A, B, P, M, N, K, 0, 0, none, st, &bt);
+      static const bool tile64 = getenv("LCR_GEMM_SPLITK") && atoi(getenv("LCR_GEMM_SPLITK")) == 64;
+      int rc = tile64 ? launch_gemm<64, 64, 2, 2, true>(A, B, P, M, N, K, 0, 0, none, st, &bt)
+               : bn == 128 ? launch_gemm<128, 128, 4, 1, true>(A, B, P, M, N, K, 0, 0, none, st, &bt)
+                           : launch_gemm<128, 64, 4, 1, true>(A, B, P, M, N, K, 0, 0, none, st, &bt);
       if (rc) return rc;
       hipLaunchKernelGGL(k_splitk_finish, dim3(static_cast<int>((M + 31) / 32)), dim3(256), 0, st, P, splits, C, M, N, ep);
       return check_launch("lcr_gemm_f32 (split-K)");

@@ -20,6 +20,7 @@ namespace lcr {
 
 constexpr int RS_CAP = 512;      // LDS keys per wavefront (8 B each)
 constexpr int RS_WAVES = 4;      // wavefronts (= queries in flight) per workgroup
+constexpr int RS_UNROLL = 4;     // candidate chunks (of 64) in flight per wavefront
 constexpr int GRID_MAX_B = 64;   // clouds per call
 constexpr int CELL_PER_PT = 32;  // cell budget = CELL_PER_PT * ns_cap + CELL_MIN * B
 constexpr int CELL_MIN = 4096;
@@ -243,20 +244,31 @@ __global__ __launch_bounds__(RS_WAVES * 64) void k_radius_query(const float* __r
       idx = __float_as_uint(P.w);
     };
 
+    // RS_UNROLL chunks of 64 candidates per trip: their loads are issued back to back, so a query pays the L2 round trip
+    // once per 256 candidates instead of once per 64
     int n = 0;
-    for (int t0 = 0; t0 < total; t0 += 64) {
-      const int t = t0 + lane;
-      float d2 = 0.f;
-      uint32_t idx = 0;
-      bool pass = false;
-      if (t < total) {
-        candidate(t, d2, idx);
-        pass = d2 < r2;
+    for (int t0 = 0; t0 < total; t0 += 64 * RS_UNROLL) {
+      float d2[RS_UNROLL];
+      uint32_t idx[RS_UNROLL];
+      bool pass[RS_UNROLL];
+#pragma unroll
+      for (int u = 0; u < RS_UNROLL; ++u) {
+        const int t = t0 + 64 * u + lane;
+        d2[u] = 0.f;
+        idx[u] = 0;
+        pass[u] = false;
+        if (t < total) {
+          candidate(t, d2[u], idx[u]);
+          pass[u] = d2[u] < r2;
+        }
       }
-      const uint64_t m = __ballot(pass);
-      const int off = n + __popcll(m & lanemask_lt());
-      if (pass && off < RS_CAP) keys[off] = (static_cast<uint64_t>(__float_as_uint(d2)) << 32) | idx;
-      n += __popcll(m);
+#pragma unroll
+      for (int u = 0; u < RS_UNROLL; ++u) {
+        const uint64_t m = __ballot(pass[u]);
+        const int off = n + __popcll(m & lanemask_lt());
+        if (pass[u] && off < RS_CAP) keys[off] = (static_cast<uint64_t>(__float_as_uint(d2[u])) << 32) | idx[u];
+        n += __popcll(m);
+      }
     }
     if (out_cnt) {
       if (lane == 0) out_cnt[qi] = n;
