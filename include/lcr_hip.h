@@ -90,7 +90,8 @@ int lcr_radius_search(const float* q, const float* s, const int64_t* qlen, const
  * padded with Ns like the reference's neighbour lists; feature tensors are row-major [N,C].
  * ------------------------------------------------------------------------------------------------ */
 /* C = A·B on the fp32 matrix cores with fused epilogue: C[m][:] = (A·B)[m][:] / rowdiv[m] + bias, and per-(segment,group)
- * sum / sum-of-squares of C accumulated into stats[LCR_GN_REPLICAS,S,groups,2] (fp64; consumers add the replicas — they
+ * sum / sum-of-squares of C ADDED to stats[LCR_GN_REPLICAS,S,groups,2] (fp64; the caller zeroes the table — one fill per
+ * forward pass can cover every layer's table; consumers add the replicas — they
  * only spread same-address atomics) for the GroupNorm that follows.
  * transA: A is stored [K,M]; transB: B is stored [N,K] (nn.Linear weight).  Replaces F.linear + the (15,C,Cout)
  * contraction of KPConv.forward (modules/kpconv/kpconv.py:108-116) and torch.matmul in NetVlad.py:56,68. */
@@ -124,7 +125,8 @@ int lcr_maxpool(const float* x, const void* idx, int idx_is_64, int64_t M, int64
                 const int32_t* order, void* stream);
 /* pos[n] = (sum_c x[n][c] > 0) — the flag behind KPConv's neighbour count. */
 int lcr_row_positive(const float* x, int64_t N, int C, uint8_t* pos, void* stream);
-/* Segmented GroupNorm statistics (sum, sumsq per segment and group, fp64, [LCR_GN_REPLICAS,S,groups,2]) of x[N,C]. */
+/* Segmented GroupNorm statistics (sum, sumsq per segment and group, fp64, [LCR_GN_REPLICAS,S,groups,2]) of x[N,C],
+ * ADDED to the caller-zeroed table. */
 int lcr_groupnorm_stats(const float* x, int64_t N, int C, int groups, const int64_t* seg_len, int S, double* stats, void* stream);
 /* y = act( GN(x; stats,gamma,beta) [+ res | + GN(res; res_stats,res_gamma,res_beta)] ), act = LeakyReLU(slope) if act != 0
  * (modules/kpconv/modules.py:33-50, 78-84, 207-225).  Optional pos[n] = (sum_c y[n][c] > 0). */

@@ -1,6 +1,7 @@
 """KPEncoder — experiments/lcrnet/backbone4.py:11-89 (4 stages / 11 blocks), same attribute names => same checkpoint keys."""
 import torch.nn as nn
 
+from . import functional as F
 from .modules.kpconv import ConvBlock, ResidualBlock, StageContext
 
 
@@ -27,6 +28,10 @@ class KPEncoder(nn.Module):
         seg = data_dict.get("segment_lengths")
         order = data_dict.get("order")
         ctx = [StageContext(None if seg is None else seg[i], None if order is None else order[i]) for i in range(4)]
+        with F.stats_arena(feats.device):
+            return self._forward(feats, P, N, S, ctx)
+
+    def _forward(self, feats, P, N, S, ctx):
         f1 = self.encoder1_1(feats, P[0], P[0], N[0], ctx[0], ctx[0])
         f1 = self.encoder1_2(f1, P[0], P[0], N[0], ctx[0], ctx[0])
         f2 = self.encoder2_1(f1, P[1], P[0], S[0], ctx[1], ctx[0])

@@ -214,9 +214,29 @@ __global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ 
 
   if (!(batch.count && batch.strided == 2)) k_end = K;   // K may have been replaced by a per-entry value above
   const int nk = (k_end - k_begin + GM_BK - 1) / GM_BK;   // split-K chunks are multiples of GM_BK, so loaders only need the global bound K
+  // Both prologue tiles are requested before anything waits (for nk == 1 the second request re-reads tile 0: its pieces are
+  // out of K, so their addresses fall back to column 0 — cache hits, never stored).  The epilogue's per-column bias and the
+  // GroupNorm segment of this row block (a chain of dependent scalar loads) are fetched here too, under the same latency.
   gload(k_begin, 0);
+  gload(k_begin + GM_BK, 1);
+  const bool want_stats = ep.stats != nullptr;
+  float bias_v[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + (w % WN) * (32 * NT) + j * 32 + (lane & 31);
+    bias_v[j] = (ep.bias && col < N) ? ep.bias[col] : 0.f;
+  }
+  int blk_first = 0;
+  int64_t blk_seg_start = 0, blk_seg_end = 0;
+  if (want_stats) {
+    blk_seg_end = ep.seg_len[0];
+    while (blk_first + 1 < ep.S && m0 >= blk_seg_end) {
+      ++blk_first;
+      blk_seg_start = blk_seg_end;
+      blk_seg_end += ep.seg_len[blk_first];
+    }
+  }
   sstore(0, 0);
-  if (nk > 1) gload(k_begin + GM_BK, 1);
   __syncthreads();
   const int a_off = (lane >> 5) * LDA + wm * 32 + (lane & 31);
   const int b_off = (lane >> 5) * LDB + wn * (32 * NT) + (lane & 31);
@@ -291,7 +311,6 @@ __global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ 
   }
 
   // ---- epilogue -------------------------------------------------------------------------------------------------
-  const bool want_stats = ep.stats != nullptr;
   const int gs = want_stats ? N / ep.groups : 1;   // channels per group
   const int64_t wrow0 = m0 + wm * 32;
 
@@ -299,7 +318,7 @@ __global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ 
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int col = n0 + wn * (32 * NT) + j * 32 + (lane & 31);
-    const float bv = (ep.bias && col < N) ? ep.bias[col] : 0.f;
+    const float bv = bias_v[j];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -322,13 +341,7 @@ __global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ 
   if (want_stats) {
     __shared__ double s_red[BN][2];
     double* rep = ep.stats + static_cast<int64_t>(blockIdx.x % GN_REPLICAS) * ep.S * ep.groups * 2;
-    int blk_first = 0;
-    int64_t seg_start = 0, seg_end = ep.seg_len[0];
-    while (blk_first + 1 < ep.S && m0 >= seg_end) {
-      ++blk_first;
-      seg_start = seg_end;
-      seg_end += ep.seg_len[blk_first];
-    }
+    int64_t seg_start = blk_seg_start, seg_end = blk_seg_end;
     const int64_t blk_last_row = min(m0 + BM - 1, M - 1);
     const bool uniform = blk_last_row < seg_end;      // block-uniform
     if (uniform) {
@@ -575,7 +588,8 @@ static int gemm_impl(const float* A, const float* B, float* C, int64_t M, int N,
     }
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (stats) hipMemsetAsync(stats, 0, sizeof(double) * 2 * S * groups * GN_REPLICAS, st);
+  // `stats` ACCUMULATES: the caller passes a zeroed table (one fill per forward pass for all layers, instead of a fill
+  // launch in front of every GEMM)
   if (M == 0) return LCR_OK;
   GemmEpilogue ep{bias, rowdiv, seg_len, S, groups, stats};
   {

@@ -194,7 +194,7 @@ extern "C" int lcr_groupnorm_stats(const float* x, int64_t N, int C, int groups,
     return LCR_EARG;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipMemsetAsync(stats, 0, sizeof(double) * 2 * S * groups * GN_REPLICAS, st);
+  // `stats` accumulates into a caller-zeroed table, like lcr_gemm_f32
   if (N == 0) return LCR_OK;
   hipLaunchKernelGGL(k_gn_stats, dim3(static_cast<int>((N + 255) / 256)), dim3(256), 0, st, x, N, C, groups, seg_len, S, stats);   // 4 waves x 64 rows
   return check_launch("lcr_groupnorm_stats");

@@ -1,6 +1,7 @@
 """Thin tensor-level wrappers over the C ABI (include/lcr_hip.h).  No arithmetic happens in Python: every function
 allocates the outputs with torch and launches HIP kernels on the current stream.  Inference only (no autograd)."""
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -63,6 +64,42 @@ def _idx_args(idx):
     raise RuntimeError("neighbor indices must be int32 or int64")
 
 
+class _StatsArena(threading.local):
+    buf = None
+    off = 0
+
+
+_ARENA = _StatsArena()
+
+
+class stats_arena:
+    """Context manager: GroupNorm statistics tables of every GEMM / groupnorm_stats call inside are carved out of ONE zeroed
+    fp64 buffer (one fill launch per forward pass instead of one per layer).  Per host thread; nests by replacement."""
+
+    def __init__(self, device, entries=1 << 18):
+        self.device, self.entries = device, entries
+
+    def __enter__(self):
+        self.prev = (_ARENA.buf, _ARENA.off)
+        _ARENA.buf = torch.zeros(self.entries, dtype=torch.float64, device=self.device)
+        _ARENA.off = 0
+        return self
+
+    def __exit__(self, *exc):
+        _ARENA.buf, _ARENA.off = self.prev
+        return False
+
+
+def _zero_stats(S, groups, device):
+    n = GN_REPLICAS * S * groups * 2
+    buf = _ARENA.buf
+    if buf is not None and buf.device == device and _ARENA.off + n <= buf.numel():
+        v = buf[_ARENA.off:_ARENA.off + n].view(GN_REPLICAS, S, groups, 2)
+        _ARENA.off += n
+        return v
+    return torch.zeros((GN_REPLICAS, S, groups, 2), dtype=torch.float64, device=device)
+
+
 def gemm(a, b, trans_b=False, trans_a=False, bias=None, rowdiv=None, seg_len=None, groups=0):
     """C = A·B (+ fused epilogue).  a: [M,K] ([K,M] if trans_a); b: [K,N] ([N,K] if trans_b, i.e. an nn.Linear weight).
     Returns (C, stats) where stats is the fp64 [GN_REPLICAS,S,groups,2] GroupNorm accumulator (sum the replicas; None if
@@ -78,7 +115,7 @@ def gemm(a, b, trans_b=False, trans_a=False, bias=None, rowdiv=None, seg_len=Non
     if groups:
         seg_len = _seg(seg_len, M, a.device)
         S = seg_len.numel()
-        stats = torch.empty((GN_REPLICAS, S, groups, 2), dtype=torch.float64, device=a.device)
+        stats = _zero_stats(S, groups, a.device)
     nbytes = ctypes.c_size_t(0)
     _lib.lib().lcr_gemm_f32_ws_bytes(M, N, K, int(trans_a), int(trans_b), ctypes.byref(nbytes))
     ws = _lib.workspace(nbytes.value, a.device) if nbytes.value else None       # split-K partials for deep, short problems
@@ -91,7 +128,7 @@ def gemm(a, b, trans_b=False, trans_a=False, bias=None, rowdiv=None, seg_len=Non
 
 def groupnorm_stats(x, groups, seg_len=None):
     seg_len = _seg(seg_len, x.shape[0], x.device)
-    stats = torch.empty((GN_REPLICAS, seg_len.numel(), groups, 2), dtype=torch.float64, device=x.device)
+    stats = _zero_stats(seg_len.numel(), groups, x.device)
     _lib.check(_lib.lib().lcr_groupnorm_stats(_lib.ptr(x), x.shape[0], x.shape[1], groups, _lib.ptr(seg_len), seg_len.numel(),
                                               _lib.ptr(stats), _lib.stream_ptr(x.device)), "lcr_groupnorm_stats")
     return stats

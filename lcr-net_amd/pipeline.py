@@ -6,6 +6,8 @@ searches — many short, latency-bound launches and two tiny D2H length reads) r
 batch k (throughput-bound MFMA/HBM kernels) run on stream B.  Ordering is by events; tensors produced on A and consumed on B
 are `record_stream`ed so the caching allocator cannot recycle them early.
 """
+import os
+
 import torch
 
 from .data import precompute_batch, voxelize_raw_scans
@@ -13,7 +15,7 @@ from .data import precompute_batch, voxelize_raw_scans
 
 class DescriptorPipeline:
     def __init__(self, model, voxel_size=0.3, radius=1.275, num_stages=4, neighbor_limits=(64, 65, 74, 80), upsampling=False,
-                 raw_voxel=None, overlap=True, producer_thread=True, depth=2):
+                 raw_voxel=None, overlap=True, producer_thread=True, depth=2, pre_workers=1):
         """raw_voxel: voxel size of the raw-scan ingest step (None = inputs are already voxelised like the reference's
         downsampled .npy scans; 0.3 = BASELINE configs[1]).  upsampling: also compute the 3 decoder-only upsampling lists."""
         self.model = model
@@ -22,8 +24,11 @@ class DescriptorPipeline:
         self.upsampling, self.raw_voxel, self.overlap = upsampling, raw_voxel, overlap
         dev = next(model.parameters()).device
         self.device = dev
-        self.pre_stream = torch.cuda.Stream(dev) if overlap else None
-        self.producer_thread, self.depth = producer_thread, depth
+        # the pre-processing chain is latency-bound (hundreds of dependent short launches): give it the high-priority queue so
+        # that its launches are not parked behind the encoder's long kernels
+        prio = -1 if os.environ.get("LCR_PRE_PRIORITY", "1") != "0" else 0
+        self.pre_stream = torch.cuda.Stream(dev, priority=prio) if overlap else None
+        self.producer_thread, self.depth, self.pre_workers = producer_thread, depth, pre_workers
         self.enc_streams = None      # set by enable_dual_encoder(): consecutive batches' encoders on alternating streams
 
     def enable_dual_encoder(self):
@@ -87,41 +92,64 @@ class DescriptorPipeline:
             yield self.encode(dd)
 
     def _run_threaded(self, batches):
-        """Same overlap, but the pre-processing (whose two length read-backs block the host) runs in its own host thread,
+        """Same overlap, but the pre-processing (whose two length read-backs block the host) runs in its own host thread(s),
         `depth` batches ahead, so the encoder stream never waits for the host to come back from a synchronisation.  ctypes
-        releases the GIL during every kernel launch / synchronisation, so the two threads do interleave."""
+        releases the GIL during every kernel launch / synchronisation, so the threads do interleave.  With `pre_workers` > 1,
+        consecutive batches are pre-processed concurrently on separate streams: the pre-processing of ONE batch is a chain of
+        ~400 dependent short launches and two host round trips, i.e. latency- not throughput-bound."""
         import queue
         import threading
         main = torch.cuda.current_stream(self.device)
-        pre = self.pre_stream
-        pre.wait_stream(main)
-        q = queue.Queue(maxsize=self.depth)
         dev = self.device
+        W = max(1, int(self.pre_workers))
+        streams = [self.pre_stream] + [torch.cuda.Stream(dev, priority=self.pre_stream.priority) for _ in range(W - 1)]
+        for st in streams:
+            st.wait_stream(main)
+        out = queue.Queue()
+        slots = threading.Semaphore(self.depth + W - 1)      # batches pre-processed but not yet consumed
+        it = enumerate(iter(batches))
+        it_lock = threading.Lock()
 
-        def producer():
+        def producer(st):
             try:
                 torch.cuda.set_device(dev)
-                with torch.cuda.stream(pre):
-                    for pts, lens in batches:
+                with torch.cuda.stream(st):
+                    while True:
+                        slots.acquire()
+                        with it_lock:
+                            nxt = next(it, None)
+                        if nxt is None:
+                            slots.release()
+                            break
+                        k, (pts, lens) = nxt
                         dd = self.preprocess(pts, lens)
                         ev = torch.cuda.Event()
-                        ev.record(pre)
-                        q.put((dd, ev))
-                q.put(None)
+                        ev.record(st)
+                        out.put((k, dd, ev))
+                out.put(None)
             except BaseException as e:   # surface errors in the consumer
-                q.put(e)
+                out.put(e)
 
-        th = threading.Thread(target=producer, daemon=True)
-        th.start()
+        threads = [threading.Thread(target=producer, args=(st,), daemon=True) for st in streams]
+        for th in threads:
+            th.start()
         k = 0
+        ready = {}           # out-of-order arrivals (several workers)
+        finished = 0
         pending = None       # (descriptors, done event) of the previous batch when two encoder streams are used
         while True:
-            item = q.get()
-            if item is None:
+            while k not in ready and finished < W:
+                item = out.get()
+                if item is None:
+                    finished += 1
+                elif isinstance(item, BaseException):
+                    raise item
+                else:
+                    ready[item[0]] = item[1:]
+            if k not in ready:
                 break
-            if isinstance(item, BaseException):
-                raise item
-            dd, ev = item
+            dd, ev = ready.pop(k)
+            slots.release()
             es = main if self.enc_streams is None else self.enc_streams[k % 2]
             for v in dd.values():
                 for t in (v if isinstance(v, (list, tuple)) else [v]):
@@ -146,4 +174,5 @@ class DescriptorPipeline:
         if pending is not None:
             main.wait_event(pending[1])
             yield pending[0]
-        th.join()
+        for th in threads:
+            th.join()
