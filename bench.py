@@ -153,6 +153,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    iso = None
+    if rank == 0:
+        # the same GEMM launches once more with nothing else on the GPU (one stream, outside the timed region): in the timed
+        # region three streams share the CUs, so a launch's event-to-event duration includes time it spent waiting for them
+        iso_timer = F.KernelTimer({"gemm"})
+        dd_iso = pipe.preprocess(raw_pts, raw_lens)
+        pipe.encode(dd_iso)
+        torch.cuda.synchronize()
+        F.set_timer(iso_timer)
+        for _ in range(3):
+            pipe.encode(dd_iso)
+        torch.cuda.synchronize()
+        F.set_timer(None)
+        g = iso_timer.summary()["gemm"]
+        iso = sum(2.0 * m[0] * m[1] * m[2] for _, m in g) / sum(t for t, _ in g) / 1e12
     if rank == 0:
         assert torch.isfinite(desc).all() and abs(float(desc.norm(dim=1).mean()) - 1.0) < 1e-3
         # ---- roofline of the dominant kernel family, measured live with HIP events on the launch stream.
@@ -175,6 +190,7 @@ def main():
         roof = {"bound": "mfma", "kernel": "lcr::k_gemm_f32 (fp32 MFMA, %d launches/step)" % (len(gem) // max(args.steps, 1)),
                 "achieved": round(flops / t_gemm / 1e12, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(flops / t_gemm / 1e12 / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
+                "achieved_alone": round(iso, 2), "frac_alone": round(iso / FP32_PEAK_TFLOPS, 4),
                 "avg_launch_us": round(t_gemm / max(len(gem), 1) * 1e6, 2),
                 "gflop_per_launch": round(flops / max(len(gem), 1) / 1e9, 3),
                 "share_of_step": {"gemm": round(t_gemm / dt, 3), "kpconv_aggregate": round(t_agg / dt, 3)},

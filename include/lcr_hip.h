@@ -86,6 +86,34 @@ int lcr_radius_search(const float* q, const float* s, const int64_t* qlen, const
                       void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * a-3  the whole per-batch pre-processing — replaces precompute_data_stack_mode (experiments/lcrnet/data.py:10-74: the
+ *      subsampling loop :20-29 and the 10 searches :33-69) for a stack of B clouds, as ONE native call: 3 grid subsamples,
+ *      4 support grids and up to 10 radius searches issued fork-join over side streams, voxel counts read back at the end.
+ * lcr_precompute_layout sizes the two arenas for stage-0 capacity n0 and reports where every result lives in `out`
+ * (byte offsets; int32 indices padded with sum(lengths) like the reference's lists; stage-0 points are the input itself).
+ * lcr_precompute_batch: points0 f32[n0,3] and lengths0 i64[B] on the device; voxel_size is stage 0's (stage i uses
+ * voxel_size * 2^i, radius * 2^i, data.py:28,73); lengths_host i64[num_stages*B] and status_host (LCR_STATUS_* bits) are
+ * HOST outputs — the call returns after synchronising `stream`.  LCR_STATUS_KEY_OVERFLOW: retry with key_bits_hint = 0.
+ * ------------------------------------------------------------------------------------------------ */
+#define LCR_MAX_STAGES 8
+typedef struct LcrPrecomputeLayout {
+  int     num_stages, B, upsampling;
+  int     limits[LCR_MAX_STAGES];
+  int64_t cap[LCR_MAX_STAGES];                 /* row capacity of every stage-i array */
+  size_t  off_points[LCR_MAX_STAGES];          /* f32[cap,3]            (i >= 1) */
+  size_t  off_lengths[LCR_MAX_STAGES];         /* i64[B]                (i >= 1) */
+  size_t  off_order[LCR_MAX_STAGES];           /* i32[cap]  cell-sorted processing order */
+  size_t  off_neighbors[LCR_MAX_STAGES];       /* i32[cap, limits[i]] */
+  size_t  off_subsampling[LCR_MAX_STAGES];     /* i32[cap, limits[i]]   rows = stage i+1 points (i < num_stages-1) */
+  size_t  off_upsampling[LCR_MAX_STAGES];      /* i32[cap, limits[i+1]] rows = stage i points   (i < num_stages-1, if enabled) */
+  size_t  out_bytes, ws_bytes;
+} LcrPrecomputeLayout;
+int lcr_precompute_layout(int64_t n0, int B, int num_stages, const int* limits, int upsampling, LcrPrecomputeLayout* layout);
+int lcr_precompute_batch(const float* points0, const int64_t* lengths0, const LcrPrecomputeLayout* layout, float voxel_size,
+                         float radius, int key_bits_hint, void* out, size_t out_bytes, void* ws, size_t ws_bytes,
+                         int64_t* lengths_host, uint32_t* status_host, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * a-4 / a-5 / a-6  KPConv encoder building blocks (fp32).  Index tensors are [M,H] int32 or int64 (idx_is_64),
  * padded with Ns like the reference's neighbour lists; feature tensors are row-major [N,C].
  * ------------------------------------------------------------------------------------------------ */

@@ -176,8 +176,15 @@ __global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ 
 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wm = w / WN, wn = w % WN;
-  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * BM;
-  const int n0 = blockIdx.y * BN;
+  // XCD-aware tile order.  Workgroups go round-robin to the 8 XCDs (linear id % 8), each with its own L2; the column tiles
+  // of one row block all read the same A rows, so they are given ids that land on ONE XCD back to back: the A tile is then
+  // fetched from HBM / Infinity Cache once instead of once per column tile (PMC: GEMM fetch traffic was ~2x algorithmic).
+  const int ntn = (N + BN - 1) / BN;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int64_t m_tile = static_cast<int64_t>(slot / ntn) * 8 + xcd;
+  const int64_t m0 = m_tile * BM;
+  const int n0 = (slot % ntn) * BN;
+  if (m0 >= M) return;                     // padding of the row-block count to a multiple of 8
 
   // two register stages: the tile for K-step t+2 is requested while step t computes and step t+1 already sits in registers,
   // so a global load has two full MFMA phases (~2 x 1024 cycles) to land before it is needed for the LDS store
@@ -336,11 +343,11 @@ __global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ 
 
   // GroupNorm statistics.  Fast path (all BM rows of the workgroup in one segment — all but B-1 workgroups): wavefront
   // partials are folded in LDS (ds_add_f64) and the workgroup issues one pair of global fp64 atomics per group, into the
-  // statistics replica (blockIdx.x % GN_REPLICAS).  Slow path (a segment boundary inside the tile): per wavefront, per
+  // statistics replica (row block % GN_REPLICAS).  Slow path (a segment boundary inside the tile): per wavefront, per
   // segment present in its 32 rows, straight to global memory.
   if (want_stats) {
     __shared__ double s_red[BN][2];
-    double* rep = ep.stats + static_cast<int64_t>(blockIdx.x % GN_REPLICAS) * ep.S * ep.groups * 2;
+    double* rep = ep.stats + static_cast<int64_t>(m_tile % GN_REPLICAS) * ep.S * ep.groups * 2;
     int64_t seg_start = blk_seg_start, seg_end = blk_seg_end;
     const int64_t blk_last_row = min(m0 + BM - 1, M - 1);
     const bool uniform = blk_last_row < seg_end;      // block-uniform
@@ -416,7 +423,8 @@ static int launch_gemm(const float* A, const float* B, float* C, int64_t M, int 
                        hipStream_t st, const GemmBatch* batch = nullptr) {
   static const GemmBatch no_batch = {};
   const GemmBatch& bt = batch ? *batch : no_batch;
-  dim3 grid(div_up(M, BM), div_up(N, BN), bt.count ? bt.count : 1);
+  const int mt8 = (div_up(M, BM) + 7) / 8 * 8;
+  dim3 grid(mt8 * div_up(N, BN), 1, bt.count ? bt.count : 1);     // see the XCD-aware tile order in the kernel
   dim3 block(GM_T);
   if (!transA && !transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, false, false, VEC>), grid, block, 0, st, A, B, C, M, N, K, ep, bt);
   else if (!transA && transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, false, true, VEC>), grid, block, 0, st, A, B, C, M, N, K, ep, bt);

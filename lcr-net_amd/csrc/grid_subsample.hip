@@ -68,6 +68,7 @@ struct GsLayout {
   int32_t*  hm_bk;       // [n]   bucket of each element
   int32_t*  hm_mem;      // [n]   bucket member lists
   int32_t*  hm_at;       // [n]
+  int32_t*  hm_arr;      // [n]   arrival index of every element inside its bucket
   int32_t*  hm_gmin;     // [bucket_cap]
   int32_t*  hm_cnt;      // [bucket_cap]
   int32_t*  hm_start;    // [bucket_cap]
@@ -99,6 +100,7 @@ static GsLayout gs_layout(void* ws, int64_t n_cap, int B) {
   L.hm_bk = c.take<int32_t>(n);
   L.hm_mem = c.take<int32_t>(n);
   L.hm_at = c.take<int32_t>(n + 1);
+  L.hm_arr = c.take<int32_t>(n);
   const size_t bc = static_cast<size_t>(bucket_cap_of(n_cap, B));
   L.hm_gmin = c.take<int32_t>(bc);
   L.hm_cnt = c.take<int32_t>(bc);
@@ -321,29 +323,58 @@ __device__ __forceinline__ int hm_block_excl_scan(int v, int* total, int* lds) {
   return base + inc - v;
 }
 
-// exclusive scan of a[0..n) in place (block-wide, arbitrary n); reversed => scan from the top index downwards
+// exclusive scan of a[0..n) in place (block-wide, arbitrary n); reversed => scan from the top index downwards.
+// Tiles of 4*HM_T elements, four consecutive entries per thread: neighbouring lanes touch neighbouring 16-B pieces (a
+// thread-contiguous chunking made every load instruction touch 64 different cache lines).
 template <bool REVERSED>
 __device__ void hm_scan_inplace(int32_t* a, int n, int* lds) {
-  const int chunk = (n + HM_T - 1) / HM_T;
-  const int lo = threadIdx.x * chunk, hi = min(lo + chunk, n);
-  int s = 0;
-  for (int i = lo; i < hi; ++i) s += a[REVERSED ? n - 1 - i : i];
-  int tot;
-  int run = hm_block_excl_scan(s, &tot, lds);
-  for (int i = lo; i < hi; ++i) {
-    const int idx = REVERSED ? n - 1 - i : i;
-    const int v = a[idx];
-    a[idx] = run;
-    run += v;
+  int carry = 0;
+  for (int base = 0; base < n; base += 4 * HM_T) {
+    const int i0 = base + 4 * threadIdx.x;
+    int v[4], s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k;
+      v[k] = i < n ? a[REVERSED ? n - 1 - i : i] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += v[k];
+    int tot;
+    int run = carry + hm_block_excl_scan(s, &tot, lds);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k;
+      if (i < n) a[REVERSED ? n - 1 - i : i] = run;
+      run += v[k];
+    }
+    carry += tot;
   }
   __syncthreads();
+}
+
+// Every pass below walks its index range in batches of HU entries per thread: the batch's loads are issued together, then
+// consumed — one workgroup per cloud is latency-bound, so the number of DEPENDENT memory round trips per pass is what counts.
+constexpr int HU = 4;
+
+// key % nb for nb < 2^31: 32-bit remainder when the key fits, else floor(key * (1/nb)) in fp64 (exact quotient within +-1 for
+// keys < 2^53, fixed up), else the 64-bit division.  The generic 64-bit urem costs ~100 instructions per element and phase.
+__device__ __forceinline__ int hm_bucket(uint64_t key, uint64_t nb64, double inv_nb) {
+  if ((key >> 32) == 0 && (nb64 >> 32) == 0) return static_cast<int>(static_cast<uint32_t>(key) % static_cast<uint32_t>(nb64));
+  if ((key >> 52) == 0 && (nb64 >> 31) == 0) {
+    int64_t q = static_cast<int64_t>(static_cast<double>(key) * inv_nb);
+    int64_t r = static_cast<int64_t>(key) - q * static_cast<int64_t>(nb64);
+    if (r < 0) r += static_cast<int64_t>(nb64);
+    if (r >= static_cast<int64_t>(nb64)) r -= static_cast<int64_t>(nb64);
+    return static_cast<int>(r);
+  }
+  return static_cast<int>(key % nb64);
 }
 
 __global__ __launch_bounds__(HM_T) void k_gs_hashorder(const GsHeader* __restrict__ h, const uint64_t* __restrict__ ins_key,
                                                        const int32_t* __restrict__ ins_seg, const float* __restrict__ bary,
                                                        int32_t* __restrict__ hm_t, int32_t* __restrict__ hm_bk,
                                                        int32_t* __restrict__ hm_mem, int32_t* __restrict__ hm_at,
-                                                       int32_t* __restrict__ hm_gmin, int32_t* __restrict__ hm_cnt,
+                                                       int32_t* __restrict__ hm_arr, int32_t* __restrict__ hm_gmin, int32_t* __restrict__ hm_cnt,
                                                        int32_t* __restrict__ hm_start, float* __restrict__ out_xyz) {
   __shared__ int lds[HM_T / 64];
   const int b = blockIdx.x;
@@ -351,12 +382,13 @@ __global__ __launch_bounds__(HM_T) void k_gs_hashorder(const GsHeader* __restric
   if (n <= 0) return;
   const int64_t o = h->out_off[b];
   const uint64_t* key = ins_key + o;
-  int32_t* t = hm_t + o;
-  int32_t* bk = hm_bk + o;
-  int32_t* mem = hm_mem + o;
-  int32_t* at = hm_at + o;
+  int32_t* t = hm_t + o;         // list position of every element after the previous phase (ping-pongs with bk)
+  int32_t* bk = hm_bk + o;       // bucket of every element in this phase, then its new list position
+  int32_t* memt = hm_mem + o;    // member lists: the TIMESTAMPS of every bucket's elements, bucket after bucket
+  int32_t* arrv = hm_arr + o;    // arrival index of every element inside its bucket (its slot in the member list)
+  int32_t* at = hm_at + o;       // first: group size at the group's creation time; after the scan: elements in newer groups
   const int64_t bo = (h->in_off[b] * 9) / 4 + 64 * b;   // this cloud's slice of the bucket arrays
-  int32_t* gmin = hm_gmin + bo;
+  int32_t* gmin = hm_gmin + bo;  // earliest member (group creation time); after pass B2: list position of the group's head
   int32_t* cnt = hm_cnt + bo;
   int32_t* start = hm_start + bo;
   const int tid = threadIdx.x;
@@ -364,6 +396,7 @@ __global__ __launch_bounds__(HM_T) void k_gs_hashorder(const GsHeader* __restric
   int lo = 0;
   for (int p = 0; p < N_SCHED; ++p) {
     const int64_t nb64 = c_sched[p];
+    const double inv_nb = 1.0 / static_cast<double>(nb64);
     const int hi = static_cast<int>(min(static_cast<int64_t>(n), nb64));
     const int nb = static_cast<int>(min(nb64, static_cast<int64_t>(2147483647)));
     // only buckets that can be hit matter, but all nb are scanned for the member offsets; nb <= 2.25 n + 64
@@ -371,43 +404,144 @@ __global__ __launch_bounds__(HM_T) void k_gs_hashorder(const GsHeader* __restric
       gmin[i] = 0x7fffffff;
       cnt[i] = 0;
     }
-    for (int e = lo + tid; e < hi; e += HM_T) t[e] = e;   // new elements: timestamp = insertion rank
     __syncthreads();
-    for (int e = tid; e < hi; e += HM_T) {
-      const int bb = static_cast<int>(key[e] % static_cast<uint64_t>(nb64));
-      bk[e] = bb;
-      atomicMin(&gmin[bb], t[e]);
-      atomicAdd(&cnt[bb], 1);
-      at[e] = 0;
+    // pass A: bucket of every element; per bucket the earliest member (group creation time) and the member count.  The
+    // counting atomic returns the element's arrival index inside its bucket (its slot in the member list, pass C).
+    for (int e0 = tid; e0 < hi; e0 += HU * HM_T) {
+      uint64_t kk[HU];
+      int tt[HU];
+#pragma unroll
+      for (int k = 0; k < HU; ++k) {
+        const int e = e0 + k * HM_T;
+        if (e < hi) {
+          kk[k] = key[e];
+          tt[k] = e >= lo ? e : t[e];            // new elements: timestamp = insertion rank
+        }
+      }
+      int bb[HU], arr[HU];
+#pragma unroll
+      for (int k = 0; k < HU; ++k) {
+        const int e = e0 + k * HM_T;
+        if (e < hi) {
+          bb[k] = hm_bucket(kk[k], static_cast<uint64_t>(nb64), inv_nb);
+          atomicMin(&gmin[bb[k]], tt[k]);
+          arr[k] = atomicAdd(&cnt[bb[k]], 1);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < HU; ++k) {
+        const int e = e0 + k * HM_T;
+        if (e < hi) {
+          bk[e] = bb[k];
+          if (e >= lo) t[e] = e;
+          at[e] = 0;
+          arrv[e] = arr[k];
+        }
+      }
     }
     __syncthreads();
-    // group sizes keyed by the group's creation time
-    for (int i = tid; i < nb; i += HM_T) {
-      const int c = cnt[i];
-      if (c > 0) at[gmin[i]] = c;
-      start[i] = c;
+    // pass B: group sizes keyed by the group's creation time
+    for (int i0 = tid; i0 < nb; i0 += HU * HM_T) {
+      int c[HU], g[HU];
+#pragma unroll
+      for (int k = 0; k < HU; ++k) {
+        const int i = i0 + k * HM_T;
+        if (i < nb) {
+          c[k] = cnt[i];
+          g[k] = gmin[i];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < HU; ++k) {
+        const int i = i0 + k * HM_T;
+        if (i < nb) {
+          if (c[k] > 0) at[g[k]] = c[k];
+          start[i] = c[k];
+        }
+      }
     }
     __syncthreads();
     hm_scan_inplace<true>(at, hi, lds);     // at[tt] = number of elements in groups created AFTER time tt
     hm_scan_inplace<false>(start, nb, lds);  // member-list offsets per bucket
-    for (int e = tid; e < hi; e += HM_T) {
-      const int bb = bk[e];
-      const int slot = start[bb] + atomicSub(&cnt[bb], 1) - 1;
-      mem[slot] = e;
+    // pass C: member lists (timestamps), and per bucket the list position of its group (replaces gmin)
+    for (int e0 = tid; e0 < hi; e0 += HU * HM_T) {
+      int bb[HU], tt[HU], ar[HU], s0[HU];
+#pragma unroll
+      for (int k = 0; k < HU; ++k) {
+        const int e = e0 + k * HM_T;
+        if (e < hi) {
+          bb[k] = bk[e];
+          tt[k] = t[e];
+          ar[k] = arrv[e];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < HU; ++k) {
+        const int e = e0 + k * HM_T;
+        if (e < hi) s0[k] = start[bb[k]];
+      }
+#pragma unroll
+      for (int k = 0; k < HU; ++k) {
+        const int e = e0 + k * HM_T;
+        if (e < hi) memt[s0[k] + ar[k]] = tt[k];
+      }
+    }
+    for (int i0 = tid; i0 < nb; i0 += HU * HM_T) {
+      int g[HU];
+#pragma unroll
+      for (int k = 0; k < HU; ++k) {
+        const int i = i0 + k * HM_T;
+        g[k] = i < nb ? gmin[i] : 0x7fffffff;
+      }
+#pragma unroll
+      for (int k = 0; k < HU; ++k) {
+        const int i = i0 + k * HM_T;
+        if (i < nb && g[k] != 0x7fffffff) gmin[i] = at[g[k]];
+      }
     }
     __syncthreads();
-    for (int e = tid; e < hi; e += HM_T) {
-      const int bb = bk[e];
-      const int te = t[e];
-      const int s0 = start[bb];
-      const int s1 = (bb + 1 < nb) ? start[bb + 1] : hi;
-      int r = 0;
-      for (int s = s0; s < s1; ++s) r += t[mem[s]] > te;   // newer members of the bucket come first
-      bk[e] = at[gmin[bb]] + r;                              // position in the list after this phase
+    // pass D: new list position = (elements of groups created later) + (newer members of the own bucket)
+    for (int e0 = tid; e0 < hi; e0 += HU * HM_T) {
+      int bb[HU], te[HU], s0[HU], s1[HU], a0[HU], r[HU];
+#pragma unroll
+      for (int k = 0; k < HU; ++k) {
+        const int e = e0 + k * HM_T;
+        bb[k] = 0;
+        te[k] = 0;
+        if (e < hi) {
+          bb[k] = bk[e];
+          te[k] = t[e];
+        }
+      }
+      int maxlen = 0;
+#pragma unroll
+      for (int k = 0; k < HU; ++k) {
+        const int e = e0 + k * HM_T;
+        s0[k] = s1[k] = a0[k] = 0;
+        if (e < hi) {
+          s0[k] = start[bb[k]];
+          s1[k] = (bb[k] + 1 < nb) ? start[bb[k] + 1] : hi;
+          a0[k] = gmin[bb[k]];
+        }
+        r[k] = 0;
+      }
+#pragma unroll
+      for (int k = 0; k < HU; ++k) maxlen = max(maxlen, s1[k] - s0[k]);
+      for (int j = 0; j < maxlen; ++j) {        // buckets hold one or two elements almost always
+#pragma unroll
+        for (int k = 0; k < HU; ++k)
+          if (s0[k] + j < s1[k]) r[k] += memt[s0[k] + j] > te[k];   // newer members of the bucket come first
+      }
+#pragma unroll
+      for (int k = 0; k < HU; ++k) {
+        const int e = e0 + k * HM_T;
+        if (e < hi) bk[e] = a0[k] + r[k];        // position in the list after this phase
+      }
     }
     __syncthreads();
-    for (int e = tid; e < hi; e += HM_T) t[e] = bk[e];
-    __syncthreads();
+    int32_t* sw = t;                             // the new positions become the next phase's timestamps
+    t = bk;
+    bk = sw;
     lo = hi;
     if (hi >= n) break;
   }
@@ -472,7 +606,7 @@ extern "C" int lcr_grid_subsample_ex(const float* xyz, const int64_t* len, int B
   if (rc) return rc;
   hipLaunchKernelGGL(k_gs_offsets, dim3(1), dim3(64), 0, st, L.hdr, L.head, out_len);
   hipLaunchKernelGGL(k_gs_insertion, dim3(nblk), dim3(256), 0, st, L.hdr, L.first, L.seg_key, L.seg_first, L.ins_key, L.ins_seg);
-  hipLaunchKernelGGL(k_gs_hashorder, dim3(B), dim3(HM_T), 0, st, L.hdr, L.ins_key, L.ins_seg, L.bary, L.hm_t, L.hm_bk, L.hm_mem, L.hm_at,
+  hipLaunchKernelGGL(k_gs_hashorder, dim3(B), dim3(HM_T), 0, st, L.hdr, L.ins_key, L.ins_seg, L.bary, L.hm_t, L.hm_bk, L.hm_mem, L.hm_at, L.hm_arr,
                      L.hm_gmin, L.hm_cnt, L.hm_start, out_xyz);
   return check_launch("lcr_grid_subsample");
 }

@@ -1,0 +1,199 @@
+// precompute.hip — a-3: the whole `precompute_data_stack_mode` of one batch (experiments/lcrnet/data.py:10-74) behind ONE C call.
+//
+// The reference runs this collate in DataLoader worker processes (utils/utils/torch.py:48-77).  On the GPU it is a chain of
+// ~250 short dependent launches (3 grid subsamples, 4 support grids, 10 radius searches) plus a read-back of the voxel counts;
+// driving that chain from Python costs more host time than the kernels take and fights the encoder's launching thread for
+// the interpreter lock.  Here the chain is issued natively, fork-join over side streams:
+//
+//   main   : subsample 1 ──► subsample 2 ──► subsample 3 ───────────────────────────────► join ► lengths D2H ► sync
+//   side i : (points i ready) grid i ► order i ► neighbors[i] ► upsampling[i-1] ► (points i+1 ready) subsampling[i]
+//
+// so a stage's grid build and searches overlap the next stage's subsampling.  Results land in one caller-provided arena whose
+// layout lcr_precompute_layout reports; capacities are bounded by the stage-0 point count (every stage is a subset sample).
+#include <cstring>
+
+#include "common.h"
+
+namespace lcr {
+
+struct PreCtx {
+  hipStream_t side[LCR_MAX_STAGES] = {};
+  hipEvent_t  ready[LCR_MAX_STAGES] = {};
+  hipEvent_t  done[LCR_MAX_STAGES] = {};
+  int64_t*    pinned = nullptr;      // [LCR_MAX_STAGES * 64 + 8] host staging of the device-side lengths + status
+  int         device = -1;
+  bool        ok = false;
+};
+
+static PreCtx& pre_ctx() {
+  static thread_local PreCtx c;      // one set of side streams per host thread that drives pre-processing
+  int dev = 0;
+  hipGetDevice(&dev);
+  if (!c.ok || c.device != dev) {
+    for (int i = 0; i < LCR_MAX_STAGES; ++i) {
+      hipStreamCreateWithFlags(&c.side[i], hipStreamNonBlocking);
+      hipEventCreateWithFlags(&c.ready[i], hipEventDisableTiming);
+      hipEventCreateWithFlags(&c.done[i], hipEventDisableTiming);
+    }
+    hipHostMalloc(reinterpret_cast<void**>(&c.pinned), sizeof(int64_t) * (LCR_MAX_STAGES * 64 + 8), hipHostMallocDefault);
+    c.device = dev;
+    c.ok = true;
+  }
+  return c;
+}
+
+struct PreWs {
+  uint32_t* status;                       // [1] shared device status word
+  void*     sub_ws[LCR_MAX_STAGES];       // workspace of the subsample that PRODUCES stage i (i >= 1)
+  size_t    sub_bytes[LCR_MAX_STAGES];
+  void*     grid_ws[LCR_MAX_STAGES];
+  size_t    grid_bytes[LCR_MAX_STAGES];
+  size_t    bytes;
+};
+
+static int carve_ws(void* ws, const LcrPrecomputeLayout& L, PreWs* W) {
+  Carver c(ws, ~size_t(0));
+  W->status = c.take<uint32_t>(64);
+  for (int i = 0; i < L.num_stages; ++i) {
+    W->sub_ws[i] = nullptr;
+    W->sub_bytes[i] = 0;
+    if (i > 0) {
+      int rc = lcr_grid_subsample_ws_bytes(L.cap[i - 1], L.B, &W->sub_bytes[i]);
+      if (rc) return rc;
+      W->sub_ws[i] = c.take<char>(W->sub_bytes[i]);
+    }
+    int rc = lcr_support_grid_ws_bytes(L.cap[i], L.B, &W->grid_bytes[i]);
+    if (rc) return rc;
+    W->grid_ws[i] = c.take<char>(W->grid_bytes[i]);
+  }
+  W->bytes = c.off;
+  return LCR_OK;
+}
+
+}  // namespace lcr
+
+using namespace lcr;
+
+extern "C" int lcr_precompute_layout(int64_t n0, int B, int num_stages, const int* limits, int upsampling, LcrPrecomputeLayout* L) {
+  if (!L || !limits || n0 < 0 || B < 1 || B > 64 || num_stages < 1 || num_stages > LCR_MAX_STAGES) {
+    set_error("lcr_precompute_layout: bad argument (B <= 64, stages <= %d)", LCR_MAX_STAGES);
+    return LCR_EARG;
+  }
+  std::memset(L, 0, sizeof(*L));
+  L->num_stages = num_stages;
+  L->B = B;
+  L->upsampling = upsampling ? 1 : 0;
+  const int64_t cap = n0 > 0 ? n0 : 1;
+  Carver c(nullptr, ~size_t(0));
+  for (int i = 0; i < num_stages; ++i) {
+    if (limits[i] < 1) {
+      set_error("lcr_precompute_layout: neighbor limits must be >= 1");
+      return LCR_EARG;
+    }
+    L->limits[i] = limits[i];
+    L->cap[i] = cap;
+  }
+  for (int i = 0; i < num_stages; ++i) {
+    L->off_points[i] = i > 0 ? c.off : 0;
+    if (i > 0) c.take<float>(3 * cap);
+    L->off_lengths[i] = i > 0 ? c.off : 0;
+    if (i > 0) c.take<int64_t>(B);
+    L->off_order[i] = c.off;
+    c.take<int32_t>(cap);
+    L->off_neighbors[i] = c.off;
+    c.take<int32_t>(cap * limits[i]);
+    if (i + 1 < num_stages) {
+      L->off_subsampling[i] = c.off;
+      c.take<int32_t>(cap * limits[i]);
+      if (upsampling) {
+        L->off_upsampling[i] = c.off;
+        c.take<int32_t>(cap * limits[i + 1]);
+      }
+    }
+  }
+  L->out_bytes = c.off;
+  PreWs W;
+  int rc = carve_ws(nullptr, *L, &W);
+  if (rc) return rc;
+  L->ws_bytes = W.bytes;
+  return LCR_OK;
+}
+
+extern "C" int lcr_precompute_batch(const float* points0, const int64_t* lengths0, const LcrPrecomputeLayout* L, float voxel_size,
+                                    float radius, int key_bits_hint, void* out, size_t out_bytes, void* ws, size_t ws_bytes,
+                                    int64_t* lengths_host, uint32_t* status_host, void* stream) {
+  if (!points0 || !lengths0 || !L || !out || !ws || !lengths_host || !status_host || !(voxel_size > 0.f) || !(radius > 0.f)) {
+    set_error("lcr_precompute_batch: bad argument");
+    return LCR_EARG;
+  }
+  if (out_bytes < L->out_bytes || ws_bytes < L->ws_bytes) {
+    set_error("lcr_precompute_batch: arena too small (out %zu < %zu or ws %zu < %zu)", out_bytes, L->out_bytes, ws_bytes, L->ws_bytes);
+    return LCR_ESPACE;
+  }
+  const int S = L->num_stages, B = L->B;
+  PreWs W;
+  int rc = carve_ws(ws, *L, &W);
+  if (rc) return rc;
+  PreCtx& C = pre_ctx();
+  hipStream_t main = static_cast<hipStream_t>(stream);
+  char* o = static_cast<char*>(out);
+  const float* pts[LCR_MAX_STAGES];
+  const int64_t* lens[LCR_MAX_STAGES];
+  pts[0] = points0;
+  lens[0] = lengths0;
+  for (int i = 1; i < S; ++i) {
+    pts[i] = reinterpret_cast<const float*>(o + L->off_points[i]);
+    lens[i] = reinterpret_cast<const int64_t*>(o + L->off_lengths[i]);
+  }
+  auto i32 = [&](size_t off) { return reinterpret_cast<int32_t*>(o + off); };
+
+  hipMemsetAsync(W.status, 0, sizeof(uint32_t) * 64, main);
+  float v = voxel_size, r = radius;
+  float radii[LCR_MAX_STAGES];
+  for (int i = 0; i < S; ++i) {
+    if (i > 0) {
+      v *= 2.f;
+      rc = lcr_grid_subsample_ex(pts[i - 1], lens[i - 1], B, L->cap[i - 1], v, key_bits_hint, const_cast<float*>(pts[i]),
+                                 const_cast<int64_t*>(lens[i]), W.status, W.sub_ws[i], W.sub_bytes[i], main);
+      if (rc) return rc;
+    }
+    radii[i] = r;
+    hipEventRecord(C.ready[i], main);
+    hipStream_t s = C.side[i];
+    hipStreamWaitEvent(s, C.ready[i], 0);
+    rc = lcr_support_grid_build(pts[i], lens[i], B, L->cap[i], r, W.status, W.grid_ws[i], W.grid_bytes[i], s);
+    if (rc) return rc;
+    rc = lcr_support_grid_order(W.grid_ws[i], L->cap[i], B, i32(L->off_order[i]), s);
+    if (rc) return rc;
+    rc = lcr_radius_query(pts[i], lens[i], B, L->cap[i], W.grid_ws[i], L->cap[i], r, L->limits[i], nullptr, i32(L->off_neighbors[i]),
+                          nullptr, s);
+    if (rc) return rc;
+    if (i > 0 && L->upsampling) {
+      rc = lcr_radius_query(pts[i - 1], lens[i - 1], B, L->cap[i - 1], W.grid_ws[i], L->cap[i], r, L->limits[i], nullptr,
+                            i32(L->off_upsampling[i - 1]), nullptr, s);
+      if (rc) return rc;
+    }
+    if (i > 0) {
+      hipStream_t sp = C.side[i - 1];
+      hipStreamWaitEvent(sp, C.ready[i], 0);
+      rc = lcr_radius_query(pts[i], lens[i], B, L->cap[i], W.grid_ws[i - 1], L->cap[i - 1], radii[i - 1], L->limits[i - 1], nullptr,
+                            i32(L->off_subsampling[i - 1]), nullptr, sp);
+      if (rc) return rc;
+    }
+    r *= 2.f;
+  }
+  for (int i = 0; i < S; ++i) {
+    hipEventRecord(C.done[i], C.side[i]);
+    hipStreamWaitEvent(main, C.done[i], 0);
+  }
+  for (int i = 0; i < S; ++i) hipMemcpyAsync(C.pinned + i * 64, lens[i], sizeof(int64_t) * B, hipMemcpyDeviceToHost, main);
+  hipMemcpyAsync(C.pinned + LCR_MAX_STAGES * 64, W.status, sizeof(uint32_t), hipMemcpyDeviceToHost, main);
+  hipError_t e = hipStreamSynchronize(main);
+  if (e != hipSuccess) {
+    set_error("lcr_precompute_batch: %s", hipGetErrorString(e));
+    return LCR_EHIP;
+  }
+  for (int i = 0; i < S; ++i) std::memcpy(lengths_host + static_cast<size_t>(i) * B, C.pinned + i * 64, sizeof(int64_t) * B);
+  std::memcpy(status_host, C.pinned + LCR_MAX_STAGES * 64, sizeof(uint32_t));
+  return check_launch("lcr_precompute_batch");
+}

@@ -8,8 +8,11 @@ Two entry points:
   * precompute_batch(...)            — the throughput path: capacity buffers + device-side lengths, the 4 support grids
     shared by the 10 searches (7 if the decoder-only upsampling lists are skipped), int32 indices, ONE host sync at the end.
 """
+import ctypes
+
 import torch
 
+from . import _lib
 from .modules.ops import SupportGrid, grid_subsample, grid_subsample_device, radius_search
 
 STATUS_KEY_OVERFLOW = 1
@@ -39,8 +42,62 @@ def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, 
             "subsampling": subsampling_list, "upsampling": upsampling_list}
 
 
+MAX_STAGES = 8
+
+
+class PrecomputeLayout(ctypes.Structure):
+    """Mirror of LcrPrecomputeLayout (include/lcr_hip.h)."""
+    _fields_ = [("num_stages", ctypes.c_int), ("B", ctypes.c_int), ("upsampling", ctypes.c_int),
+                ("limits", ctypes.c_int * MAX_STAGES), ("cap", ctypes.c_int64 * MAX_STAGES),
+                ("off_points", ctypes.c_size_t * MAX_STAGES), ("off_lengths", ctypes.c_size_t * MAX_STAGES),
+                ("off_order", ctypes.c_size_t * MAX_STAGES), ("off_neighbors", ctypes.c_size_t * MAX_STAGES),
+                ("off_subsampling", ctypes.c_size_t * MAX_STAGES), ("off_upsampling", ctypes.c_size_t * MAX_STAGES),
+                ("out_bytes", ctypes.c_size_t), ("ws_bytes", ctypes.c_size_t)]
+
+
+def precompute_batch_native(points, lengths, num_stages, voxel_size, radius, neighbor_limits, upsampling=True, key_bits_hint=32):
+    """precompute_batch as ONE native call (csrc/precompute.hip): same dictionary, int32 indices.  The ~250 launches and the
+    length read-back are issued by C++ (fork-join over side streams) with the interpreter lock released throughout."""
+    _lib.require_cuda(points, lengths)
+    assert points.dtype == torch.float32 and points.is_contiguous() and lengths.dtype == torch.int64 and num_stages == len(neighbor_limits)
+    dev = points.device
+    lengths = lengths.contiguous()
+    n0, B, S = points.shape[0], lengths.numel(), num_stages
+    L = _lib.lib()
+    lay = PrecomputeLayout()
+    lim = (ctypes.c_int * S)(*[int(x) for x in neighbor_limits])
+    _lib.check(L.lcr_precompute_layout(n0, B, S, ctypes.cast(lim, ctypes.c_void_p), int(bool(upsampling)), ctypes.addressof(lay)),
+               "lcr_precompute_layout")
+    out = torch.empty(max(lay.out_bytes, 256), dtype=torch.uint8, device=dev)
+    ws = torch.empty(max(lay.ws_bytes, 256), dtype=torch.uint8, device=dev)
+    lens_host = (ctypes.c_int64 * (S * B))()
+    status = ctypes.c_uint32(0)
+    _lib.check(L.lcr_precompute_batch(_lib.ptr(points), _lib.ptr(lengths), ctypes.addressof(lay), float(voxel_size), float(radius),
+                                      int(key_bits_hint), _lib.ptr(out), out.numel(), _lib.ptr(ws), ws.numel(),
+                                      ctypes.addressof(lens_host), ctypes.addressof(status), _lib.stream_ptr(dev)), "lcr_precompute_batch")
+    st = status.value
+    if st & STATUS_KEY_OVERFLOW and key_bits_hint:
+        return precompute_batch_native(points, lengths, num_stages, voxel_size, radius, neighbor_limits, upsampling, 0)
+    if st:
+        raise RuntimeError("precompute_batch: device status 0x%x" % st)
+    lengths_host = [[int(lens_host[i * B + b]) for b in range(B)] for i in range(S)]
+    tot = [sum(l) for l in lengths_host]
+
+    def view(off, rows, cols, dtype, esize):
+        return out[off:off + rows * cols * esize].view(dtype).view(rows, cols)
+
+    pts = [points] + [view(lay.off_points[i], tot[i], 3, torch.float32, 4) for i in range(1, S)]
+    lens = [lengths] + [out[lay.off_lengths[i]:lay.off_lengths[i] + 8 * B].view(torch.int64) for i in range(1, S)]
+    orders = [out[lay.off_order[i]:lay.off_order[i] + 4 * tot[i]].view(torch.int32) for i in range(S)]
+    neighbors = [view(lay.off_neighbors[i], tot[i], lay.limits[i], torch.int32, 4) for i in range(S)]
+    subsampling = [view(lay.off_subsampling[i], tot[i + 1], lay.limits[i], torch.int32, 4) for i in range(S - 1)]
+    upsamp = [view(lay.off_upsampling[i], tot[i], lay.limits[i + 1], torch.int32, 4) for i in range(S - 1)] if upsampling else []
+    return {"order": orders, "points": pts, "lengths": lens, "neighbors": neighbors, "subsampling": subsampling, "upsampling": upsamp,
+            "lengths_host": lengths_host, "segment_lengths": lens}
+
+
 def precompute_batch(points, lengths, num_stages, voxel_size, radius, neighbor_limits, upsampling=True,
-                     index_dtype=torch.int32, key_bits_hint=32):
+                     index_dtype=torch.int32, key_bits_hint=32, native=True):
     """Same five lists as precompute_data_stack_mode for a stack of B clouds, plus:
          'lengths_host'    : list of python lists (per stage),
          'segment_lengths' : per-stage device int64 lengths (GroupNorm segments = clouds; regroup for pair semantics).
@@ -48,6 +105,9 @@ def precompute_batch(points, lengths, num_stages, voxel_size, radius, neighbor_l
     assert num_stages == len(neighbor_limits)
     dev = points.device
     lengths = lengths.to(dev)
+    if native and index_dtype == torch.int32:
+        return precompute_batch_native(points.contiguous(), lengths, num_stages, voxel_size, radius, neighbor_limits, upsampling,
+                                       key_bits_hint)
     pts, lens, statuses = [points.contiguous()], [lengths], []
     v = voxel_size
     for i in range(1, num_stages):
@@ -72,7 +132,7 @@ def precompute_batch(points, lengths, num_stages, voxel_size, radius, neighbor_l
     host = torch.stack(lens + [torch.cat([s.long() for s in statuses] + [g.status.long() for g in grids]).sum().expand(lengths.numel())]).cpu()
     status = int(host[-1][0])
     if status & STATUS_KEY_OVERFLOW and key_bits_hint:
-        return precompute_batch(points, lengths, num_stages, voxel_size, radius, neighbor_limits, upsampling, index_dtype, 0)
+        return precompute_batch(points, lengths, num_stages, voxel_size, radius, neighbor_limits, upsampling, index_dtype, 0, native)
     if status:
         raise RuntimeError("precompute_batch: device status 0x%x" % status)
     lengths_host = [host[i].tolist() for i in range(num_stages)]

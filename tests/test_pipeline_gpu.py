@@ -41,3 +41,24 @@ def test_overlapped_pipeline_matches_sequential():
         for i, n in enumerate(grp):
             want = torch.from_numpy(golden[f"{n}/anc_global"])[0]
             assert (d[i].cpu() - want).abs().max().item() < 1e-4
+
+
+def test_native_precompute_matches_python_path():
+    """lcr_precompute_batch (one native call, fork-join side streams) returns exactly the lists of the op-by-op Python path."""
+    from lcrnet_amd.data import precompute_batch
+    scans = [load_scan(n) for n in ["003854", "000958", "004481"]]
+    pts = torch.from_numpy(np.concatenate(scans)).cuda()
+    lens = torch.tensor([len(s) for s in scans], dtype=torch.int64, device="cuda")
+    limits = [74, 68, 70, 67]
+    for ups in (True, False):
+        for rep in range(3):                             # repeat: a missing stream dependency would show up as differences
+            a = precompute_batch(pts, lens, 4, 0.3, 1.275, limits, upsampling=ups, native=False)
+            b = precompute_batch(pts, lens, 4, 0.3, 1.275, limits, upsampling=ups, native=True)
+            torch.cuda.synchronize()
+            assert a["lengths_host"] == b["lengths_host"]
+            for key in ("points", "lengths", "neighbors", "subsampling", "upsampling"):
+                assert len(a[key]) == len(b[key])
+                for x, y in zip(a[key], b[key]):
+                    assert x.shape == y.shape and x.dtype == y.dtype and torch.equal(x, y), key
+            for x, y in zip(a["order"], b["order"]):      # cell-sorted order: same cells, order inside a cell is free
+                assert x.shape == y.shape and torch.equal(torch.sort(x.long())[0], torch.sort(y.long())[0])
