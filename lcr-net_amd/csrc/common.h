@@ -72,9 +72,10 @@ __device__ __forceinline__ float ord2f(uint32_t u) {
   return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
-// Per-cloud bounding boxes of stacked points with few atomics: every workgroup takes a contiguous chunk of rows; if the
-// chunk lies inside one cloud (the common case) it is reduced in registers -> shuffles -> LDS and costs 6 atomics per
-// workgroup, otherwise each lane falls back to its own atomics.  bb_* hold order-preserving encodings (f2ord).
+// Per-cloud bounding boxes of stacked points with few atomics: every workgroup takes a contiguous chunk of rows and, for
+// each cloud that intersects it (one, except for the B-1 chunks that straddle a boundary), reduces the rows in registers ->
+// shuffles -> LDS and issues 6 atomics.  (A per-row atomic fallback for the straddling chunks used to dominate the kernel:
+// same-address atomics serialise at ~0.4 us each.)  bb_* hold order-preserving encodings (f2ord).
 __device__ __forceinline__ void bbox_accumulate(const float* __restrict__ xyz, int64_t n, const int64_t* __restrict__ off, int B,
                                                 uint32_t (*bb_min)[3], uint32_t (*bb_max)[3]) {
   __shared__ uint32_t s_mn[16][3], s_mx[16][3];
@@ -83,51 +84,45 @@ __device__ __forceinline__ void bbox_accumulate(const float* __restrict__ xyz, i
   const int64_t hi = lo + chunk < n ? lo + chunk : n;
   if (lo >= hi) return;
   const int b_lo = cloud_of(off, B, lo), b_hi = cloud_of(off, B, hi - 1);
-  if (b_lo != b_hi) {
-    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-      const int b = cloud_of(off, B, i);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int b = b_lo; b <= b_hi; ++b) {          // block-uniform
+    const int64_t r0 = lo > off[b] ? lo : off[b];
+    const int64_t r1 = hi < off[b + 1] ? hi : off[b + 1];
+    uint32_t mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
+    for (int64_t i = r0 + threadIdx.x; i < r1; i += blockDim.x) {
+#pragma unroll
       for (int d = 0; d < 3; ++d) {
         const uint32_t u = f2ord(xyz[3 * i + d]);
-        atomicMin(&bb_min[b][d], u);
-        atomicMax(&bb_max[b][d], u);
+        mn[d] = u < mn[d] ? u : mn[d];
+        mx[d] = u > mx[d] ? u : mx[d];
       }
     }
-    return;
-  }
-  uint32_t mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
-  for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      const uint32_t u = f2ord(xyz[3 * i + d]);
-      mn[d] = u < mn[d] ? u : mn[d];
-      mx[d] = u > mx[d] ? u : mx[d];
-    }
-  }
 #pragma unroll
-  for (int d = 0; d < 3; ++d) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-      const uint32_t a = __shfl_xor(mn[d], s), c = __shfl_xor(mx[d], s);
-      mn[d] = a < mn[d] ? a : mn[d];
-      mx[d] = c > mx[d] ? c : mx[d];
+      for (int s = 32; s >= 1; s >>= 1) {
+        const uint32_t a = __shfl_xor(mn[d], s), c = __shfl_xor(mx[d], s);
+        mn[d] = a < mn[d] ? a : mn[d];
+        mx[d] = c > mx[d] ? c : mx[d];
+      }
     }
-  }
-  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  if ((threadIdx.x & 63) == 0)
-    for (int d = 0; d < 3; ++d) {
-      s_mn[w][d] = mn[d];
-      s_mx[w][d] = mx[d];
+    if ((threadIdx.x & 63) == 0)
+      for (int d = 0; d < 3; ++d) {
+        s_mn[w][d] = mn[d];
+        s_mx[w][d] = mx[d];
+      }
+    __syncthreads();
+    if (threadIdx.x < 3 && r0 < r1) {
+      const int d = threadIdx.x;
+      uint32_t a = s_mn[0][d], c = s_mx[0][d];
+      for (int k = 1; k < nw; ++k) {
+        a = s_mn[k][d] < a ? s_mn[k][d] : a;
+        c = s_mx[k][d] > c ? s_mx[k][d] : c;
+      }
+      atomicMin(&bb_min[b][d], a);
+      atomicMax(&bb_max[b][d], c);
     }
-  __syncthreads();
-  if (threadIdx.x < 3) {
-    const int d = threadIdx.x;
-    uint32_t a = s_mn[0][d], c = s_mx[0][d];
-    for (int k = 1; k < nw; ++k) {
-      a = s_mn[k][d] < a ? s_mn[k][d] : a;
-      c = s_mx[k][d] > c ? s_mx[k][d] : c;
-    }
-    atomicMin(&bb_min[b_lo][d], a);
-    atomicMax(&bb_max[b_lo][d], c);
+    __syncthreads();
   }
 }
 
@@ -153,5 +148,8 @@ __device__ __forceinline__ T wave_sum(T v) {
 // ws needs scan_ws_bytes(n) bytes.
 size_t scan_ws_bytes(int64_t n);
 int exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int64_t* total, void* ws, hipStream_t st);
+// same, over min(n, *n_dev + n_add) entries (n_dev: device-side count; launches are sized for n and exit early beyond it)
+int exclusive_scan_i32_dev(const int32_t* in, int32_t* out, int64_t n, const int32_t* n_dev, int n_add, int64_t* total, void* ws,
+                           hipStream_t st);
 
 }  // namespace lcr

@@ -589,7 +589,8 @@ extern "C" int lcr_grid_subsample_ex(const float* xyz, const int64_t* len, int B
     hipLaunchKernelGGL(k_gs_offsets, dim3(1), dim3(64), 0, st, L.hdr, static_cast<const int32_t*>(nullptr), out_len);
     return check_launch("lcr_grid_subsample");
   }
-  hipLaunchKernelGGL(k_gs_bbox, dim3(nblk), dim3(256), 0, st, L.hdr, xyz);
+  // one workgroup per CU at most: every workgroup ends with 6 atomics on its cloud's box, and same-address atomics serialise
+  hipLaunchKernelGGL(k_gs_bbox, dim3(n_cap > 0 ? min(div_up(n_cap, 1024), 512) : 1), dim3(256), 0, st, L.hdr, xyz);
   hipLaunchKernelGGL(k_gs_params, dim3(1), dim3(64), 0, st, L.hdr, voxel, inv_voxel, key_bits_hint, status);
   hipLaunchKernelGGL(k_gs_keys, dim3(nblk), dim3(256), 0, st, L.hdr, xyz, voxel, L.keyA, L.valA, status);
   const int max_passes = key_bits_hint > 0 ? (key_bits_hint + 7) / 8 : 8;

@@ -147,6 +147,13 @@ __device__ __forceinline__ int cell_coord(double p, double org, double inv_cell,
   return static_cast<int>(c);
 }
 
+__global__ __launch_bounds__(256) void k_grid_zero(const GridHeader* __restrict__ h, int32_t* __restrict__ cell_cnt) {
+  const int64_t n = static_cast<int64_t>(h->n_cells) + 1;
+  int4* c4 = reinterpret_cast<int4*>(cell_cnt);            // workspace slices are 256-B aligned; the tail beyond n is scratch
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i * 4 < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    c4[i] = make_int4(0, 0, 0, 0);
+}
+
 __global__ __launch_bounds__(256) void k_grid_count(GridHeader* h, const float* __restrict__ s, int32_t* __restrict__ cell_cnt,
                                                     int32_t* __restrict__ pt_cell) {
   const int B = h->B;
@@ -360,13 +367,15 @@ extern "C" int lcr_support_grid_build(const float* s, const int64_t* slen, int B
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int64_t cell_cap = CELL_PER_PT * ns_cap + static_cast<int64_t>(CELL_MIN) * B;
-  hipMemsetAsync(L.cell_cnt, 0, sizeof(int32_t) * cell_cap, st);
   hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, st, L.hdr, slen, B, ns_cap, cell_cap, status);
   const int nblk = ns_cap > 0 ? min(div_up(ns_cap, 256), 2048) : 1;
-  hipLaunchKernelGGL(k_grid_bbox, dim3(nblk), dim3(256), 0, st, L.hdr, s);
+  hipLaunchKernelGGL(k_grid_bbox, dim3(ns_cap > 0 ? min(div_up(ns_cap, 1024), 512) : 1), dim3(256), 0, st, L.hdr, s);   // few workgroups: 6 same-address atomics each
   hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(64), 0, st, L.hdr, radius);
+  // only the n_cells (device-side) cells in use are zeroed and scanned: the capacity is 32 cells per point SLOT, and the
+  // coarse stages fill a small part of it
+  hipLaunchKernelGGL(k_grid_zero, dim3(min(div_up(cell_cap + 1, 1024), 2048)), dim3(256), 0, st, L.hdr, L.cell_cnt);
   hipLaunchKernelGGL(k_grid_count, dim3(nblk), dim3(256), 0, st, L.hdr, s, L.cell_cnt, L.pt_cell);
-  int rc = exclusive_scan_i32(L.cell_cnt, L.cell_start, cell_cap + 1, nullptr, L.scan_ws, st);
+  int rc = exclusive_scan_i32_dev(L.cell_cnt, L.cell_start, cell_cap + 1, &L.hdr->n_cells, 1, nullptr, L.scan_ws, st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_grid_scatter, dim3(nblk), dim3(256), 0, st, L.hdr, s, L.cell_cnt, L.cell_start, L.pt_cell, L.sorted);
   return check_launch("lcr_support_grid_build");
