@@ -33,18 +33,42 @@ __device__ __forceinline__ int seg_of(const int64_t* __restrict__ seg_len, int S
 // Flat float4 mapping: thread t handles 4 consecutive channels of one row (C % 4 == 0), so loads/stores are 16-B vectors and
 // all 64 lanes are busy for every C.  Row flags (pos) are reduced across the C/4 lanes of a row (C <= 256).
 constexpr int GN_TABLE = 2048;   // (segment, group) pairs whose mean / rstd fit the LDS table
+constexpr int GN_MAX_SEG = 256;  // segments per call
 
 template <bool POS>
 __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, GnSide gx, const float* __restrict__ res, GnSide gr,
                                                   float* __restrict__ y, int64_t N, int C, int groups, const int64_t* __restrict__ seg_len, int S,
                                                   float eps, float slope, int act, uint8_t* __restrict__ pos) {
-  __shared__ float2 s_x[GN_TABLE], s_r[GN_TABLE];   // (mean, rstd) per (segment, group): the fp64 finalisation runs once per block
+  // Every workgroup owns a CONTIGUOUS range of rows, so it touches one segment (two or three at scan boundaries) and only
+  // folds the statistics replicas of those: (mean, rstd) per (segment, group) of the range, finalised in fp64 once per block.
+  __shared__ float2 s_x[GN_TABLE], s_r[GN_TABLE];
+  __shared__ int64_t s_start[GN_MAX_SEG + 1];       // first row of every segment (prefix of seg_len)
   const int gs = C / groups;
-  for (int i = threadIdx.x; i < S * groups; i += blockDim.x) {
-    const double cnt = static_cast<double>(seg_len[i / groups]) * gs;
+  const int c4n = C >> 2;                           // float4 pieces per row
+  const int64_t rows_per_blk = (N + gridDim.x - 1) / gridDim.x;
+  const int64_t row_lo = static_cast<int64_t>(blockIdx.x) * rows_per_blk;
+  const int64_t row_hi = min(row_lo + rows_per_blk, N);
+  if (row_lo >= row_hi) return;
+  if (threadIdx.x == 0) {
+    int64_t o = 0;
+    for (int i = 0; i < S; ++i) {
+      s_start[i] = o;
+      o += seg_len[i];
+    }
+    s_start[S] = o;
+  }
+  __syncthreads();
+  int seg_lo = 0, seg_hi = 0;                        // segments of the first / last row (the last segment absorbs rows beyond the sum)
+  while (seg_lo + 1 < S && row_lo >= s_start[seg_lo + 1]) ++seg_lo;
+  seg_hi = seg_lo;
+  while (seg_hi + 1 < S && row_hi - 1 >= s_start[seg_hi + 1]) ++seg_hi;
+  const int nseg = seg_hi - seg_lo + 1;
+  for (int i = threadIdx.x; i < nseg * groups; i += blockDim.x) {
+    const int sg = seg_lo + i / groups, g = i - (i / groups) * groups;
+    const double cnt = static_cast<double>(seg_len[sg]) * gs;
     double sx = 0.0, sxx = 0.0, rx = 0.0, rxx = 0.0;
     for (int rep = 0; rep < GN_REPLICAS; ++rep) {     // fold the statistics replicas (fixed order: deterministic given the sums)
-      const int64_t o = (static_cast<int64_t>(rep) * S * groups + i) * 2;
+      const int64_t o = ((static_cast<int64_t>(rep) * S + sg) * groups + g) * 2;
       sx += gx.stats[o];
       sxx += gx.stats[o + 1];
       if (gr.stats) {
@@ -62,15 +86,13 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, G
     }
   }
   __syncthreads();
-  const int c4n = C >> 2;                         // float4 pieces per row
-  const int64_t total = N * c4n;
-  for (int64_t t = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; t < ((total + 63) & ~int64_t(63));
-       t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-    const bool live = t < total;
-    const int64_t n = live ? t / c4n : N - 1;
+  const int64_t t_lo = row_lo * c4n, t_hi = row_hi * c4n;
+  for (int64_t t = t_lo + threadIdx.x; t < ((t_hi - t_lo + 63) & ~int64_t(63)) + t_lo; t += blockDim.x) {
+    const bool live = t < t_hi;
+    const int64_t n = live ? t / c4n : row_hi - 1;
     const int c0 = live ? static_cast<int>(t - n * c4n) * 4 : 0;
-    int64_t slen;
-    const int s = seg_of(seg_len, S, n, &slen);
+    int s = seg_lo;
+    while (s < seg_hi && n >= s_start[s + 1]) ++s;
     const float4 xv = *reinterpret_cast<const float4*>(x + n * C + c0);
     const float4 gam = *reinterpret_cast<const float4*>(gx.gamma + c0);
     const float4 bet = *reinterpret_cast<const float4*>(gx.beta + c0);
@@ -86,7 +108,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, G
     float rowsum = 0.f;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int gi = s * groups + (c0 + u) / gs;
+      const int gi = (s - seg_lo) * groups + (c0 + u) / gs;
       const float2 mr = s_x[gi];
       float v = (xin[u] - mr.x) * mr.y * g4[u] + b4[u];
       if (res) {
@@ -169,8 +191,8 @@ extern "C" int lcr_groupnorm_apply(const float* x, const double* stats, const fl
   }
   if (N == 0) return LCR_OK;
   GnSide gx{stats, gamma, beta}, gr{res_stats, res_gamma, res_beta};
-  if (C % 4 != 0 || S * groups > GN_TABLE) {
-    set_error("lcr_groupnorm_apply: C must be a multiple of 4 and S*groups <= %d", GN_TABLE);
+  if (C % 4 != 0 || S * groups > GN_TABLE || S > GN_MAX_SEG) {
+    set_error("lcr_groupnorm_apply: C must be a multiple of 4, S*groups <= %d and S <= %d", GN_TABLE, GN_MAX_SEG);
     return LCR_EARG;
   }
   const int c4n = C / 4;
@@ -178,7 +200,8 @@ extern "C" int lcr_groupnorm_apply(const float* x, const double* stats, const fl
     set_error("lcr_groupnorm_apply: row flags need C/4 to be a power of two <= 64");
     return LCR_EARG;
   }
-  const int nblk = static_cast<int>(std::min<int64_t>((N * c4n + 255) / 256, 256 * 16));
+  // contiguous row ranges per workgroup, >= 2048 float4 pieces each (the per-block statistics fold is amortised over them)
+  const int nblk = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((N * c4n + 2047) / 2048, 256 * 8)));
   if (pos)
     hipLaunchKernelGGL((k_gn_apply<true>), dim3(nblk), dim3(256), 0, static_cast<hipStream_t>(stream), x, gx, res, gr, y, N, C, groups, seg_len,
                        S, eps, slope, act, pos);

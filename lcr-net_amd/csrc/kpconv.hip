@@ -390,19 +390,28 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_cin1(const float* __re
                                                                const int32_t* __restrict__ order) {
   __shared__ float s_a[KP_WAVES][16];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // this lane's output channel(s): the (15, Cout) weights and the bias stay in registers for every query of the wavefront
+  constexpr int MAXO = 4;                       // Cout <= 256
+  float wreg[MAXO][KP_K], breg[MAXO];
+#pragma unroll
+  for (int q = 0; q < MAXO; ++q) {
+    const int o = lane + 64 * q;
+    breg[q] = (bias && o < Cout) ? bias[o] : 0.f;
+#pragma unroll
+    for (int k = 0; k < KP_K; ++k) wreg[q][k] = o < Cout ? W[k * Cout + o] : 0.f;
+  }
   for (int64_t t = static_cast<int64_t>(blockIdx.x) * KP_WAVES + w; t < M; t += static_cast<int64_t>(gridDim.x) * KP_WAVES) {
     const int64_t m = order ? order[t] : t;
     const float qx = q_pts[3 * m], qy = q_pts[3 * m + 1], qz = q_pts[3 * m + 2];
     const float inv_sigma = 1.f / sigma;
-    float a[KP_K];
+    float a[16];
 #pragma unroll
-    for (int k = 0; k < KP_K; ++k) a[k] = 0.f;
-    int cnt = 0;
+    for (int k = 0; k < 16; ++k) a[k] = 0.f;
     for (int h = lane; h < H; h += 64) {
       const int64_t j = static_cast<int64_t>(idx[m * H + h]);
       if (j >= 0 && j < Ns) {
         const float f = s_feats[j];
-        cnt += f > 0.f ? 1 : 0;
+        a[15] += f > 0.f ? 1.f : 0.f;            // neighbour count rides along as the 16th value (exact: small integers)
         const float dx = s_pts[3 * j + 0] - qx, dy = s_pts[3 * j + 1] - qy, dz = s_pts[3 * j + 2] - qz;
 #pragma unroll
         for (int k = 0; k < KP_K; ++k) {
@@ -411,21 +420,40 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_cin1(const float* __re
         }
       }
     }
-    cnt = wave_sum(cnt);
+    // reduce-scatter of the 16 per-lane partials over the wavefront: each exchange halves the values a lane is responsible
+    // for (8 + 4 + 2 + 1 exchanges, then two plain ones) instead of 16 full six-step reductions.  Lane l ends with the total
+    // of value k(l) = bits 5..2 of l (bit 5 = 8, bit 4 = 4, bit 3 = 2, bit 2 = 1).
+    {
+      const bool u5 = lane & 32, u4 = lane & 16, u3 = lane & 8, u2 = lane & 4;
+      float b8[8], b4[4], b2[2], b1;
 #pragma unroll
-    for (int k = 0; k < KP_K; ++k) {
-      const float s = wave_sum(a[k]);
-      if (lane == 0) s_a[w][k] = s;
+      for (int i = 0; i < 8; ++i) b8[i] = (u5 ? a[i + 8] : a[i]) + __shfl_xor(u5 ? a[i] : a[i + 8], 32);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b4[i] = (u4 ? b8[i + 4] : b8[i]) + __shfl_xor(u4 ? b8[i] : b8[i + 4], 16);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) b2[i] = (u3 ? b4[i + 2] : b4[i]) + __shfl_xor(u3 ? b4[i] : b4[i + 2], 8);
+      b1 = (u2 ? b2[1] : b2[0]) + __shfl_xor(u2 ? b2[0] : b2[1], 4);
+      b1 += __shfl_xor(b1, 2);
+      b1 += __shfl_xor(b1, 1);
+      if ((lane & 3) == 0) s_a[w][(u5 ? 8 : 0) + (u4 ? 4 : 0) + (u3 ? 2 : 0) + (u2 ? 1 : 0)] = b1;
     }
     wave_lds_sync();
-    const float div = static_cast<float>(cnt > 1 ? cnt : 1);
-    for (int o = lane; o < Cout; o += 64) {
-      float v = 0.f;
+    const float cntf = s_a[w][15];
+    const float div = cntf > 1.f ? cntf : 1.f;
+    float av[KP_K];
 #pragma unroll
-      for (int k = 0; k < KP_K; ++k) v = fmaf(s_a[w][k], W[k * Cout + o], v);
-      v = v / div;
-      if (bias) v += bias[o];
-      out[m * Cout + o] = v;
+    for (int k = 0; k < KP_K; ++k) av[k] = s_a[w][k];
+#pragma unroll
+    for (int q = 0; q < MAXO; ++q) {
+      const int o = lane + 64 * q;
+      if (o < Cout) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < KP_K; ++k) v = fmaf(av[k], wreg[q][k], v);
+        v = v / div;
+        if (bias) v += breg[q];
+        out[m * Cout + o] = v;
+      }
     }
     wave_lds_sync();
   }
@@ -545,7 +573,7 @@ extern "C" int lcr_kpconv_aggregate(const float* s_feats, const uint8_t* s_pos, 
 extern "C" int lcr_kpconv_cin1(const float* s_feats, const float* q_pts, const float* s_pts, const void* idx, int idx_is_64, int64_t M,
                                int64_t Ns, int H, const float* kernel_points_host, float sigma, const float* W, const float* bias, int Cout,
                                float* out, const int32_t* order, void* stream) {
-  if (!s_feats || !q_pts || !s_pts || !idx || !kernel_points_host || !W || !out || M < 0 || H < 1 || Cout < 1 || !(sigma > 0.f)) {
+  if (!s_feats || !q_pts || !s_pts || !idx || !kernel_points_host || !W || !out || M < 0 || H < 1 || Cout < 1 || Cout > 256 || !(sigma > 0.f)) {
     set_error("lcr_kpconv_cin1: bad argument");
     return LCR_EARG;
   }
