@@ -30,7 +30,7 @@ extern "C" {
 /* bits of the device-side status word written by data-dependent stages */
 #define LCR_STATUS_KEY_OVERFLOW 1u   /* voxel key needs more than 64 bits together with the cloud id */
 #define LCR_STATUS_LEN_MISMATCH 2u
-#define LCR_GN_REPLICAS 8           /* copies of every GroupNorm statistics table (see lcr_gemm_f32) */   /* sum(lengths) exceeds the capacity passed by the host */
+#define LCR_GN_REPLICAS 8  /* copies of every GroupNorm statistics table (see lcr_gemm_f32) */   /* sum(lengths) exceeds the capacity passed by the host */
 
 const char* lcr_last_error(void);
 int lcr_version(void);

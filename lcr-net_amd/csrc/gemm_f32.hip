@@ -341,21 +341,53 @@ __global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ 
     }
   }
 
-  // GroupNorm statistics.  Fast path (all BM rows of the workgroup in one segment — all but B-1 workgroups): wavefront
-  // partials are folded in LDS (ds_add_f64) and the workgroup issues one pair of global fp64 atomics per group, into the
-  // statistics replica (row block % GN_REPLICAS).  Slow path (a segment boundary inside the tile): per wavefront, per
-  // segment present in its 32 rows, straight to global memory.
+  // GroupNorm statistics.  Fast path (all BM rows of the workgroup in one segment — all but B-1 workgroups): every lane parks
+  // the fp32 sums of its 16 values per column in LDS, one thread per column folds the 2*WM row slices in fp64, the gs lanes of
+  // a group are folded with shuffles in the BN/64 wavefronts that hold the columns, and the workgroup issues one pair of
+  // global fp64 atomics per group into the statistics replica (row block % GN_REPLICAS).  (A version with fp64 shuffles in
+  // every wavefront + LDS fp64 atomics cost 8-9 us per unary GEMM.)  Slow path (a segment boundary inside the tile): per
+  // wavefront, per segment present in its 32 rows, straight to global memory.
   if (want_stats) {
-    __shared__ double s_red[BN][2];
+    __shared__ float s_part[2][2 * WM][BN];
     double* rep = ep.stats + static_cast<int64_t>(m_tile % GN_REPLICAS) * ep.S * ep.groups * 2;
     int64_t seg_start = blk_seg_start, seg_end = blk_seg_end;
     const int64_t blk_last_row = min(m0 + BM - 1, M - 1);
     const bool uniform = blk_last_row < seg_end;      // block-uniform
     if (uniform) {
-      for (int i = threadIdx.x; i < BN * 2; i += GM_T) (&s_red[0][0])[i] = 0.0;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float s = 0.f, ss = 0.f;                      // rows beyond M hold zeros in the accumulators
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s += acc[j][r];
+          ss = fmaf(acc[j][r], acc[j][r], ss);
+        }
+        const int cl = wn * (32 * NT) + j * 32 + (lane & 31);
+        s_part[0][2 * wm + (lane >> 5)][cl] = s;
+        s_part[1][2 * wm + (lane >> 5)][cl] = ss;
+      }
       __syncthreads();
-    }
-    if (wrow0 < M) {
+      if (threadIdx.x < BN) {
+        const int cl = threadIdx.x;
+        double ds = 0.0, dss = 0.0;
+#pragma unroll
+        for (int r = 0; r < 2 * WM; ++r) {
+          ds += static_cast<double>(s_part[0][r][cl]);
+          dss += static_cast<double>(s_part[1][r][cl]);
+        }
+        const int span = gs < 64 ? gs : 64;           // gs is a power of two; groups wider than 64 columns add per wavefront
+        for (int d = 1; d < span; d <<= 1) {
+          ds += __shfl_xor(ds, d);
+          dss += __shfl_xor(dss, d);
+        }
+        const int col = n0 + cl;
+        if ((cl & (span - 1)) == 0 && col < N) {
+          double* d = rep + (static_cast<int64_t>(blk_first) * ep.groups + col / gs) * 2;
+          atomicAdd(d, ds);
+          atomicAdd(d + 1, dss);
+        }
+      }
+    } else if (wrow0 < M) {
       const int64_t wlast = min(wrow0 + 31, M - 1);
       int sg = blk_first;
       while (sg + 1 < ep.S && wrow0 >= seg_end) {
@@ -386,33 +418,15 @@ __global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ 
             dss += __shfl_xor(dss, d);
           }
           if (lane < 32 && (lane & (span - 1)) == 0 && col < N) {
-            if (uniform) {
-              const int gl = (col - n0) / gs;
-              atomicAdd(&s_red[gl][0], ds);
-              atomicAdd(&s_red[gl][1], dss);
-            } else {
-              double* d = rep + (static_cast<int64_t>(sg) * ep.groups + col / gs) * 2;
-              atomicAdd(d, ds);
-              atomicAdd(d + 1, dss);
-            }
+            double* d = rep + (static_cast<int64_t>(sg) * ep.groups + col / gs) * 2;
+            atomicAdd(d, ds);
+            atomicAdd(d + 1, dss);
           }
         }
         if (wlast < seg_end || sg + 1 >= ep.S) break;
         ++sg;
         seg_start = seg_end;
         seg_end += ep.seg_len[sg];
-      }
-    }
-    if (uniform) {
-      __syncthreads();
-      const int ngl = (BN + gs - 1) / gs;
-      for (int i = threadIdx.x; i < ngl; i += GM_T) {
-        const int g = n0 / gs + i;
-        if (g < ep.groups && (n0 + i * gs) < N) {
-          double* d = rep + (static_cast<int64_t>(blk_first) * ep.groups + g) * 2;
-          atomicAdd(d, s_red[i][0]);
-          atomicAdd(d + 1, s_red[i][1]);
-        }
       }
     }
   }
