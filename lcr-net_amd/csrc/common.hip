@@ -1,6 +1,7 @@
 // common.hip — error plumbing + device-wide scan used by the grid/sort stages.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -93,7 +94,76 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_apply(const int32_t* __restrict
   }
 }
 
-size_t scan_ws_bytes(int64_t n) { return align_up(sizeof(int32_t) * (static_cast<size_t>((n + SCAN_TILE - 1) / SCAN_TILE) + 1)); }
+
+// ---- single-pass scan (decoupled look-back) -----------------------------------------------------------------------
+// One launch instead of three: tiles take their index from an atomic ticket (so a tile only ever waits for tiles that started
+// earlier), publish (flag | value) as ONE 64-bit word with agent-scope atomics — flag and value travel together, so nothing
+// else has to become visible across the per-XCD L2s — and wavefront 0 looks back over 64 predecessors at a time.
+// state[t] = flag << 32 | uint32 value; flag 0 = nothing yet, 1 = tile aggregate, 2 = inclusive prefix.  The state words and
+// the ticket must be zero at launch (one small memset per scan).
+constexpr uint64_t SCAN_AGG = 1ull << 32, SCAN_INC = 2ull << 32;
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_lookback(const int32_t* __restrict__ in, int32_t* __restrict__ out, int64_t n,
+                                                          const int32_t* __restrict__ n_dev, int n_add, int64_t* __restrict__ total,
+                                                          uint64_t* __restrict__ state, uint32_t* __restrict__ ticket) {
+  __shared__ int lds[8];
+  __shared__ int s_tile, s_prefix;
+  if (n_dev) n = min(n, static_cast<int64_t>(*n_dev) + n_add);
+  if (threadIdx.x == 0) s_tile = static_cast<int>(atomicAdd(ticket, 1u));
+  __syncthreads();
+  const int tile = s_tile;
+  const int64_t base = static_cast<int64_t>(tile) * SCAN_TILE + threadIdx.x * SCAN_I;
+  if (static_cast<int64_t>(tile) * SCAN_TILE >= n) return;      // every later ticket is beyond n as well: nobody waits for this tile
+  int v[SCAN_I];
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_I; ++k) {
+    v[k] = (base + k < n) ? in[base + k] : 0;
+    s += v[k];
+  }
+  int tot;
+  int run = block_excl_scan(s, &tot, lds);
+  if (threadIdx.x < 64) {                                         // wavefront 0: publish, then look back
+    const int lane = threadIdx.x;
+    int prefix = 0;
+    if (tile == 0) {
+      if (lane == 0) __hip_atomic_store(&state[0], SCAN_INC | static_cast<uint32_t>(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (lane == 0) __hip_atomic_store(&state[tile], SCAN_AGG | static_cast<uint32_t>(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int j0 = tile - 1;; j0 -= 64) {
+        const int j = j0 - lane;                                  // lane 0 = nearest predecessor
+        uint64_t w = SCAN_INC;                                    // before tile 0: an empty inclusive prefix
+        if (j >= 0) {
+          do {
+            w = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } while ((w >> 32) == 0);
+        }
+        const uint64_t inc = __ballot((w >> 32) == 2);
+        const int val = static_cast<int>(static_cast<uint32_t>(w));
+        if (inc) {
+          const int first = __builtin_ctzll(inc);                 // nearest tile that already knows its inclusive prefix
+          prefix += wave_sum(lane <= first ? val : 0);
+          break;
+        }
+        prefix += wave_sum(val);
+      }
+      if (lane == 0) __hip_atomic_store(&state[tile], SCAN_INC | static_cast<uint32_t>(prefix + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) {
+      s_prefix = prefix;
+      if (total && static_cast<int64_t>(tile + 1) * SCAN_TILE >= n) *total = static_cast<int64_t>(prefix) + tot;
+    }
+  }
+  __syncthreads();
+  run += s_prefix;
+#pragma unroll
+  for (int k = 0; k < SCAN_I; ++k) {
+    if (base + k < n) out[base + k] = run;
+    run += v[k];
+  }
+}
+
+size_t scan_ws_bytes(int64_t n) { return align_up(sizeof(uint64_t) * (static_cast<size_t>((n + SCAN_TILE - 1) / SCAN_TILE) + 2)); }
 
 int exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int64_t* total, void* ws, hipStream_t st) {
   return exclusive_scan_i32_dev(in, out, n, nullptr, 0, total, ws, st);
@@ -106,6 +176,14 @@ int exclusive_scan_i32_dev(const int32_t* in, int32_t* out, int64_t n, const int
     return LCR_OK;
   }
   const int nt = static_cast<int>((n + SCAN_TILE - 1) / SCAN_TILE);
+  static const bool three_pass = getenv("LCR_SCAN_3PASS") != nullptr;     // the previous three-launch form, kept for A/B
+  if (!three_pass) {
+    uint64_t* state = static_cast<uint64_t*>(ws);                           // [nt] words + the ticket
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(state + nt);
+    hipMemsetAsync(ws, 0, sizeof(uint64_t) * (static_cast<size_t>(nt) + 1), st);
+    hipLaunchKernelGGL(k_scan_lookback, dim3(nt), dim3(SCAN_T), 0, st, in, out, n, n_dev, n_add, total, state, ticket);
+    return check_launch("exclusive_scan_i32");
+  }
   int32_t* sums = static_cast<int32_t*>(ws);
   hipLaunchKernelGGL(k_scan_tile_sums, dim3(nt), dim3(SCAN_T), 0, st, in, n, sums, n_dev, n_add);
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_T), 0, st, sums, nt, total, n_dev, n_add);
