@@ -146,7 +146,7 @@ def precompute_batch(points, lengths, num_stages, voxel_size, radius, neighbor_l
             "lengths_host": lengths_host, "segment_lengths": lens}
 
 
-def voxelize_raw_scans(points, lengths, voxel_size, key_bits_hint=40):
+def voxelize_raw_scans(points, lengths, voxel_size, key_bits_hint=32):
     """Raw-scan ingest (replaces the offline Open3D voxel_down_sample(0.3) of data/Kitti/downsample_pcd.py:29
     with the a-1 kernel): stacked raw scans -> stacked voxel barycentres; returns (points, lengths_dev, lengths_host)."""
     out, out_len, status = grid_subsample_device(points, lengths, voxel_size, key_bits_hint=key_bits_hint)

@@ -62,3 +62,22 @@ def test_native_precompute_matches_python_path():
                     assert x.shape == y.shape and x.dtype == y.dtype and torch.equal(x, y), key
             for x, y in zip(a["order"], b["order"]):      # cell-sorted order: same cells, order inside a cell is free
                 assert x.shape == y.shape and torch.equal(torch.sort(x.long())[0], torch.sort(y.long())[0])
+
+
+@pytest.mark.parametrize("sizes", [[2000], [37, 5000, 1], [300, 0, 4000]])
+def test_native_precompute_ragged_batches(sizes):
+    """Single cloud, tiny clouds and an EMPTY cloud inside the batch: native call == op-by-op path."""
+    from lcrnet_amd.data import precompute_batch
+    rng = np.random.default_rng(5)
+    scan = load_scan("003854")
+    clouds = [scan[rng.choice(len(scan), n, replace=False)] if n else np.zeros((0, 3), np.float32) for n in sizes]
+    pts = torch.from_numpy(np.concatenate(clouds).astype(np.float32)).cuda()
+    lens = torch.tensor(sizes, dtype=torch.int64, device="cuda")
+    limits = [20, 20, 20, 20]
+    a = precompute_batch(pts, lens, 4, 0.3, 1.275, limits, native=False)
+    b = precompute_batch(pts, lens, 4, 0.3, 1.275, limits, native=True)
+    torch.cuda.synchronize()
+    assert a["lengths_host"] == b["lengths_host"]
+    for key in ("points", "lengths", "neighbors", "subsampling", "upsampling"):
+        for x, y in zip(a[key], b[key]):
+            assert x.shape == y.shape and torch.equal(x, y), key
