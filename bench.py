@@ -121,7 +121,7 @@ def main():
     pipe = DescriptorPipeline(model, VOXEL, RADIUS, NUM_STAGES, LIMITS, upsampling=not args.no_upsampling, raw_voxel=VOXEL,
                               overlap=not args.no_overlap, producer_thread=not args.no_thread, pre_workers=args.pre_workers, depth=args.depth)
     if not (args.single_encoder or args.no_overlap or args.no_thread):
-        pipe.enable_dual_encoder()
+        pipe.enable_dual_encoder(int(os.environ.get("LCR_ENC_STREAMS", "2")))
 
     def run_steps(n):
         """n steps = n batches, each fully processed (voxelise .. descriptors [+ all-gather]); the pre-processing of step

@@ -31,10 +31,10 @@ class DescriptorPipeline:
         self.producer_thread, self.depth, self.pre_workers = producer_thread, depth, pre_workers
         self.enc_streams = None      # set by enable_dual_encoder(): consecutive batches' encoders on alternating streams
 
-    def enable_dual_encoder(self):
+    def enable_dual_encoder(self, n=2):
         """Run the encoders of consecutive batches on two alternating streams so that the small-grid kernels of one (stage-3/4
         GEMMs, GroupNorm, NetVLAD) fill the gaps of the other.  Results are handed back in order on the caller's stream."""
-        self.enc_streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
+        self.enc_streams = [torch.cuda.Stream(self.device) for _ in range(n)]
         return self
 
     # ---- stages -----------------------------------------------------------------------------------------------------
@@ -150,7 +150,7 @@ class DescriptorPipeline:
                 break
             dd, ev = ready.pop(k)
             slots.release()
-            es = main if self.enc_streams is None else self.enc_streams[k % 2]
+            es = main if self.enc_streams is None else self.enc_streams[k % len(self.enc_streams)]
             for v in dd.values():
                 for t in (v if isinstance(v, (list, tuple)) else [v]):
                     if torch.is_tensor(t) and t.is_cuda:
@@ -159,7 +159,7 @@ class DescriptorPipeline:
             if self.enc_streams is None:
                 yield self.encode(dd)
             else:
-                if k < 2:
+                if k < len(self.enc_streams):
                     es.wait_stream(main)                    # weights / inputs prepared on the caller's stream
                 with torch.cuda.stream(es):
                     desc = self.encode(dd)
