@@ -126,12 +126,6 @@ int lcr_precompute_batch(const float* points0, const int64_t* lengths0, const Lc
 int lcr_gemm_f32(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB,
                  const float* bias, const float* rowdiv, const int64_t* seg_len, int S, int groups, double* stats,
                  void* stream);
-/* Same with an optional workspace (lcr_gemm_f32_ws_bytes; 0 bytes = not useful) that enables split-K with large tiles for deep,
- * short problems (the stage-3/4 KPConv contractions). */
-int lcr_gemm_f32_ws_bytes(int64_t M, int N, int K, int transA, int transB, size_t* bytes);
-int lcr_gemm_f32_ex(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB,
-                    const float* bias, const float* rowdiv, const int64_t* seg_len, int S, int groups, double* stats,
-                    void* ws, size_t ws_bytes, void* stream);
 /* Tuning hook for tools/gemm_bench.py: 0 = heuristic tile choice, 1..5 = force 128x128 / 128x64 / 128x32 / 64x64 / 64x128. */
 void lcr_gemm_debug_force_tile(int tile);
 /* Batched C_z[M,N] = A_z^T · B_z with A_z stored [K_z, M] (per-entry K and element offsets, HOST arrays, count <= 64). */

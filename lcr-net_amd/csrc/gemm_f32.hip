@@ -30,7 +30,6 @@ constexpr int GM_MAX_BATCH = 64;
 struct GemmBatch {
   int     count;                 // 0 = plain GEMM
   int     strided;               // 1: entry z uses offsets z * {a,b,c}_off[0] and K = k[0] (uniform batch)
-                                 // 2: split-K: entry z reduces k in [z*k[0], min((z+1)*k[0], K)) into the partial C + z*c_off[0]
   int     k[GM_MAX_BATCH];
   int64_t a_off[GM_MAX_BATCH], b_off[GM_MAX_BATCH], c_off[GM_MAX_BATCH];
 };
@@ -149,12 +148,8 @@ template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                                        int64_t M, int N, int K, GemmEpilogue ep, GemmBatch batch) {
   static_assert(WM * WN == 4 && BM == 32 * WM, "one 32-row MFMA tile per wavefront along M");
-  int k_begin = 0, k_end = K;
-  if (batch.count && batch.strided == 2) {
-    k_begin = blockIdx.z * batch.k[0];
-    k_end = min(k_begin + batch.k[0], K);
-    C += static_cast<int64_t>(blockIdx.z) * batch.c_off[0];
-  } else if (batch.count) {
+  constexpr int k_begin = 0;
+  if (batch.count) {
     const int z = blockIdx.z;
     if (batch.strided) {
       A += static_cast<int64_t>(z) * batch.a_off[0];
@@ -219,8 +214,7 @@ __global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ 
       acc2[j][r] = 0.f;
     }
 
-  if (!(batch.count && batch.strided == 2)) k_end = K;   // K may have been replaced by a per-entry value above
-  const int nk = (k_end - k_begin + GM_BK - 1) / GM_BK;   // split-K chunks are multiples of GM_BK, so loaders only need the global bound K
+  const int nk = (K + GM_BK - 1) / GM_BK;                 // K may have been replaced by a per-entry value above
   // Both prologue tiles are requested before anything waits (for nk == 1 the second request re-reads tile 0: its pieces are
   // out of K, so their addresses fall back to column 0 — cache hits, never stored).  The epilogue's per-column bias and the
   // GroupNorm segment of this row block (a chain of dependent scalar loads) are fetched here too, under the same latency.
@@ -447,120 +441,6 @@ static int launch_gemm(const float* A, const float* B, float* C, int64_t M, int 
   return check_launch("lcr_gemm_f32");
 }
 
-// Split-K finish: C = (sum_z P[z]) / rowdiv + bias, plus the GroupNorm sums of C.  One workgroup per 32 rows.
-__global__ __launch_bounds__(256) void k_splitk_finish(const float* __restrict__ P, int splits, float* __restrict__ C, int64_t M, int N,
-                                                       GemmEpilogue ep) {
-  __shared__ double s_red[64][2];          // up to 64 groups
-  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * 32;
-  const int c4n = N >> 2;                  // float4 columns
-  const bool want_stats = ep.stats != nullptr;
-  const int gs = want_stats ? N / ep.groups : 1;
-  int seg = 0;
-  bool uniform = true;
-  if (want_stats) {
-    int64_t end = ep.seg_len[0];
-    while (seg + 1 < ep.S && r0 >= end) {
-      ++seg;
-      end += ep.seg_len[seg];
-    }
-    uniform = min(r0 + 31, M - 1) < end;
-    for (int i = threadIdx.x; i < 64 * 2; i += 256) (&s_red[0][0])[i] = 0.0;
-    __syncthreads();
-  }
-  double* rep = want_stats ? ep.stats + static_cast<int64_t>(blockIdx.x % GN_REPLICAS) * ep.S * ep.groups * 2 : nullptr;
-  // thread -> fixed float4 column (c4n divides 256 for the encoder's N), a subset of the 32 rows: column sums stay in registers
-  const int colq = threadIdx.x % c4n, rsub = threadIdx.x / c4n, rstep = 256 / c4n;
-  const int c0 = colq * 4;
-  float cs[4] = {0.f, 0.f, 0.f, 0.f}, css[4] = {0.f, 0.f, 0.f, 0.f};
-  if (rsub < rstep)
-    for (int r = rsub; r < 32; r += rstep) {
-      const int64_t row = r0 + r;
-      if (row >= M) break;
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int z = 0; z < splits; ++z) {
-        const float4 v = *reinterpret_cast<const float4*>(P + (static_cast<int64_t>(z) * M + row) * N + c0);
-        acc.x += v.x;
-        acc.y += v.y;
-        acc.z += v.z;
-        acc.w += v.w;
-      }
-      float o[4] = {acc.x, acc.y, acc.z, acc.w};
-      const float d = ep.rowdiv ? ep.rowdiv[row] : 1.f;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (ep.rowdiv) o[u] = o[u] / d;
-        if (ep.bias) o[u] += ep.bias[c0 + u];
-      }
-      *reinterpret_cast<float4*>(C + row * N + c0) = make_float4(o[0], o[1], o[2], o[3]);
-      if (want_stats) {
-        if (uniform) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            cs[u] += o[u];
-            css[u] = fmaf(o[u], o[u], css[u]);
-          }
-        } else {
-          const int sg = seg_of_row(ep.seg_len, ep.S, row);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int g = (c0 + u) / gs;
-            atomicAdd(rep + (static_cast<int64_t>(sg) * ep.groups + g) * 2, static_cast<double>(o[u]));
-            atomicAdd(rep + (static_cast<int64_t>(sg) * ep.groups + g) * 2 + 1, static_cast<double>(o[u]) * o[u]);
-          }
-        }
-      }
-    }
-  if (want_stats && uniform && rsub < rstep) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int g = (c0 + u) / gs;
-      atomicAdd(&s_red[g][0], static_cast<double>(cs[u]));
-      atomicAdd(&s_red[g][1], static_cast<double>(css[u]));
-    }
-  }
-  if (want_stats && uniform) {
-    __syncthreads();
-    for (int g = threadIdx.x; g < ep.groups; g += 256) {
-      atomicAdd(rep + (static_cast<int64_t>(seg) * ep.groups + g) * 2, s_red[g][0]);
-      atomicAdd(rep + (static_cast<int64_t>(seg) * ep.groups + g) * 2 + 1, s_red[g][1]);
-    }
-  }
-}
-
-// split-K plan for deep, short problems (the stage-3/4 KPConv contractions: M = 6-19 k, K = 1920-3840): big tiles for reuse,
-// K split so that >= ~512 workgroups exist.  Returns the number of splits (1 = do not split).
-static int splitk_plan(int64_t M, int N, int K, int transA, int transB, int* bn_out) {
-  if (transA || transB || K < 960 || (K % GM_BK) || (N % 64) || (256 % (N / 4)) != 0) return 1;   // finish kernel: N/4 divides 256
-  // experiment hook: LCR_GEMM_SPLITK="tile,splits" (tile 64 or 128; splits 0 = auto)
-  static int cfg_tile = 128, cfg_splits = 0;
-  static bool parsed = false;
-  if (!parsed) {
-    const char* e = getenv("LCR_GEMM_SPLITK");
-    if (e) sscanf(e, "%d,%d", &cfg_tile, &cfg_splits);
-    parsed = true;
-  }
-  if (cfg_tile == 64) {
-    const int64_t tiles = ((M + 63) / 64) * ((N + 63) / 64);
-    if (tiles >= 1024) return 1;
-    int splits = cfg_splits > 0 ? cfg_splits : static_cast<int>((1024 + tiles - 1) / tiles);
-    const int kmax = K / 256;
-    if (splits > kmax) splits = kmax;
-    if (splits < 2) return 1;
-    *bn_out = 64;
-    return splits;
-  }
-  const int bn = N >= 128 ? 128 : 64;
-  const int64_t tiles = ((M + 127) / 128) * ((N + bn - 1) / bn);
-  if (tiles >= 384) return 1;
-  int splits = static_cast<int>((512 + tiles - 1) / tiles);
-  const int kmax = K / 256;                      // keep >= 8 K-steps per split
-  if (splits > kmax) splits = kmax;
-  if (splits > 16) splits = 16;
-  if (splits < 2) return 1;
-  *bn_out = bn;
-  return splits;
-}
-
 }  // namespace lcr
 
 using namespace lcr;
@@ -569,31 +449,16 @@ using namespace lcr;
 static int g_force_tile = 0;
 extern "C" void lcr_gemm_debug_force_tile(int t) { g_force_tile = t; }
 
-extern "C" int lcr_gemm_f32_ws_bytes(int64_t M, int N, int K, int transA, int transB, size_t* bytes) {
-  if (!bytes) return LCR_EARG;
-  int bn = 0;
-  const int splits = getenv("LCR_GEMM_SPLITK") ? splitk_plan(M, N, K, transA, transB, &bn) : 1;   // measured slower than 64x64 tiles on MI355X; opt-in
-  *bytes = splits > 1 ? sizeof(float) * static_cast<size_t>(splits) * M * N : 0;
-  return LCR_OK;
-}
-
 static int gemm_impl(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB, const float* bias,
-                     const float* rowdiv, const int64_t* seg_len, int S, int groups, double* stats, void* ws, size_t ws_bytes, void* stream);
+                     const float* rowdiv, const int64_t* seg_len, int S, int groups, double* stats, void* stream);
 
 extern "C" int lcr_gemm_f32(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB, const float* bias,
                             const float* rowdiv, const int64_t* seg_len, int S, int groups, double* stats, void* stream) {
-  return gemm_impl(A, B, C, M, N, K, transA, transB, bias, rowdiv, seg_len, S, groups, stats, nullptr, 0, stream);
-}
-
-// Same, with an optional workspace (lcr_gemm_f32_ws_bytes) that enables the split-K path for deep, short problems.
-extern "C" int lcr_gemm_f32_ex(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB, const float* bias,
-                               const float* rowdiv, const int64_t* seg_len, int S, int groups, double* stats, void* ws, size_t ws_bytes,
-                               void* stream) {
-  return gemm_impl(A, B, C, M, N, K, transA, transB, bias, rowdiv, seg_len, S, groups, stats, ws, ws_bytes, stream);
+  return gemm_impl(A, B, C, M, N, K, transA, transB, bias, rowdiv, seg_len, S, groups, stats, stream);
 }
 
 static int gemm_impl(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB, const float* bias,
-                     const float* rowdiv, const int64_t* seg_len, int S, int groups, double* stats, void* ws, size_t ws_bytes, void* stream) {
+                     const float* rowdiv, const int64_t* seg_len, int S, int groups, double* stats, void* stream) {
   if (!A || !B || !C || M < 0 || N <= 0 || K <= 0) {
     set_error("lcr_gemm_f32: bad argument");
     return LCR_EARG;
@@ -614,27 +479,6 @@ static int gemm_impl(const float* A, const float* B, float* C, int64_t M, int N,
   // launch in front of every GEMM)
   if (M == 0) return LCR_OK;
   GemmEpilogue ep{bias, rowdiv, seg_len, S, groups, stats};
-  {
-    int bn = 0;
-    const int splits = (ws && getenv("LCR_GEMM_SPLITK") && !g_force_tile) ? splitk_plan(M, N, K, transA, transB, &bn) : 1;
-    if (splits > 1 && ws_bytes >= sizeof(float) * static_cast<size_t>(splits) * M * N && (groups == 0 || groups <= 64) &&
-        reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(B) % 16 == 0) {
-      GemmBatch bt = {};
-      bt.count = splits;
-      bt.strided = 2;
-      bt.k[0] = ((K / GM_BK + splits - 1) / splits) * GM_BK;     // K-steps per split, in elements
-      bt.c_off[0] = M * N;
-      GemmEpilogue none{nullptr, nullptr, nullptr, 0, 0, nullptr};
-      float* P = static_cast<float*>(ws);
-      static const bool tile64 = getenv("LCR_GEMM_SPLITK") && atoi(getenv("LCR_GEMM_SPLITK")) == 64;
-      int rc = tile64 ? launch_gemm<64, 64, 2, 2, true>(A, B, P, M, N, K, 0, 0, none, st, &bt)
-               : bn == 128 ? launch_gemm<128, 128, 4, 1, true>(A, B, P, M, N, K, 0, 0, none, st, &bt)
-                           : launch_gemm<128, 64, 4, 1, true>(A, B, P, M, N, K, 0, 0, none, st, &bt);
-      if (rc) return rc;
-      hipLaunchKernelGGL(k_splitk_finish, dim3(static_cast<int>((M + 31) / 32)), dim3(256), 0, st, P, splits, C, M, N, ep);
-      return check_launch("lcr_gemm_f32 (split-K)");
-    }
-  }
   // 16-byte vector loads need leading dimensions that are multiples of 4 floats (bases: torch allocations are >= 256-B aligned,
   // row offsets inside them are multiples of the leading dimension)
   const int64_t lda = transA ? M : K, ldb = transB ? K : N;

@@ -2,15 +2,16 @@
 //
 // Reference: KPConv.forward, experiments/lcrnet/modules/kpconv/kpconv.py:79-122 — gathers (M,H,3) and (M,H,C), builds
 // (M,H,15,3) differences, (M,15,H) influences, bmm -> (M,15,C), then the (15,C,Cout) contraction, every intermediate
-// materialised in HBM (~2.6 GB per scan).  Here one wavefront owns one query point:
-//   1. lanes = neighbours: each lane gathers its support point (shadow rows skipped instead of a +1e6 pad, kpconv.py:91),
-//      evaluates the 15 linear influences max(0, 1 - |y - k|/sigma) (:96-99) and parks them in LDS;
-//   2. lanes = channels: the wavefront streams the valid neighbours' feature rows (coalesced 128-256 B segments),
-//      accumulating the 15 x C weighted sums (:104) in registers (for C = 32 the two half-waves take alternate neighbours
-//      and are folded with one cross-lane add);
+// materialised in HBM (~2.6 GB per scan).  Here one wavefront owns one query point (k_kpconv_aggregate_vec):
+//   1. lanes = neighbours: the valid ones (shadow rows skipped instead of a +1e6 pad, kpconv.py:91) are compacted in order into
+//      LDS as (relative position, index) — 16 B each;
+//   2. per 4 neighbours, D[16 kernel points x C] += W[16 x 4] * F[4 x C] on v_mfma_f32_16x16x4_f32 (exact fp32): lane l evaluates
+//      the ONE linear influence max(0, 1 - |y - k|/sigma) (:96-99) it feeds to the matrix core — neighbour (l>>4), kernel point
+//      (l&15) — and fetches 4 consecutive channels of that neighbour's feature row with one 16-B load (:104);
 //   3. writes the (15*C) row that lcr_gemm_f32 contracts with the (15*C, Cout) weights (:108-110) and the neighbour
 //      count used by its epilogue (:113-116: neighbours whose feature row sums to > 0).
-// Only the (M, 15*C) aggregate goes through HBM/Infinity-Cache between the two halves (fusing it away is the next step).
+// Only the (M, 15*C) aggregate goes through HBM/Infinity-Cache between the two halves.  Earlier variants (VALU accumulation with
+// the influences parked in LDS; MFMA with scalar 4-B gathers) are described with their measurements in DESIGN.md §4.1.
 // encoder1_1 (C_in = 1, backbone4.py:15) is fully fused in k_kpconv_cin1.
 #include <algorithm>
 #include <cstdlib>
@@ -27,252 +28,15 @@ struct KPoints {
   float p[KP_K][3];
 };
 
-// Compacts the valid (non-shadow) neighbours of one query into LDS, in order, together with their 15 influences.
-template <typename IdxT>
-__device__ __forceinline__ int gather_neighbours(const IdxT* __restrict__ row, int H, int64_t Ns, const float* __restrict__ s_pts,
-                                                 const float* __restrict__ q, const KPoints& kp, float sigma,
-                                                 int32_t* __restrict__ l_idx, float* __restrict__ l_w /*[KP_HMAX][16]*/) {
-  // influence = max(0, 1 - |y - k| / sigma) (kpconv.py:96-99) evaluated as 1 - sqrt(d2) * (1/sigma) with the hardware
-  // v_sqrt_f32 (1 ulp): ~2 ulp from the reference's sqrt-then-divide, far inside the 1e-4 feature tolerance, and ~2x
-  // fewer issue slots than the correctly-rounded sqrt + IEEE division sequence
-  const float inv_sigma = 1.f / sigma;
-  const int lane = threadIdx.x & 63;
-  int n = 0;
-  for (int h0 = 0; h0 < H; h0 += 64) {
-    const int h = h0 + lane;
-    int64_t j = Ns;
-    if (h < H) j = static_cast<int64_t>(row[h]);
-    const bool ok = j >= 0 && j < Ns;
-    const uint64_t m = __ballot(ok);
-    const int slot = n + __popcll(m & lanemask_lt());
-    if (ok) {
-      const float dx = s_pts[3 * j + 0] - q[0], dy = s_pts[3 * j + 1] - q[1], dz = s_pts[3 * j + 2] - q[2];
-      l_idx[slot] = static_cast<int32_t>(j);
-#pragma unroll
-      for (int k = 0; k < KP_K; ++k) {
-        const float ex = dx - kp.p[k][0], ey = dy - kp.p[k][1], ez = dz - kp.p[k][2];
-        const float d2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-        l_w[slot * 16 + k] = fmaxf(1.f - __builtin_amdgcn_sqrtf(d2) * inv_sigma, 0.f);
-      }
-      l_w[slot * 16 + 15] = 0.f;
-    }
-    n += __popcll(m);
-  }
-  // rows n .. round_up(n, 4) - 1 are read by the MFMA aggregation as zero-weight neighbours
-  if (lane < 48 && (n & 3)) {
-    const int slot = n + (lane >> 4);
-    if (slot < ((n + 3) & ~3)) l_w[slot * 16 + (lane & 15)] = 0.f;
-  }
-  return n;
-}
-
-// the 15 influences of one neighbour (padded to 16 floats, 64-B aligned): four 16-B LDS reads instead of fifteen 4-B ones
-__device__ __forceinline__ void load_w16(const float* __restrict__ p, float (&w)[16]) {
-  const float4* q = reinterpret_cast<const float4*>(p);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float4 v = q[i];
-    w[4 * i + 0] = v.x;
-    w[4 * i + 1] = v.y;
-    w[4 * i + 2] = v.z;
-    w[4 * i + 3] = v.w;
-  }
-}
-
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// CPL = channels per lane (C = 64*CPL) or, for HALF, C = 32 with the two half-waves splitting the neighbours
-template <typename IdxT, int CPL, bool HALF>
-__global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate(const float* __restrict__ s_feats, const uint8_t* __restrict__ s_pos,
-                                                                    const float* __restrict__ q_pts, const float* __restrict__ s_pts,
-                                                                    const IdxT* __restrict__ idx, int64_t M, int64_t Ns, int H, KPoints kp,
-                                                                    float sigma, float* __restrict__ A, float* __restrict__ nn,
-                                                                    const int32_t* __restrict__ order) {
-  constexpr int C = HALF ? 32 : 64 * CPL;
-  __shared__ int32_t s_idx[KP_WAVES][KP_HMAX + 4];
-  __shared__ __attribute__((aligned(16))) float s_w[KP_WAVES][(KP_HMAX + 4) * 16];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int64_t t = static_cast<int64_t>(blockIdx.x) * KP_WAVES + w; t < M; t += static_cast<int64_t>(gridDim.x) * KP_WAVES) {
-    const int64_t m = order ? order[t] : t;     // spatially coherent processing order (results land at their own row)
-    const float q[3] = {q_pts[3 * m], q_pts[3 * m + 1], q_pts[3 * m + 2]};
-    const int n = gather_neighbours(idx + m * H, H, Ns, s_pts, q, kp, sigma, s_idx[w], s_w[w]);
-    wave_lds_sync();
-    // neighbour count of kpconv.py:113-116
-    int cnt = 0;
-    for (int h = lane; h < n; h += 64) cnt += s_pos[s_idx[w][h]] ? 1 : 0;
-    cnt = wave_sum(cnt);
-
-    float acc[CPL][KP_K];
-#pragma unroll
-    for (int j = 0; j < CPL; ++j)
-#pragma unroll
-      for (int k = 0; k < KP_K; ++k) acc[j][k] = 0.f;
-
-    // Feature rows are gathered PF neighbours ahead (PF independent global loads in flight per lane) — the gather latency
-    // (L2 / Infinity-Cache misses on ~random rows) is what bounds this loop, not the 15 FMAs per neighbour and channel.
-    if (HALF) {
-      constexpr int PF = 4;                       // per half-wave => 8 neighbours of the query in flight
-      const int g = lane >> 5, c = lane & 31;
-      const int nh = (n - g + 1) / 2;             // neighbours owned by this half-wave: h = g, g+2, ...
-      for (int i0 = 0; i0 < nh; i0 += PF) {
-        float f[PF];
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-          const int i = i0 + u < nh ? i0 + u : nh - 1;
-          f[u] = s_feats[static_cast<int64_t>(s_idx[w][g + 2 * i]) * C + c];
-        }
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-          if (i0 + u < nh) {
-            float wv[16];
-            load_w16(&s_w[w][(g + 2 * (i0 + u)) * 16], wv);
-#pragma unroll
-            for (int k = 0; k < KP_K; ++k) acc[0][k] = fmaf(wv[k], f[u], acc[0][k]);
-          }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < KP_K; ++k) acc[0][k] += __shfl_xor(acc[0][k], 32);
-      if (lane < 32) {
-        float* out = A + m * (KP_K * C);
-#pragma unroll
-        for (int k = 0; k < KP_K; ++k) out[k * C + c] = acc[0][k];
-      }
-    } else {
-      constexpr int PF = CPL >= 4 ? 2 : (CPL == 2 ? 4 : 8);
-      for (int h0 = 0; h0 < n; h0 += PF) {
-        float f[PF][CPL];
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-          const int h = h0 + u < n ? h0 + u : n - 1;
-          const float* r0 = s_feats + static_cast<int64_t>(s_idx[w][h]) * C;
-#pragma unroll
-          for (int j = 0; j < CPL; ++j) f[u][j] = r0[lane + 64 * j];
-        }
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-          if (h0 + u < n) {                        // wave-uniform
-            float wv[16];
-            load_w16(&s_w[w][(h0 + u) * 16], wv);
-#pragma unroll
-            for (int k = 0; k < KP_K; ++k)
-#pragma unroll
-              for (int j = 0; j < CPL; ++j) acc[j][k] = fmaf(wv[k], f[u][j], acc[j][k]);
-          }
-        }
-      }
-      float* out = A + m * (KP_K * C);
-#pragma unroll
-      for (int k = 0; k < KP_K; ++k)
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) out[k * C + lane + 64 * j] = acc[j][k];
-    }
-    if (lane == 0) nn[m] = static_cast<float>(cnt > 1 ? cnt : 1);
-    wave_lds_sync();
-  }
-}
-
-// MFMA variant of the aggregation (default): per query, D[16 kernel points x C channels] += W[16 x 4 neighbours] * F[4 x C] with
-// v_mfma_f32_16x16x4_f32 (exact fp32).  The influence matrix W is never stored: lane l evaluates the ONE entry it feeds to the
-// matrix core — neighbour h0 + (l>>4), kernel point l&15 — from the neighbour's relative position (16 B in LDS, broadcast to
-// its 16 lanes) and its own kernel point (3 registers).  That leaves ~2.6 KB of LDS per wavefront (index + relative position
-// per neighbour), so a CU holds its full 32 wavefronts: the kernel is bound by the latency of the row gathers, and occupancy
-// is what hides it.  B operand: lane l <- feature[idx[h0 + (l>>4)]][c0 + (l&15)] straight from global/L2 (64-B row segments).
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-template <typename IdxT, int C>
-__global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate_mfma(const float* __restrict__ s_feats, const uint8_t* __restrict__ s_pos,
-                                                                         const float* __restrict__ q_pts, const float* __restrict__ s_pts,
-                                                                         const IdxT* __restrict__ idx, int64_t M, int64_t Ns, int H, KPoints kp,
-                                                                         float sigma, float* __restrict__ A, float* __restrict__ nn,
-                                                                         const int32_t* __restrict__ order) {
-  constexpr int NTILE = C / 16;
-  __shared__ __attribute__((aligned(16))) float4 s_rel[KP_WAVES][KP_HMAX + 8];   // (dx, dy, dz, bits(index)) per valid neighbour
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int sub = lane >> 4, col = lane & 15;
-  const float inv_sigma = 1.f / sigma;
-  // this lane's kernel point (row `col` of the 16-row operand; row 15 is padding)
-  float kx = 0.f, ky = 0.f, kz = 0.f;
-#pragma unroll
-  for (int k = 0; k < KP_K; ++k)
-    if (col == k) {
-      kx = kp.p[k][0];
-      ky = kp.p[k][1];
-      kz = kp.p[k][2];
-    }
-  const bool real_k = col < KP_K;
-  for (int64_t t = static_cast<int64_t>(blockIdx.x) * KP_WAVES + w; t < M; t += static_cast<int64_t>(gridDim.x) * KP_WAVES) {
-    const int64_t m = order ? order[t] : t;
-    const float qx = q_pts[3 * m], qy = q_pts[3 * m + 1], qz = q_pts[3 * m + 2];
-    // phase 1: lanes = neighbours; compact the valid ones (in order) with their relative positions; count the "positive" ones
-    int n = 0, cnt = 0;
-    for (int h0 = 0; h0 < H; h0 += 64) {
-      const int h = h0 + lane;
-      int64_t j = Ns;
-      if (h < H) j = static_cast<int64_t>(idx[m * H + h]);
-      const bool ok = j >= 0 && j < Ns;
-      const uint64_t mk = __ballot(ok);
-      if (ok) {
-        const int slot = n + __popcll(mk & lanemask_lt());
-        s_rel[w][slot] = make_float4(s_pts[3 * j] - qx, s_pts[3 * j + 1] - qy, s_pts[3 * j + 2] - qz, __uint_as_float(static_cast<uint32_t>(j)));
-        cnt += s_pos[j] ? 1 : 0;
-      }
-      n += __popcll(mk);
-    }
-    cnt = wave_sum(cnt);
-    wave_lds_sync();
-
-    floatx4 acc[NTILE];
-#pragma unroll
-    for (int tt = 0; tt < NTILE; ++tt) acc[tt] = floatx4{0.f, 0.f, 0.f, 0.f};
-    const int n4 = (n + 3) & ~3;
-    for (int h0 = 0; h0 < n4; h0 += 8) {           // two 4-neighbour steps per iteration: 2 * NTILE gathers in flight per lane
-      const int ha = h0 + sub, hb = h0 + 4 + sub;
-      const bool second = h0 + 4 < n4;             // wave-uniform
-      const float4 pa = s_rel[w][ha < n ? ha : n - 1];
-      const float4 pb = s_rel[w][hb < n ? hb : n - 1];
-      const float* ra = s_feats + static_cast<int64_t>(__float_as_uint(pa.w)) * C + col;
-      const float* rb = s_feats + static_cast<int64_t>(__float_as_uint(pb.w)) * C + col;
-      float fa[NTILE], fb[NTILE];
-#pragma unroll
-      for (int tt = 0; tt < NTILE; ++tt) {
-        fa[tt] = ra[tt * 16];
-        fb[tt] = rb[tt * 16];
-      }
-      // influence of neighbour ha / hb on this lane's kernel point (kpconv.py:96-99), zero for padding rows / neighbours
-      float ex = pa.x - kx, ey = pa.y - ky, ez = pa.z - kz;
-      float wa = fmaxf(1.f - __builtin_amdgcn_sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * inv_sigma, 0.f);
-      wa = (real_k && ha < n) ? wa : 0.f;
-      ex = pb.x - kx, ey = pb.y - ky, ez = pb.z - kz;
-      float wb = fmaxf(1.f - __builtin_amdgcn_sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * inv_sigma, 0.f);
-      wb = (real_k && hb < n) ? wb : 0.f;
-#pragma unroll
-      for (int tt = 0; tt < NTILE; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, fa[tt], acc[tt], 0, 0, 0);
-      if (second) {
-#pragma unroll
-        for (int tt = 0; tt < NTILE; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb, fb[tt], acc[tt], 0, 0, 0);
-      }
-    }
-    // D[row = kernel point 4*sub + r][col]: rows of 16 consecutive channels -> 64-B segments of the (15*C) output row
-    float* out = A + m * (KP_K * C);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int k = 4 * sub + r;
-      if (k < KP_K) {
-#pragma unroll
-        for (int tt = 0; tt < NTILE; ++tt) out[k * C + tt * 16 + col] = acc[tt][r];
-      }
-    }
-    if (lane == 0) nn[m] = static_cast<float>(cnt > 1 ? cnt : 1);
-    wave_lds_sync();
-  }
-}
-
-// Vector-gather form of the MFMA aggregation (default).  Same math as k_kpconv_aggregate_mfma, but a lane fetches V = 4 (C >= 64)
+// The aggregation kernel.  A lane fetches V = 4 (C >= 64)
 // or 2 (C = 32) CONSECUTIVE channels of its neighbour's row with one 16-B / 8-B load, so a 4-neighbour step of C = 64 is one
 // load instruction per lane (4 full 256-B rows per wavefront instruction) instead of four, and the V components feed V MFMA tiles
 // whose column `col` is channel q*16V + V*col + v: the output row is then written with V-wide stores.  Loads run D steps ahead
@@ -519,33 +283,11 @@ template <typename IdxT>
 static int launch_aggregate(const float* s_feats, const uint8_t* s_pos, const float* q_pts, const float* s_pts, const IdxT* idx, int64_t M,
                             int64_t Ns, int H, int C, const KPoints& kp, float sigma, float* A, float* nn, const int32_t* order, hipStream_t st) {
   dim3 grid(grid_for(M, KP_WAVES)), block(KP_WAVES * 64);
-  static const bool use_valu = getenv("LCR_KPCONV_VALU") != nullptr;   // A/B switch for profiling; the MFMA path is the default
-  static const bool use_scalar_gather = getenv("LCR_KPCONV_SCALAR_GATHER") != nullptr;   // previous MFMA variant, kept for A/B profiling
-  if (!use_valu && !use_scalar_gather) {
-    switch (C) {
-      case 32: hipLaunchKernelGGL((k_kpconv_aggregate_vec<IdxT, 32>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
-      case 64: hipLaunchKernelGGL((k_kpconv_aggregate_vec<IdxT, 64>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
-      case 128: hipLaunchKernelGGL((k_kpconv_aggregate_vec<IdxT, 128>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
-      case 256: hipLaunchKernelGGL((k_kpconv_aggregate_vec<IdxT, 256>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
-      default: set_error("lcr_kpconv_aggregate: C must be 32, 64, 128 or 256 (got %d)", C); return LCR_EARG;
-    }
-    return check_launch("lcr_kpconv_aggregate");
-  }
-  if (!use_valu) {
-    switch (C) {
-      case 32: hipLaunchKernelGGL((k_kpconv_aggregate_mfma<IdxT, 32>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
-      case 64: hipLaunchKernelGGL((k_kpconv_aggregate_mfma<IdxT, 64>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
-      case 128: hipLaunchKernelGGL((k_kpconv_aggregate_mfma<IdxT, 128>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
-      case 256: hipLaunchKernelGGL((k_kpconv_aggregate_mfma<IdxT, 256>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
-      default: set_error("lcr_kpconv_aggregate: C must be 32, 64, 128 or 256 (got %d)", C); return LCR_EARG;
-    }
-    return check_launch("lcr_kpconv_aggregate");
-  }
   switch (C) {
-    case 32: hipLaunchKernelGGL((k_kpconv_aggregate<IdxT, 1, true>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
-    case 64: hipLaunchKernelGGL((k_kpconv_aggregate<IdxT, 1, false>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
-    case 128: hipLaunchKernelGGL((k_kpconv_aggregate<IdxT, 2, false>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
-    case 256: hipLaunchKernelGGL((k_kpconv_aggregate<IdxT, 4, false>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
+    case 32: hipLaunchKernelGGL((k_kpconv_aggregate_vec<IdxT, 32>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
+    case 64: hipLaunchKernelGGL((k_kpconv_aggregate_vec<IdxT, 64>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
+    case 128: hipLaunchKernelGGL((k_kpconv_aggregate_vec<IdxT, 128>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
+    case 256: hipLaunchKernelGGL((k_kpconv_aggregate_vec<IdxT, 256>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
     default: set_error("lcr_kpconv_aggregate: C must be 32, 64, 128 or 256 (got %d)", C); return LCR_EARG;
   }
   return check_launch("lcr_kpconv_aggregate");

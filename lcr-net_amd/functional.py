@@ -116,13 +116,10 @@ def gemm(a, b, trans_b=False, trans_a=False, bias=None, rowdiv=None, seg_len=Non
         seg_len = _seg(seg_len, M, a.device)
         S = seg_len.numel()
         stats = _zero_stats(S, groups, a.device)
-    nbytes = ctypes.c_size_t(0)
-    _lib.lib().lcr_gemm_f32_ws_bytes(M, N, K, int(trans_a), int(trans_b), ctypes.byref(nbytes))
-    ws = _lib.workspace(nbytes.value, a.device) if nbytes.value else None       # split-K partials for deep, short problems
-    _timed("gemm", lambda: _lib.check(_lib.lib().lcr_gemm_f32_ex(
+    _timed("gemm", lambda: _lib.check(_lib.lib().lcr_gemm_f32(
         _lib.ptr(a), _lib.ptr(b), _lib.ptr(c), M, N, K, int(trans_a), int(trans_b), _lib.ptr(bias), _lib.ptr(rowdiv),
-        _lib.ptr(seg_len) if groups else None, S, int(groups), _lib.ptr(stats), _lib.ptr(ws), nbytes.value,
-        _lib.stream_ptr(a.device)), "lcr_gemm_f32"), meta=(M, N, K))
+        _lib.ptr(seg_len) if groups else None, S, int(groups), _lib.ptr(stats), _lib.stream_ptr(a.device)), "lcr_gemm_f32"),
+        meta=(M, N, K))
     return c, stats
 
 

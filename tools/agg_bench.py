@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Micro-benchmark of lcr_kpconv_aggregate / lcr_radius_query on the bench workload's real neighbourhoods (batch of 8 synthetic
 scans): µs per launch and achieved algorithmic GB/s (idx + xyz + support rows + A output), HIP events.
-    python tools/agg_bench.py            (LCR_KPCONV_SCALAR_GATHER=1 / LCR_KPCONV_VALU=1 select the older variants)
+    python tools/agg_bench.py
 """
 import os
 import sys
