@@ -244,16 +244,54 @@ __global__ __launch_bounds__(256) void k_maxpool(const float* __restrict__ x, co
       n += __popcll(mk);
     }
     wave_lds_sync();
-    for (int c = lane; c < C; c += 64) {
-      float v = any_shadow ? 0.f : -INFINITY;
-      for (int h0 = 0; h0 < n; h0 += 8) {          // 8 independent row gathers in flight
-        float f[8];
+    const float init = any_shadow ? 0.f : -INFINITY;
+    if ((C & 255) == 0) {
+      // a lane owns 4 consecutive channels per 256-channel slab: one 16-B load per gathered row instead of four 4-B ones
+      for (int c = lane * 4; c < C; c += 256) {
+        float4 v = make_float4(init, init, init, init);
+        for (int h0 = 0; h0 < n; h0 += 8) {        // 8 independent row gathers in flight
+          float4 f[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) f[u] = x[static_cast<int64_t>(s_idx[w][h0 + u < n ? h0 + u : n - 1]) * C + c];
+          for (int u = 0; u < 8; ++u)
+            f[u] = *reinterpret_cast<const float4*>(x + static_cast<int64_t>(s_idx[w][h0 + u < n ? h0 + u : n - 1]) * C + c);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v = fmaxf(v, f[u]);   // duplicates of the last row do not change a max
+          for (int u = 0; u < 8; ++u) {             // duplicates of the last row do not change a max
+            v.x = fmaxf(v.x, f[u].x);
+            v.y = fmaxf(v.y, f[u].y);
+            v.z = fmaxf(v.z, f[u].z);
+            v.w = fmaxf(v.w, f[u].w);
+          }
+        }
+        *reinterpret_cast<float4*>(out + m * C + c) = v;
       }
-      out[m * C + c] = v;
+    } else if ((C & 127) == 0) {
+      for (int c = lane * 2; c < C; c += 128) {
+        float2 v = make_float2(init, init);
+        for (int h0 = 0; h0 < n; h0 += 8) {
+          float2 f[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            f[u] = *reinterpret_cast<const float2*>(x + static_cast<int64_t>(s_idx[w][h0 + u < n ? h0 + u : n - 1]) * C + c);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            v.x = fmaxf(v.x, f[u].x);
+            v.y = fmaxf(v.y, f[u].y);
+          }
+        }
+        *reinterpret_cast<float2*>(out + m * C + c) = v;
+      }
+    } else {
+      for (int c = lane; c < C; c += 64) {
+        float v = init;
+        for (int h0 = 0; h0 < n; h0 += 8) {
+          float f[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) f[u] = x[static_cast<int64_t>(s_idx[w][h0 + u < n ? h0 + u : n - 1]) * C + c];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v = fmaxf(v, f[u]);
+        }
+        out[m * C + c] = v;
+      }
     }
     wave_lds_sync();
   }
