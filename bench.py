@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-BATCH = 8
+BATCH = int(os.environ.get("LCR_BENCH_BATCH", "8"))   # BASELINE configs[1]: 8 scans per step (override only for experiments)
 VOXEL, RADIUS, NUM_STAGES = 0.3, 1.275, 4
 LIMITS = [64, 65, 74, 80]          # reference training/eval default (dataset_loop_detection.py:25,80)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
