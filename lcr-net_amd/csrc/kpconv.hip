@@ -57,7 +57,7 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate_vec(const fl
                                                                         const int32_t* __restrict__ order) {
   constexpr int V = C >= 64 ? 4 : 2;
   constexpr int NL = C / (16 * V);           // vector loads per lane per 4-neighbour step
-  constexpr int D = NL == 1 ? 4 : 2;         // steps in flight
+  constexpr int D = NL == 1 ? 4 : 2;         // steps in flight (register ring)
   typedef typename VecOf<V>::type VecT;
   __shared__ __attribute__((aligned(16))) float4 s_rel[KP_WAVES][KP_HMAX + 8];   // (dx, dy, dz, bits(index)) per valid neighbour
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -107,24 +107,33 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate_vec(const fl
 #pragma unroll
       for (int q = 0; q < NL; ++q) ff[q] = *reinterpret_cast<const VecT*>(r + q * 16 * V);
     };
+    // Branch-free steady state: steps are rounded up to a multiple of D and every fetch is issued unconditionally with its
+    // neighbour index clamped (a duplicate of the last row: a cache hit whose influence is masked to zero).  One basic block per
+    // trip keeps the s_waitcnt counts exact, so the D-step register ring really runs D steps ahead; with conditional fetches
+    // the compiler waited for vmcnt(0) — the load it had just issued — before every MFMA group.
+    if (n > 0) {
+      auto compute = [&](int s, const float4& pp, const VecT (&ff)[NL]) {
+        const float ex = pp.x - kx, ey = pp.y - ky, ez = pp.z - kz;
+        float wv = fmaxf(1.f - __builtin_amdgcn_sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * inv_sigma, 0.f);
+        wv = (real_k && 4 * s + sub < n) ? wv : 0.f;
 #pragma unroll
-    for (int d = 0; d < D; ++d)
-      if (d < steps) fetch(d, p[d], f[d]);
-    for (int s0 = 0; s0 < steps; s0 += D) {
+        for (int q = 0; q < NL; ++q)
 #pragma unroll
-      for (int d = 0; d < D; ++d) {
-        const int s = s0 + d;
-        if (s < steps) {                                     // wave-uniform
-          const float ex = p[d].x - kx, ey = p[d].y - ky, ez = p[d].z - kz;
-          float wv = fmaxf(1.f - __builtin_amdgcn_sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * inv_sigma, 0.f);
-          wv = (real_k && 4 * s + sub < n) ? wv : 0.f;
+          for (int v = 0; v < V; ++v) acc[q][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, vget(ff[q], v), acc[q][v], 0, 0, 0);
+      };
 #pragma unroll
-          for (int q = 0; q < NL; ++q)
+      for (int d = 0; d < D; ++d) fetch(d, p[d], f[d]);
+      int s0 = 0;
+      for (; s0 + D <= steps; s0 += D) {                    // full trips: D x (compute, refill), no branch inside
 #pragma unroll
-            for (int v = 0; v < V; ++v) acc[q][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, vget(f[d][q], v), acc[q][v], 0, 0, 0);
-          if (s + D < steps) fetch(s + D, p[d], f[d]);
+        for (int d = 0; d < D; ++d) {
+          compute(s0 + d, p[d], f[d]);
+          fetch(s0 + d + D, p[d], f[d]);
         }
       }
+#pragma unroll
+      for (int d = 0; d < D - 1; ++d)                       // the last steps % D steps: their rows are already on the way
+        if (s0 + d < steps) compute(s0 + d, p[d], f[d]);
     }
     float* out = A + m * (KP_K * C) + V * col;
 #pragma unroll
