@@ -191,7 +191,7 @@ __global__ __launch_bounds__(RS_WAVES * 64) void k_radius_query(const float* __r
                                                                  const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
                                                                  float r2, int limit, int64_t* __restrict__ out64,
                                                                  int32_t* __restrict__ out32, int32_t* __restrict__ out_cnt) {
-  __shared__ uint64_t s_keys[RS_WAVES][RS_CAP];
+  __shared__ __attribute__((aligned(16))) uint64_t s_keys[RS_WAVES][RS_CAP + 16];   // + sentinel padding of the rank loop
   __shared__ int s_run_a[RS_WAVES][12];     // first sorted slot of each x-run
   __shared__ int s_run_p[RS_WAVES][12];     // exclusive prefix of run lengths
   __shared__ int64_t s_qoff[GRID_MAX_B + 1];
@@ -258,16 +258,22 @@ __global__ __launch_bounds__(RS_WAVES * 64) void k_radius_query(const float* __r
       float d2[RS_UNROLL];
       uint32_t idx[RS_UNROLL];
       bool pass[RS_UNROLL];
+      // unconditional loads with the candidate index clamped (lanes beyond `total` re-read the last candidate and are masked
+      // out afterwards): a load inside a lane-conditional block made the compiler wait for it at the end of the block, so the
+      // RS_UNROLL loads were never in flight together
+      float4 P[RS_UNROLL];
 #pragma unroll
       for (int u = 0; u < RS_UNROLL; ++u) {
-        const int t = t0 + 64 * u + lane;
-        d2[u] = 0.f;
-        idx[u] = 0;
-        pass[u] = false;
-        if (t < total) {
-          candidate(t, d2[u], idx[u]);
-          pass[u] = d2[u] < r2;
-        }
+        const int t = min(t0 + 64 * u + lane, total - 1);
+        const int r = (t >= p1) + (t >= p2) + (t >= p3) + (t >= p4) + (t >= p5) + (t >= p6) + (t >= p7) + (t >= p8);
+        P[u] = sorted[s_run_a[w][r] + (t - s_run_p[w][r])];
+      }
+#pragma unroll
+      for (int u = 0; u < RS_UNROLL; ++u) {
+        const float dx = fsub(qx, P[u].x), dy = fsub(qy, P[u].y), dz = fsub(qz, P[u].z);
+        d2[u] = fadd(fadd(fmul(dx, dx), fmul(dy, dy)), fmul(dz, dz));
+        idx[u] = __float_as_uint(P[u].w);
+        pass[u] = (t0 + 64 * u + lane < total) && d2[u] < r2;
       }
 #pragma unroll
       for (int u = 0; u < RS_UNROLL; ++u) {
@@ -290,15 +296,24 @@ __global__ __launch_bounds__(RS_WAVES * 64) void k_radius_query(const float* __r
     int32_t* row32 = HAS32 ? out32 + qi * static_cast<int64_t>(limit) : nullptr;
 
     if (n <= RS_CAP) {
-      // all-pairs rank over the LDS keys (keys are unique: the index is part of the key)
+      // all-pairs rank over the LDS keys (keys are unique: the index is part of the key).  The list is padded to a multiple of
+      // 16 with all-ones sentinels (never smaller than a key) so that the comparison loop runs in groups of 16 broadcast reads:
+      // with 4 per group the loop was bound by LDS latency and took half of the kernel.
+      if (lane < 16 && n + lane < ((n + 15) & ~15)) keys[n + lane] = ~0ull;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int n16 = (n + 15) & ~15;
       for (int e = lane; e < n; e += 64) {
         const uint64_t k = keys[e];
         int rank = 0;
-        int j = 0;
-        for (; j + 4 <= n; j += 4) {
-          rank += (keys[j] < k) + (keys[j + 1] < k) + (keys[j + 2] < k) + (keys[j + 3] < k);
+        for (int j = 0; j < n16; j += 16) {
+          ulonglong2 kj[8];                       // 8 x ds_read_b128 (two keys each), all lanes the same address
+#pragma unroll
+          for (int u = 0; u < 8; ++u) kj[u] = *reinterpret_cast<const ulonglong2*>(&keys[j + 2 * u]);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) rank += (kj[u].x < k) + (kj[u].y < k);
         }
-        for (; j < n; ++j) rank += keys[j] < k;
         if (rank < limit) {
           const int64_t v = static_cast<int64_t>(static_cast<uint32_t>(k));
           if (HAS64) row64[rank] = v;
