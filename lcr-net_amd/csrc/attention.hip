@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64) void k_attention(const float* __restrict__ q, c
 // y = LayerNorm(a + b) * gamma + beta, rows of D (<= 1024) features; one wavefront per row
 __global__ __launch_bounds__(256) void k_add_layernorm(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int64_t N, int D, float eps, float* __restrict__ y) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
   for (int64_t n = static_cast<int64_t>(blockIdx.x) * 4 + w; n < N; n += static_cast<int64_t>(gridDim.x) * 4) {
     float vals[16];
     float s = 0.f;

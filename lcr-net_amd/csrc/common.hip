@@ -22,7 +22,7 @@ constexpr int SCAN_I = 16;
 constexpr int SCAN_TILE = SCAN_T * SCAN_I;
 
 __device__ __forceinline__ int block_excl_scan(int v, int* total, int* lds /*>=4+1 ints*/) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
   int inc = wave_incl_scan(v);
   if (lane == 63) lds[w] = inc;
   __syncthreads();

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ 
   __shared__ __attribute__((aligned(16))) float As[2][GM_BK * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[2][GM_BK * LDB];
 
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
   const int wm = w / WN, wn = w % WN;
   // XCD-aware tile order.  Workgroups go round-robin to the 8 XCDs (linear id % 8), each with its own L2; the column tiles
   // of one row block all read the same A rows, so they are given ids that land on ONE XCD back to back: the A tile is then

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void k_gs_insertion(const GsHeader* __restrict
 
 // ---- libstdc++ unordered_map iteration order, one workgroup per cloud -----------------------------------------------
 __device__ __forceinline__ int hm_block_excl_scan(int v, int* total, int* lds) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
   const int inc = wave_incl_scan(v);
   if (lane == 63) lds[w] = inc;
   __syncthreads();

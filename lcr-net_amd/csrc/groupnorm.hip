@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, G
 __global__ __launch_bounds__(256) void k_gn_stats(const float* __restrict__ x, int64_t N, int C, int groups, const int64_t* __restrict__ seg_len,
                                                   int S, double* __restrict__ stats) {
   const int gs = C / groups;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
   const int64_t r0 = (static_cast<int64_t>(blockIdx.x) * 4 + w) * 64;
   const int64_t r1 = r0 + 64 < N ? r0 + 64 : N;
   if (r0 >= N) return;

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate_vec(const fl
   constexpr int D = NL == 1 ? 4 : 2;         // steps in flight (register ring)
   typedef typename VecOf<V>::type VecT;
   __shared__ __attribute__((aligned(16))) float4 s_rel[KP_WAVES][KP_HMAX + 8];   // (dx, dy, dz, bits(index)) per valid neighbour
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
   const int sub = lane >> 4, col = lane & 15;
   const float inv_sigma = 1.f / sigma;
   float kx = 0.f, ky = 0.f, kz = 0.f;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_cin1(const float* __re
                                                                const float* __restrict__ bias, int Cout, float* __restrict__ out,
                                                                const int32_t* __restrict__ order) {
   __shared__ float s_a[KP_WAVES][16];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
   // this lane's output channel(s): the (15, Cout) weights and the bias stay in registers for every query of the wavefront
   constexpr int MAXO = 4;                       // Cout <= 256
   float wreg[MAXO][KP_K], breg[MAXO];
@@ -237,7 +237,7 @@ template <typename IdxT>
 __global__ __launch_bounds__(256) void k_maxpool(const float* __restrict__ x, const IdxT* __restrict__ idx, int64_t M, int64_t Ns, int H, int C,
                                                  float* __restrict__ out, const int32_t* __restrict__ order) {
   __shared__ int32_t s_idx[4][KP_HMAX];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
   for (int64_t t = static_cast<int64_t>(blockIdx.x) * 4 + w; t < M; t += static_cast<int64_t>(gridDim.x) * 4) {
     const int64_t m = order ? order[t] : t;
     int n = 0;
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void k_maxpool(const float* __restrict__ x, co
 
 // pos[n] = (sum_c x[n][c] > 0): the per-support flag behind KPConv's neighbour count (kpconv.py:113-114)
 __global__ __launch_bounds__(256) void k_row_pos(const float* __restrict__ x, int64_t N, int C, uint8_t* __restrict__ pos) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
   for (int64_t n = static_cast<int64_t>(blockIdx.x) * 4 + w; n < N; n += static_cast<int64_t>(gridDim.x) * 4) {
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += x[n * C + c];

@@ -32,7 +32,7 @@ struct BnParams {
 };
 
 __global__ __launch_bounds__(256) void k_row_l2norm(const float* __restrict__ x, int64_t N, int C, float eps, float* __restrict__ y) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
   for (int64_t n = static_cast<int64_t>(blockIdx.x) * 4 + w; n < N; n += static_cast<int64_t>(gridDim.x) * 4) {
     float ss = 0.f;
     for (int c = lane; c < C; c += 64) {
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_row_l2norm(const float* __restrict__ x,
 
 // act[n][k] <- softmax_k( BN_eval(act[n][k]) ), lane = cluster (64 clusters = one wavefront)
 __global__ __launch_bounds__(256) void k_bn_softmax64(float* __restrict__ act, int64_t N, BnParams bn, float eps) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
   const float scale = bn.w[lane] / sqrtf(bn.var[lane] + eps);
   const float mean = bn.mean[lane], beta = bn.b[lane];
   for (int64_t n = static_cast<int64_t>(blockIdx.x) * 4 + w; n < N; n += static_cast<int64_t>(gridDim.x) * 4) {

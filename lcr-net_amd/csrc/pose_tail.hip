@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void k_top1_stats(const float* __restrict__ lo
   const int b = blockIdx.x;
   const int M1 = M + 1, N1 = N + 1;
   const float* s = logS + static_cast<int64_t>(b) * M1 * N1;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
   for (int i = w; i < M1; i += 4) {
     float best = -INFINITY;
     int bj = 0;

@@ -14,6 +14,8 @@
 // (key = d2 bits << 32 | index; n ~ 50 so n^2/64 work per lane beats a padded bitonic network).  Rows whose
 // in-radius count exceeds the LDS capacity fall back to a storage-free rank by re-enumeration (exact, slow, rare).
 // HBM-bound by its output rows (limit * 4 or 8 bytes per query); everything else stays in L2.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace lcr {
@@ -196,18 +198,16 @@ __global__ __launch_bounds__(RS_WAVES * 64) void k_radius_query(const float* __r
   __shared__ int s_run_p[RS_WAVES][12];     // exclusive prefix of run lengths
   __shared__ int64_t s_qoff[GRID_MAX_B + 1];
 
-  if (threadIdx.x == 0) {
-    int64_t o = 0;
-    for (int b = 0; b < B; ++b) {
-      s_qoff[b] = o;
-      o += qlen[b];
-    }
-    s_qoff[B] = o;
+  if (threadIdx.x < 64) {                                   // prefix of the query lengths: one load + a wavefront scan
+    const int64_t len_b = threadIdx.x < B ? qlen[threadIdx.x] : 0;
+    const int64_t inc = wave_incl_scan(len_b);
+    if (threadIdx.x < B) s_qoff[threadIdx.x] = inc - len_b;
+    if (threadIdx.x == B - 1) s_qoff[B] = inc;
   }
   __syncthreads();
   const int64_t nq = min(s_qoff[B], nq_cap);
   const int64_t ns_total = h->ns_total;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index as a scalar: per-query values stay in SGPRs
   uint64_t* keys = s_keys[w];
 
   for (int64_t qi = static_cast<int64_t>(blockIdx.x) * RS_WAVES + w; qi < nq; qi += static_cast<int64_t>(gridDim.x) * RS_WAVES) {
@@ -414,7 +414,9 @@ extern "C" int lcr_radius_query(const float* q, const int64_t* qlen, int B, int6
   GridLayout L = grid_layout(const_cast<void*>(grid_ws), ns_cap, B);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float r2 = radius * radius;   // fp32 product, as radius_neighbors_cpu.cpp:12
-  const int nblk = min(div_up(nq_cap, RS_WAVES), 256 * 8 * 4);
+  // few, long-lived workgroups: the per-workgroup prologue (query offsets) and launch ramp were ~40 % of the kernel with one
+  // workgroup per 4-16 queries
+  const int nblk = min(div_up(nq_cap, RS_WAVES), getenv("LCR_RS_NBLK") ? atoi(getenv("LCR_RS_NBLK")) : 256 * 8 * 4);
   const dim3 grid(nblk), block(RS_WAVES * 64);
   if (out_idx64 && out_idx32)
     hipLaunchKernelGGL((k_radius_query<true, true>), grid, block, 0, st, q, qlen, B, nq_cap, L.hdr, L.cell_start, L.sorted, r2, limit,

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(RX_T) void k_rx_scatter(const RadixCtl* __restrict_
   const uint32_t* vin = (pass & 1) ? vB_ : vA;
   uint32_t* vout = (pass & 1) ? const_cast<uint32_t*>(vA) : vB_;
 
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
   for (int d = lane; d < 256; d += 64) s_cnt[w][d] = 0;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();

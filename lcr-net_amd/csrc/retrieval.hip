@@ -26,7 +26,7 @@ constexpr int TK_CHUNK = 16384;  // columns staged in LDS per pass (keys are 8 B
 constexpr int TK_KMAX = 128;     // largest k supported
 
 __global__ __launch_bounds__(256) void k_row_sqnorm(const float* __restrict__ x, int64_t N, int D, float* __restrict__ out) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
   for (int64_t n = static_cast<int64_t>(blockIdx.x) * 4 + w; n < N; n += static_cast<int64_t>(gridDim.x) * 4) {
     float s = 0.f;
     for (int c = lane; c < D; c += 64) {
