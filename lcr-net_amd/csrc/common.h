@@ -126,6 +126,50 @@ __device__ __forceinline__ void bbox_accumulate(const float* __restrict__ xyz, i
   }
 }
 
+// ---- wavefront reductions on the DPP data path ----------------------------------------------------
+// __shfl_* compiles to ds_bpermute_b32 (the LDS crossbar: ~50-100 cycles per step, each step waiting for the previous), which
+// made a six-step sum / scan cost ~500 cycles per call in the wavefront-per-query kernels.  Row-level steps (16 lanes) run as
+// DPP modifiers of plain VALU instructions; the four row totals are combined through v_readlane (scalar).
+template <int CTRL>
+__device__ __forceinline__ int dpp0(int v) {                 // lanes without a source read 0
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp0(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+constexpr int DPP_QUAD_1032 = 0xB1, DPP_QUAD_2301 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+
+template <typename T>
+__device__ __forceinline__ T row_sum16(T v) {                // every lane of a 16-lane row gets the row's sum
+  v += dpp0<DPP_QUAD_1032>(v);
+  v += dpp0<DPP_QUAD_2301>(v);
+  v += dpp0<DPP_ROW_HALF_MIRROR>(v);
+  v += dpp0<DPP_ROW_MIRROR>(v);
+  return v;
+}
+__device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float rdlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+__device__ __forceinline__ int wave_sum(int v) {
+  v = row_sum16(v);
+  return rdlane(v, 0) + rdlane(v, 16) + rdlane(v, 32) + rdlane(v, 48);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row_sum16(v);
+  return (rdlane(v, 0) + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
+}
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  v += dpp0<DPP_ROW_SHR1>(v);                                // inclusive scan inside each 16-lane row
+  v += dpp0<DPP_ROW_SHR2>(v);
+  v += dpp0<DPP_ROW_SHR4>(v);
+  v += dpp0<DPP_ROW_SHR8>(v);
+  const int r0 = rdlane(v, 15), r1 = rdlane(v, 31), r2 = rdlane(v, 47);
+  const int row = lane_id() >> 4;
+  return v + (row > 0 ? r0 : 0) + (row > 1 ? r1 : 0) + (row > 2 ? r2 : 0);
+}
+// other types (int64 lengths, doubles): the generic cross-lane form
 template <typename T>
 __device__ __forceinline__ T wave_incl_scan(T v) {
 #pragma unroll

@@ -82,14 +82,15 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate_vec(const fl
       if (h < H) j = static_cast<int64_t>(idx[m * H + h]);
       const bool ok = j >= 0 && j < Ns;
       const uint64_t mk = __ballot(ok);
+      bool positive = false;
       if (ok) {
         const int slot = n + __popcll(mk & lanemask_lt());
         s_rel[w][slot] = make_float4(s_pts[3 * j] - qx, s_pts[3 * j + 1] - qy, s_pts[3 * j + 2] - qz, __uint_as_float(static_cast<uint32_t>(j)));
-        cnt += s_pos[j] ? 1 : 0;
+        positive = s_pos[j] != 0;
       }
       n += __popcll(mk);
+      cnt += __popcll(__ballot(positive));      // scalar popcount of a lane mask instead of a six-step cross-lane sum
     }
-    cnt = wave_sum(cnt);
     wave_lds_sync();
 
     floatx4 acc[NL][V];
