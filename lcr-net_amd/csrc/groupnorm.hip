@@ -87,47 +87,82 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, G
   }
   __syncthreads();
   const int64_t t_lo = row_lo * c4n, t_hi = row_hi * c4n;
-  for (int64_t t = t_lo + threadIdx.x; t < ((t_hi - t_lo + 63) & ~int64_t(63)) + t_lo; t += blockDim.x) {
-    const bool live = t < t_hi;
-    const int64_t n = live ? t / c4n : row_hi - 1;
-    const int c0 = live ? static_cast<int>(t - n * c4n) * 4 : 0;
-    int s = seg_lo;
-    while (s < seg_hi && n >= s_start[s + 1]) ++s;
-    const float4 xv = *reinterpret_cast<const float4*>(x + n * C + c0);
-    const float4 gam = *reinterpret_cast<const float4*>(gx.gamma + c0);
-    const float4 bet = *reinterpret_cast<const float4*>(gx.beta + c0);
-    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f), rgam = rv, rbet = rv;
-    if (res) rv = *reinterpret_cast<const float4*>(res + n * C + c0);
+  // One element = 4 consecutive channels of one row.  The per-channel parameters depend only on the channel offset, which is
+  // the SAME in every iteration of a thread when the block size is a multiple of C/4 (every C this model uses): they are
+  // loaded once; the row data of GU iterations is requested before any of it is used (the kernel is a pure stream).
+  constexpr int GU = 4;
+  const bool fixed_c = (blockDim.x % c4n) == 0;
+  float4 gam_f = make_float4(0.f, 0.f, 0.f, 0.f), bet_f = gam_f, rgam_f = gam_f, rbet_f = gam_f;
+  const int c0_f = static_cast<int>(threadIdx.x % c4n) * 4;
+  if (fixed_c) {
+    gam_f = *reinterpret_cast<const float4*>(gx.gamma + c0_f);
+    bet_f = *reinterpret_cast<const float4*>(gx.beta + c0_f);
     if (gr.stats) {
-      rgam = *reinterpret_cast<const float4*>(gr.gamma + c0);
-      rbet = *reinterpret_cast<const float4*>(gr.beta + c0);
+      rgam_f = *reinterpret_cast<const float4*>(gr.gamma + c0_f);
+      rbet_f = *reinterpret_cast<const float4*>(gr.beta + c0_f);
     }
-    const float xin[4] = {xv.x, xv.y, xv.z, xv.w}, g4[4] = {gam.x, gam.y, gam.z, gam.w}, b4[4] = {bet.x, bet.y, bet.z, bet.w};
-    const float rin[4] = {rv.x, rv.y, rv.z, rv.w}, rg4[4] = {rgam.x, rgam.y, rgam.z, rgam.w}, rb4[4] = {rbet.x, rbet.y, rbet.z, rbet.w};
-    float out[4];
-    float rowsum = 0.f;
+  }
+  const int64_t t_end = ((t_hi - t_lo + 63) & ~int64_t(63)) + t_lo;
+  for (int64_t tb = t_lo + threadIdx.x; tb < t_end; tb += static_cast<int64_t>(GU) * blockDim.x) {
+    float4 xv[GU], rv[GU];
+    int64_t nrow[GU];
+    int c0s[GU];
+    bool live[GU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int gi = (s - seg_lo) * groups + (c0 + u) / gs;
-      const float2 mr = s_x[gi];
-      float v = (xin[u] - mr.x) * mr.y * g4[u] + b4[u];
-      if (res) {
-        float r = rin[u];
-        if (gr.stats) {
-          const float2 rr = s_r[gi];
-          r = (r - rr.x) * rr.y * rg4[u] + rb4[u];
-        }
-        v += r;
-      }
-      if (act) v = v > 0.f ? v : v * slope;
-      out[u] = v;
-      rowsum += v;
+    for (int k = 0; k < GU; ++k) {
+      const int64_t t = tb + static_cast<int64_t>(k) * blockDim.x;
+      live[k] = t < t_hi;
+      nrow[k] = live[k] ? t / c4n : row_hi - 1;
+      c0s[k] = live[k] ? static_cast<int>(t - nrow[k] * c4n) * 4 : 0;
+      xv[k] = *reinterpret_cast<const float4*>(x + nrow[k] * C + c0s[k]);
+      rv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (res) rv[k] = *reinterpret_cast<const float4*>(res + nrow[k] * C + c0s[k]);
     }
-    if (live) *reinterpret_cast<float4*>(y + n * C + c0) = make_float4(out[0], out[1], out[2], out[3]);
-    if (POS) {
-      // the c4n (<= 64, power of two) lanes of a row are consecutive and aligned inside the wavefront
-      for (int d = 1; d < c4n; d <<= 1) rowsum += __shfl_xor(rowsum, d);
-      if (live && c0 == 0) pos[n] = rowsum > 0.f ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < GU; ++k) {
+      const int64_t t = tb + static_cast<int64_t>(k) * blockDim.x;
+      if (t >= t_end) break;                       // wave-uniform: t_end - t_lo is a multiple of 64
+      const int64_t n = nrow[k];
+      const int c0 = c0s[k];
+      int s = seg_lo;
+      while (s < seg_hi && n >= s_start[s + 1]) ++s;
+      float4 gam = gam_f, bet = bet_f, rgam = rgam_f, rbet = rbet_f;
+      if (!fixed_c) {
+        gam = *reinterpret_cast<const float4*>(gx.gamma + c0);
+        bet = *reinterpret_cast<const float4*>(gx.beta + c0);
+        if (gr.stats) {
+          rgam = *reinterpret_cast<const float4*>(gr.gamma + c0);
+          rbet = *reinterpret_cast<const float4*>(gr.beta + c0);
+        }
+      }
+      const float xin[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w}, g4[4] = {gam.x, gam.y, gam.z, gam.w}, b4[4] = {bet.x, bet.y, bet.z, bet.w};
+      const float rin[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w}, rg4[4] = {rgam.x, rgam.y, rgam.z, rgam.w},
+                  rb4[4] = {rbet.x, rbet.y, rbet.z, rbet.w};
+      float out[4];
+      float rowsum = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int gi = (s - seg_lo) * groups + (c0 + u) / gs;
+        const float2 mr = s_x[gi];
+        float v = (xin[u] - mr.x) * mr.y * g4[u] + b4[u];
+        if (res) {
+          float r = rin[u];
+          if (gr.stats) {
+            const float2 rr = s_r[gi];
+            r = (r - rr.x) * rr.y * rg4[u] + rb4[u];
+          }
+          v += r;
+        }
+        if (act) v = v > 0.f ? v : v * slope;
+        out[u] = v;
+        rowsum += v;
+      }
+      if (live[k]) *reinterpret_cast<float4*>(y + n * C + c0) = make_float4(out[0], out[1], out[2], out[3]);
+      if (POS) {
+        // the c4n (<= 64, power of two) lanes of a row are consecutive and aligned inside the wavefront
+        for (int d = 1; d < c4n; d <<= 1) rowsum += __shfl_xor(rowsum, d);
+        if (live[k] && c0 == 0) pos[n] = rowsum > 0.f ? 1 : 0;
+      }
     }
   }
 }
