@@ -11,6 +11,8 @@
 // so a stage's grid build and searches overlap the next stage's subsampling.  Results land in one caller-provided arena whose
 // layout lcr_precompute_layout reports; capacities are bounded by the stage-0 point count (every stage is a subset sample).
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "common.h"
 
@@ -25,22 +27,43 @@ struct PreCtx {
   bool        ok = false;
 };
 
-static PreCtx& pre_ctx() {
-  static thread_local PreCtx c;      // one set of side streams per host thread that drives pre-processing
+// Side streams, events and the pinned staging buffer are pooled: a call borrows one context (concurrent calls from different
+// host threads get different ones) and returns it, so short-lived driver threads do not leak streams.
+static std::mutex g_ctx_mu;
+static std::vector<PreCtx*> g_ctx_pool;
+
+static PreCtx* acquire_ctx() {
   int dev = 0;
   hipGetDevice(&dev);
-  if (!c.ok || c.device != dev) {
-    for (int i = 0; i < LCR_MAX_STAGES; ++i) {
-      hipStreamCreateWithFlags(&c.side[i], hipStreamNonBlocking);
-      hipEventCreateWithFlags(&c.ready[i], hipEventDisableTiming);
-      hipEventCreateWithFlags(&c.done[i], hipEventDisableTiming);
-    }
-    hipHostMalloc(reinterpret_cast<void**>(&c.pinned), sizeof(int64_t) * (LCR_MAX_STAGES * 64 + 8), hipHostMallocDefault);
-    c.device = dev;
-    c.ok = true;
+  {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    for (size_t i = 0; i < g_ctx_pool.size(); ++i)
+      if (g_ctx_pool[i]->device == dev) {
+        PreCtx* c = g_ctx_pool[i];
+        g_ctx_pool.erase(g_ctx_pool.begin() + static_cast<long>(i));
+        return c;
+      }
   }
+  PreCtx* c = new PreCtx();
+  for (int i = 0; i < LCR_MAX_STAGES; ++i) {
+    hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking);
+    hipEventCreateWithFlags(&c->ready[i], hipEventDisableTiming);
+    hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming);
+  }
+  hipHostMalloc(reinterpret_cast<void**>(&c->pinned), sizeof(int64_t) * (LCR_MAX_STAGES * 64 + 8), hipHostMallocDefault);
+  c->device = dev;
+  c->ok = true;
   return c;
 }
+
+struct CtxLease {
+  PreCtx* c;
+  CtxLease() : c(acquire_ctx()) {}
+  ~CtxLease() {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    g_ctx_pool.push_back(c);
+  }
+};
 
 struct PreWs {
   uint32_t* status;                       // [1] shared device status word
@@ -134,7 +157,8 @@ extern "C" int lcr_precompute_batch(const float* points0, const int64_t* lengths
   PreWs W;
   int rc = carve_ws(ws, *L, &W);
   if (rc) return rc;
-  PreCtx& C = pre_ctx();
+  CtxLease lease;                      // returned to the pool on every exit path (all work is joined into `stream` first)
+  PreCtx& C = *lease.c;
   hipStream_t main = static_cast<hipStream_t>(stream);
   char* o = static_cast<char*>(out);
   const float* pts[LCR_MAX_STAGES];
