@@ -194,8 +194,11 @@ __global__ __launch_bounds__(256) void k_gs_keys(GsHeader* h, const float* __res
     const uint64_t iy = f2u64(floorf(fdiv(fsub(xyz[3 * i + 1], h->org[b][1]), voxel)));   // :33
     const uint64_t iz = f2u64(floorf(fdiv(fsub(xyz[3 * i + 2], h->org[b][2]), voxel)));   // :34
     const uint64_t key = ix + h->NX[b] * iy + h->NX[b] * h->NY[b] * iz;                    // :35 (wraps mod 2^64 like size_t)
+    // a key that does not fit the promised bits is reported AND truncated: the result of this call is then garbage (the host
+    // retries), but the cloud field stays intact, so every cloud's voxels remain inside its own slice of the work arrays
     if (kbits < 64 && (key >> kbits) != 0) atomicOr(status, LCR_STATUS_KEY_OVERFLOW);
-    keyA[i] = (kbits < 64 ? (static_cast<uint64_t>(b) << kbits) : 0ull) | key;
+    const uint64_t kmask = kbits < 64 ? ((1ull << kbits) - 1ull) : ~0ull;
+    keyA[i] = (kbits < 64 ? (static_cast<uint64_t>(b) << kbits) : 0ull) | (key & kmask);
     valA[i] = static_cast<uint32_t>(i);
   }
 }

@@ -133,3 +133,49 @@ def test_neighbor_limit_calibration_matches_reference_demo_values():
     clouds = [dev(load_scan("003854")), dev(load_scan("000958"))]
     limits = calibrate_neighbors_stack_mode(clouds, NUM_STAGES, VOXEL, RADIUS)
     assert limits.tolist() == LIMITS
+
+
+def test_key_bits_promise_broken_then_retried():
+    """A cloud with two far-away outliers needs more voxel-key bits than the 32 the raw-scan ingest promises: the device raises
+    LCR_STATUS_KEY_OVERFLOW and voxelize_raw_scans retries with 64-bit-safe keys — result == oracle, bit for bit."""
+    from lcrnet_amd.data import voxelize_raw_scans
+    from lcrnet_amd.modules.ops import grid_subsample_device
+    rng = np.random.default_rng(3)
+    xyz = (rng.random((4000, 3)) * np.array([40, 40, 3]) - 20).astype(np.float32)
+    xyz[7] = (30000.0, -25000.0, 9000.0)                      # 2e5 x 2e5 x 3e4 voxels of 0.3 m: ~50 key bits
+    xyz[1234] = (-31000.0, 28000.0, -2000.0)
+    lens = np.array([1500, 2500], dtype=np.int64)
+    _, _, st = grid_subsample_device(dev(xyz), dev(lens), 0.3, key_bits_hint=32)
+    assert int(st.item()) & 1, "the broken promise must be reported, not silently mis-sorted"
+    got_p, got_l, got_lh = voxelize_raw_scans(dev(xyz), dev(lens), 0.3)
+    want_p, want_l = oracle_ops.grid_subsample(xyz, lens, 0.3)
+    assert got_lh == want_l.tolist() and np.array_equal(got_l.cpu().numpy(), want_l)
+    assert np.array_equal(got_p.cpu().numpy().view(np.uint32), want_p.view(np.uint32))
+
+
+def test_negative_coordinates_and_queries_outside_the_support_box():
+    from lcrnet_amd.modules.ops import radius_search
+    rng = np.random.default_rng(11)
+    s = (rng.random((3000, 3)) * 20 - 30).astype(np.float32)              # all-negative support box
+    q = np.concatenate([s[:50] + 0.01, (rng.random((50, 3)) * 400 - 200).astype(np.float32)])   # half of the queries far outside
+    ql, sl = np.array([60, 40]), np.array([1800, 1200])
+    want, cnt = oracle_ops.radius_search(q, s, ql, sl, 2.5, 40, return_counts=True)
+    got = radius_search(dev(q), dev(s), dev(ql), dev(sl), 2.5, 40)
+    assert np.array_equal(got.cpu().numpy(), want) and (cnt == 0).any() and (cnt > 0).any()
+
+
+def test_sixty_four_clouds_and_the_limit_beyond():
+    from lcrnet_amd.modules.ops import grid_subsample, radius_search
+    rng = np.random.default_rng(2)
+    B = 64
+    sizes = rng.integers(0, 200, B)
+    xyz = (rng.random((int(sizes.sum()), 3)) * 12).astype(np.float32)
+    lens = sizes.astype(np.int64)
+    want_p, want_l = oracle_ops.grid_subsample(xyz, lens, 1.0)
+    got_p, got_l = grid_subsample(dev(xyz), dev(lens), 1.0)
+    assert np.array_equal(got_l.cpu().numpy(), want_l) and np.array_equal(got_p.cpu().numpy().view(np.uint32), want_p.view(np.uint32))
+    want = oracle_ops.radius_search(xyz, xyz, lens, lens, 1.5, 16)
+    got = radius_search(dev(xyz), dev(xyz), dev(lens), dev(lens), 1.5, 16)
+    assert np.array_equal(got.cpu().numpy(), want)
+    with pytest.raises(RuntimeError):
+        grid_subsample(dev(xyz), dev(np.concatenate([lens, [0]])), 1.0)        # 65 clouds
