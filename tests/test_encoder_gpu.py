@@ -48,7 +48,9 @@ def to_dev(dd):
 
 
 @pytest.mark.parametrize("M,N,K,ta,tb", [(1000, 64, 96, 0, 0), (777, 32, 480, 0, 0), (300, 128, 64, 0, 1), (129, 256, 1920, 0, 0),
-                                          (1024, 64, 844, 1, 0), (5, 1024, 256, 0, 1), (4097, 64, 960, 0, 0), (260, 96, 100, 1, 1)])
+                                          (1024, 64, 844, 1, 0), (5, 1024, 256, 0, 1), (4097, 64, 960, 0, 0), (260, 96, 100, 1, 1),
+                                          (1000, 37, 45, 0, 0), (333, 7, 33, 0, 1), (65, 130, 31, 1, 0), (1, 1, 1, 0, 0),   # non-vector paths
+                                          (70000, 32, 32, 0, 1), (513, 160, 2048, 0, 0)])
 def test_gemm_f32_matches_torch(M, N, K, ta, tb):
     from lcrnet_amd import functional as F
     g = torch.Generator().manual_seed(M + N + K)
@@ -77,6 +79,27 @@ def test_gemm_groupnorm_statistics_segmented():
         assert torch.allclose(stats[s, :, 0].cpu(), blk.sum((0, 2)), rtol=1e-5, atol=1e-3)   # 16-value fp32 partials, fp64 across
         assert torch.allclose(stats[s, :, 1].cpu(), (blk ** 2).sum((0, 2)), rtol=1e-5, atol=1e-3)
         o += n
+
+
+@pytest.mark.parametrize("M,N,K,groups,segs", [(3000, 1024, 64, 32, [1000, 2000]), (900, 32, 64, 32, [900]), (2100, 256, 96, 32, [64, 1, 63, 1972]),
+                                               (4000, 128, 32, 2, [1500, 2500])])
+def test_gemm_statistics_shapes(M, N, K, groups, segs):
+    """Groups wider than one 64-column tile (N=1024 -> 32 channels per group ... N=128/groups=2 -> 64), one-channel groups,
+    segment boundaries on and off tile borders: fp64 sums vs torch."""
+    from lcrnet_amd import functional as F
+    g = torch.Generator().manual_seed(M + N)
+    a, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    seg = torch.tensor(segs)
+    c, stats = F.gemm(a.cuda(), b.cuda(), trans_b=True, seg_len=seg.cuda(), groups=groups)
+    stats = stats.sum(0).cpu()
+    want = a.double() @ b.double().t()
+    assert (c.cpu().double() - want).abs().max().item() < 2e-4 * want.abs().max().item()
+    r0 = 0
+    for si, n in enumerate(segs):
+        blk = want[r0:r0 + n].reshape(n, groups, N // groups)
+        r0 += n
+        assert torch.allclose(stats[si, :, 0], blk.sum((0, 2)), rtol=1e-5, atol=2e-2)
+        assert torch.allclose(stats[si, :, 1], (blk ** 2).sum((0, 2)), rtol=1e-5, atol=2e-2)
 
 
 def test_residual_blocks_match_torch_ref(model):
@@ -149,3 +172,35 @@ def test_pair_stack_groupnorm_over_pair(model, model_golden):
     assert (fc.cpu()[r] - torch.from_numpy(model_golden["pair/feats_c_vals"])).abs().max().item() < 1e-3
     assert (g[0] - torch.from_numpy(model_golden["pair/pos_global"])[0]).abs().max().item() < DESC_TOL
     assert (g[1] - torch.from_numpy(model_golden["pair/anc_global"])[0]).abs().max().item() < DESC_TOL
+
+
+@pytest.mark.parametrize("C", [32, 64, 128, 256])
+def test_aggregate_rows_without_neighbours_and_single_column(C):
+    """Rows whose neighbour list is all shadow (index == N_support) aggregate to zero with count 1 (kpconv.py:113-116 clamps the
+    count at 1); H = 1 works; matches the torch restatement on random neighbourhoods."""
+    from lcrnet_amd import functional as F
+    from lcrnet_amd.weights import base_kernel_points
+    from oracle import torch_ref
+    g = torch.Generator().manual_seed(C)
+    Ns, M, H = 500, 300, 9
+    s_pts = torch.rand(Ns, 3, generator=g) * 4
+    q_pts = s_pts[:M].clone()
+    feats = torch.randn(Ns, C, generator=g)
+    idx = torch.randint(0, Ns + 1, (M, H), generator=g).int()        # Ns = shadow
+    idx[::7] = Ns                                                    # rows with no neighbour at all
+    kp = base_kernel_points() * 1.5
+    pos = F.row_positive(feats.cuda())
+    A, nn = F.kpconv_aggregate(feats.cuda(), pos, q_pts.cuda(), s_pts.cuda(), idx.cuda(), kp, 1.2)
+    A = A.cpu().view(M, 15, C)
+    assert float(A[::7].abs().max()) == 0.0 and float(nn.cpu()[::7].min()) == 1.0 == float(nn.cpu()[::7].max())
+    # reference: dense formula
+    sp = torch.cat([s_pts, torch.full((1, 3), 1e6)])
+    sf = torch.cat([feats, torch.zeros(1, C)])
+    nb = sp[idx.long()] - q_pts[:, None, :]
+    d = (nb[:, :, None, :] - torch.from_numpy(kp).float()[None, None]).norm(dim=3)      # [M,H,15]
+    w = torch.clamp(1 - d / 1.2, min=0).transpose(1, 2)                                   # [M,15,H]
+    want = w @ sf[idx.long()]
+    assert (A - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+    A1, _ = F.kpconv_aggregate(feats.cuda(), pos, q_pts.cuda(), s_pts.cuda(), idx[:, :1].contiguous().cuda(), kp, 1.2)
+    want1 = w[:, :, :1] @ sf[idx[:, :1].long()]
+    assert (A1.cpu().view(M, 15, C) - want1).abs().max().item() < 1e-4 * max(1.0, want1.abs().max().item())
