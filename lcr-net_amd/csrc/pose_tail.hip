@@ -289,13 +289,84 @@ __device__ __forceinline__ void sk_col(const float* __restrict__ s, int M1, int 
 // (a) whole problem in one workgroup, matrix AND dual vectors resident in LDS (patch level: 129 x 129 floats = 66.5 KB; from L2
 //     every one of the 200 passes would be a chain of dependent ~1 us loads).  Four threads share a row (column): each takes
 //     every 4th element, partials are folded with two quad shuffles.
-__device__ __forceinline__ float quad_max(float x) {
-  x = fmaxf(x, __shfl_xor(x, 1));
-  return fmaxf(x, __shfl_xor(x, 2));
+__device__ __forceinline__ float quad_max(float x) {      // quad permutes on the DPP path (no LDS crossbar round trip)
+  x = fmaxf(x, dpp0<DPP_QUAD_1032>(x));
+  return fmaxf(x, dpp0<DPP_QUAD_2301>(x));
 }
 __device__ __forceinline__ float quad_sum(float x) {
-  x += __shfl_xor(x, 1);
-  return x + __shfl_xor(x, 2);
+  x += dpp0<DPP_QUAD_1032>(x);
+  return x + dpp0<DPP_QUAD_2301>(x);
+}
+
+// (a') patch level, register resident: for matrices up to 132 x 132 (the 129 x 129 patch problems) every thread keeps its 33
+//      row entries AND its 33 column entries in registers for all iterations — four threads per row / column, element e of part p
+//      is column (row) 4e + p — so a half-iteration is 33 independent exponentials per thread plus two quad folds; LDS only
+//      carries the dual vectors.  The LDS-matrix version spent ~7 us per half-iteration re-reading the matrix twice.
+constexpr int SKR_E = 33;                 // entries per thread
+constexpr int SKR_LINES = 4 * SKR_E;      // 132 rows / columns at most
+constexpr int SKR_T = 576;                // 9 wavefronts >= 4 * 132 threads
+
+__global__ __launch_bounds__(SKR_T) void k_log_sinkhorn_reg(float* __restrict__ S, const uint8_t* __restrict__ row_mask,
+                                                            const uint8_t* __restrict__ col_mask, int M, int N, int iters, float inf_val) {
+  __shared__ float u[SKR_LINES + 4], v[SKR_LINES + 4], log_mu[SKR_LINES + 4], log_nu[SKR_LINES + 4];
+  __shared__ float s_norm;
+  const int64_t b = blockIdx.x;
+  const int M1 = M + 1, N1 = N + 1;
+  float* sg = S + b * M1 * N1;
+  const int part = threadIdx.x & 3, line = threadIdx.x >> 2;
+  const bool row_live = line < M1, col_live = line < N1;
+  float R[SKR_E], Cc[SKR_E];
+#pragma unroll
+  for (int e = 0; e < SKR_E; ++e) {
+    const int j = 4 * e + part;
+    R[e] = (row_live && j < N1) ? sg[line * N1 + j] : -INFINITY;
+    Cc[e] = (col_live && j < M1) ? sg[j * N1 + line] : -INFINITY;
+  }
+  sk_setup(row_mask, col_mask, b, M, N, inf_val, u, v, log_mu, log_nu, &s_norm);
+  for (int it = 0; it < iters; ++it) {
+    {
+      float x[SKR_E], mx = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < SKR_E; ++e) {
+        const int j = 4 * e + part;
+        x[e] = R[e] + (j < N1 ? v[j] : 0.f);
+        mx = fmaxf(mx, x[e]);
+      }
+      mx = quad_max(mx);
+      const float m0 = row_live ? mx : 0.f;
+      float sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < SKR_E; ++e) sum += fast_exp(x[e] - m0);
+      sum = quad_sum(sum);
+      if (row_live && part == 0) u[line] = log_mu[line] - (mx + fast_log(sum));
+    }
+    __syncthreads();
+    {
+      float x[SKR_E], mx = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < SKR_E; ++e) {
+        const int i = 4 * e + part;
+        x[e] = Cc[e] + (i < M1 ? u[i] : 0.f);
+        mx = fmaxf(mx, x[e]);
+      }
+      mx = quad_max(mx);
+      const float m0 = col_live ? mx : 0.f;
+      float sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < SKR_E; ++e) sum += fast_exp(x[e] - m0);
+      sum = quad_sum(sum);
+      if (col_live && part == 0) v[line] = log_nu[line] - (mx + fast_log(sum));
+    }
+    __syncthreads();
+  }
+  if (row_live) {
+    const float ui = u[line], nrm = s_norm;
+#pragma unroll
+    for (int e = 0; e < SKR_E; ++e) {
+      const int j = 4 * e + part;
+      if (j < N1) sg[line * N1 + j] = R[e] + ui + v[j] - nrm;
+    }
+  }
 }
 
 __global__ __launch_bounds__(SK_T) void k_log_sinkhorn_lds(float* __restrict__ S, const uint8_t* __restrict__ row_mask,
@@ -818,7 +889,9 @@ extern "C" int lcr_log_sinkhorn(float* S, const uint8_t* row_mask, const uint8_t
                                 float* uv_ws, void* stream) {
   if (!S || !row_mask || !col_mask || !uv_ws || B < 1 || M < 1 || N < 1 || iters < 0) return LCR_EARG;
   const size_t mat_bytes = sizeof(float) * (static_cast<size_t>(M + 1) * (N + 1) + 2 * (M + N + 2));   // matrix + u, v, log_mu, log_nu
-  if (mat_bytes <= 150 * 1024) {
+  if (M + 1 <= SKR_LINES && N + 1 <= SKR_LINES) {
+    hipLaunchKernelGGL(k_log_sinkhorn_reg, dim3(static_cast<int>(B)), dim3(SKR_T), 0, ST(stream), S, row_mask, col_mask, M, N, iters, inf_val);
+  } else if (mat_bytes <= 150 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {   // > 64 KB of dynamic LDS needs an explicit opt-in
       hipFuncSetAttribute(reinterpret_cast<const void*>(&k_log_sinkhorn_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
