@@ -144,8 +144,12 @@ __device__ __forceinline__ int seg_of_row(const int64_t* __restrict__ seg_len, i
   return s;
 }
 
-template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC>
-__global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+// SHORT = the light form for K <= 128 (the unary Linears of the big stages): such a problem is all prologue — load, one to four
+// K-steps, epilogue — so what hides the load latency is the number of workgroups a CU holds, not prefetch depth: one LDS
+// buffer (17 KB), one register stage, shallow fragment prefetch, and a register budget that lets 6-8 workgroups share a CU
+// instead of 4.
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SHORT = false>
+__global__ __launch_bounds__(GM_T, SHORT ? 6 : 2) void k_gemm_f32(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                                        int64_t M, int N, int K, GemmEpilogue ep, GemmBatch batch) {
   static_assert(WM * WN == 4 && BM == 32 * WM, "one 32-row MFMA tile per wavefront along M");
   constexpr int k_begin = 0;
@@ -166,8 +170,9 @@ __global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ 
   constexpr int LDA = TA ? BM + 4 : BM + 1;
   constexpr int LDB = TB ? BN + 1 : BN + 4;
   constexpr int NT = BN / (32 * WN);
-  __shared__ __attribute__((aligned(16))) float As[2][GM_BK * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[2][GM_BK * LDB];
+  constexpr int NBUF = SHORT ? 1 : 2;
+  __shared__ __attribute__((aligned(16))) float As[NBUF][GM_BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[NBUF][GM_BK * LDB];
 
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
   const int wm = w / WN, wn = w % WN;
@@ -183,10 +188,10 @@ __global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ 
 
   // two register stages: the tile for K-step t+2 is requested while step t computes and step t+1 already sits in registers,
   // so a global load has two full MFMA phases (~2 x 1024 cycles) to land before it is needed for the LDS store
-  LoaderT<BM, LDA, VEC> la_t[2];
-  LoaderN<BM, LDA, VEC> la_n[2];
-  LoaderT<BN, LDB, VEC> lb_t[2];
-  LoaderN<BN, LDB, VEC> lb_n[2];
+  LoaderT<BM, LDA, VEC> la_t[NBUF];
+  LoaderN<BM, LDA, VEC> la_n[NBUF];
+  LoaderT<BN, LDB, VEC> lb_t[NBUF];
+  LoaderN<BN, LDB, VEC> lb_n[NBUF];
 
   auto gload = [&](int k0, int r) {
     if (TA) la_n[r].load(A, M, K, m0, k0);
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ 
   // out of K, so their addresses fall back to column 0 — cache hits, never stored).  The epilogue's per-column bias and the
   // GroupNorm segment of this row block (a chain of dependent scalar loads) are fetched here too, under the same latency.
   gload(k_begin, 0);
-  gload(k_begin + GM_BK, 1);
+  if (!SHORT) gload(k_begin + GM_BK, NBUF - 1);
   const bool want_stats = ep.stats != nullptr;
   float bias_v[NT];
 #pragma unroll
@@ -241,6 +246,37 @@ __global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ 
   __syncthreads();
   const int a_off = (lane >> 5) * LDA + wm * 32 + (lane & 31);
   const int b_off = (lane >> 5) * LDB + wn * (32 * NT) + (lane & 31);
+  if constexpr (SHORT) {
+    constexpr int KKS = GM_BK / 2, PFS = 4;
+    for (int t = 0; t < nk; ++t) {
+      if (t > 0) {
+        gload(k_begin + t * GM_BK, 0);
+        __syncthreads();                                        // every wavefront has read step t-1's fragments
+        sstore(0, 0);
+        __syncthreads();
+      }
+      const float* as = As[0] + a_off;
+      const float* bs = Bs[0] + b_off;
+      float af[PFS], bf[PFS][NT];
+#pragma unroll
+      for (int d = 0; d < PFS; ++d) {
+        af[d] = as[d * 2 * LDA];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[d][j] = bs[d * 2 * LDB + j * 32];
+      }
+#pragma unroll
+      for (int kk = 0; kk < KKS; ++kk) {
+        const int sl = kk % PFS;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[sl], bf[sl][j], acc[j], 0, 0, 0);
+        if (kk + PFS < KKS) {
+          af[sl] = as[(kk + PFS) * 2 * LDA];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) bf[sl][j] = bs[(kk + PFS) * 2 * LDB + j * 32];
+        }
+      }
+    }
+  } else {
   // One K-step: compute LDS buffer BUF while (a) the tile for step t+2 is requested into register set BUF and (b) the tile
   // for step t+1 (register set 1-BUF) is written to LDS buffer 1-BUF — its ds_writes are issued BETWEEN the MFMAs, and the
   // MFMA operand fragments are read PF K-pairs ahead: LDS latency (~100+ cycles) exceeds one 64-cycle MFMA, so a one-deep
@@ -302,6 +338,8 @@ __global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ 
     step(std::integral_constant<int, 0>{}, std::false_type{}, t);
     if (t + 1 >= nk) break;
     step(std::integral_constant<int, 1>{}, std::false_type{}, t + 1);
+  }
+
   }
 
   if (NACC == 2) {
@@ -426,7 +464,7 @@ __global__ __launch_bounds__(GM_T, 2) void k_gemm_f32(const float* __restrict__ 
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool VEC>
+template <int BM, int BN, int WM, int WN, bool VEC, bool SHORT = false>
 static int launch_gemm(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB, const GemmEpilogue& ep,
                        hipStream_t st, const GemmBatch* batch = nullptr) {
   static const GemmBatch no_batch = {};
@@ -434,10 +472,10 @@ static int launch_gemm(const float* A, const float* B, float* C, int64_t M, int 
   const int mt8 = (div_up(M, BM) + 7) / 8 * 8;
   dim3 grid(mt8 * div_up(N, BN), 1, bt.count ? bt.count : 1);     // see the XCD-aware tile order in the kernel
   dim3 block(GM_T);
-  if (!transA && !transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, false, false, VEC>), grid, block, 0, st, A, B, C, M, N, K, ep, bt);
-  else if (!transA && transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, false, true, VEC>), grid, block, 0, st, A, B, C, M, N, K, ep, bt);
-  else if (transA && !transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, true, false, VEC>), grid, block, 0, st, A, B, C, M, N, K, ep, bt);
-  else hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, true, true, VEC>), grid, block, 0, st, A, B, C, M, N, K, ep, bt);
+  if (!transA && !transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, false, false, VEC, SHORT>), grid, block, 0, st, A, B, C, M, N, K, ep, bt);
+  else if (!transA && transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, false, true, VEC, SHORT>), grid, block, 0, st, A, B, C, M, N, K, ep, bt);
+  else if (transA && !transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, true, false, VEC, SHORT>), grid, block, 0, st, A, B, C, M, N, K, ep, bt);
+  else hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, true, true, VEC, SHORT>), grid, block, 0, st, A, B, C, M, N, K, ep, bt);
   return check_launch("lcr_gemm_f32");
 }
 
@@ -496,6 +534,12 @@ static int gemm_impl(const float* A, const float* B, float* C, int64_t M, int N,
   // N >= 64 (enough workgroups for two per CU matters more than per-tile reuse at these M); N = 32 wants the 128-row tile;
   // only large, deep problems (>= 512 tiles of 128x128 and K >= 512) pay for the big tile.
   const int64_t b128 = (M + 127) / 128, nb128 = (N + 127) / 128;
+  static const bool no_short = getenv("LCR_GEMM_NO_SHORT") != nullptr;   // A/B switch while the light form is being evaluated
+  static const int short_k = getenv("LCR_GEMM_SHORT_K") ? atoi(getenv("LCR_GEMM_SHORT_K")) : 256;
+  if (!no_short && K <= short_k && !transA) {
+    if (N <= 32) return launch_gemm<128, 32, 4, 1, true, true>(A, B, C, M, N, K, transA, transB, ep, st);
+    return launch_gemm<64, 64, 2, 2, true, true>(A, B, C, M, N, K, transA, transB, ep, st);
+  }
   if (N <= 32) return launch_gemm<128, 32, 4, 1, true>(A, B, C, M, N, K, transA, transB, ep, st);
   if (K >= 512 && b128 * nb128 >= 512) return launch_gemm<128, 128, 4, 1, true>(A, B, C, M, N, K, transA, transB, ep, st);
   return launch_gemm<64, 64, 2, 2, true>(A, B, C, M, N, K, transA, transB, ep, st);
