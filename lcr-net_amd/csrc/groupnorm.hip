@@ -41,7 +41,9 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, G
                                                   float eps, float slope, int act, uint8_t* __restrict__ pos) {
   // Every workgroup owns a CONTIGUOUS range of rows, so it touches one segment (two or three at scan boundaries) and only
   // folds the statistics replicas of those: (mean, rstd) per (segment, group) of the range, finalised in fp64 once per block.
-  __shared__ float2 s_x[GN_TABLE], s_r[GN_TABLE];
+  extern __shared__ __attribute__((aligned(16))) float2 s_tab[];   // [2][S * groups]: sized by the launch, 4 KB for 8 scans
+  float2* s_x = s_tab;
+  float2* s_r = s_tab + S * groups;
   __shared__ int64_t s_start[GN_MAX_SEG + 1];       // first row of every segment (prefix of seg_len)
   const int gs = C / groups;
   const int c4n = C >> 2;                           // float4 pieces per row
@@ -237,11 +239,12 @@ extern "C" int lcr_groupnorm_apply(const float* x, const double* stats, const fl
   }
   // contiguous row ranges per workgroup, >= 2048 float4 pieces each (the per-block statistics fold is amortised over them)
   const int nblk = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((N * c4n + 2047) / 2048, 256 * 8)));
+  const size_t tab_bytes = sizeof(float2) * 2 * static_cast<size_t>(S) * groups;
   if (pos)
-    hipLaunchKernelGGL((k_gn_apply<true>), dim3(nblk), dim3(256), 0, static_cast<hipStream_t>(stream), x, gx, res, gr, y, N, C, groups, seg_len,
+    hipLaunchKernelGGL((k_gn_apply<true>), dim3(nblk), dim3(256), tab_bytes, static_cast<hipStream_t>(stream), x, gx, res, gr, y, N, C, groups, seg_len,
                        S, eps, slope, act, pos);
   else
-    hipLaunchKernelGGL((k_gn_apply<false>), dim3(nblk), dim3(256), 0, static_cast<hipStream_t>(stream), x, gx, res, gr, y, N, C, groups, seg_len,
+    hipLaunchKernelGGL((k_gn_apply<false>), dim3(nblk), dim3(256), tab_bytes, static_cast<hipStream_t>(stream), x, gx, res, gr, y, N, C, groups, seg_len,
                        S, eps, slope, act, pos);
   return check_launch("lcr_groupnorm_apply");
 }
