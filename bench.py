@@ -32,7 +32,7 @@ FP32_PEAK_TFLOPS = 157.3           # dense fp32 MFMA/vector peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-upsampling", action="store_true", help="skip the 3 decoder-only upsampling searches")
@@ -154,6 +154,7 @@ def main():
         dt = float(t.item())
 
     iso = None
+    summ = timer.summary() if rank == 0 else None     # read the timed region's log before anything else is logged
     if rank == 0:
         # the same GEMM launches once more with nothing else on the GPU (one stream, outside the timed region): in the timed
         # region three streams share the CUs, so a launch's event-to-event duration includes time it spent waiting for them
@@ -174,7 +175,6 @@ def main():
         # Dominant by time = lcr::k_gemm_f32 (all tile variants; ~30 % of the step, profiles/): compute-bound on the fp32
         # matrix cores, so "achieved" = algorithmic flops (2*M*N*K per launch) / launch time vs the 157.3 TFLOP/s
         # dense fp32 MFMA peak.  HBM traffic per launch comes from the committed rocprofv3 PMC passes (profiles/*pmc*.json).
-        summ = timer.summary()
         gem, agg = summ["gemm"], summ["kpconv_aggregate"]
         t_gemm, t_agg = sum(t for t, _ in gem), sum(t for t, _ in agg)
         flops = sum(2.0 * m[0] * m[1] * m[2] for _, m in gem)

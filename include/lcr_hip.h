@@ -33,6 +33,12 @@ extern "C" {
 #define LCR_GN_REPLICAS 8  /* copies of every GroupNorm statistics table (see lcr_gemm_f32) */   /* sum(lengths) exceeds the capacity passed by the host */
 
 const char* lcr_last_error(void);
+/* Opt-in launch timing for measurement harnesses (bench.py's roofline leg): while enabled, lcr_gemm_f32 (kind 0, meta = M,N,K)
+ * and lcr_kpconv_aggregate (kind 1, meta = M,Ns,H,C,index bytes) bracket their launch with HIP events on the launch stream —
+ * also when they are called from lcr_encoder_forward.  lcr_ktimer_enable(1) clears the log; lcr_ktimer_read synchronises on
+ * the logged events and returns the number of records of `kind`. */
+void lcr_ktimer_enable(int on);
+int lcr_ktimer_read(int kind, int max_records, double* seconds, int64_t* meta);
 int lcr_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -155,6 +161,42 @@ int lcr_groupnorm_stats(const float* x, int64_t N, int C, int groups, const int6
 int lcr_groupnorm_apply(const float* x, const double* stats, const float* gamma, const float* beta, const float* res,
                         const double* res_stats, const float* res_gamma, const float* res_beta, float* y, int64_t N, int C,
                         int groups, const int64_t* seg_len, int S, float eps, float slope, int act, uint8_t* pos, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a-6  the whole KPEncoder.forward (experiments/lcrnet/backbone4.py:60-89: encoder1_1 ... encoder4_3) as ONE native call: the
+ *      host-side sequencer over the building blocks above (same launches, arguments and order as the module tree of
+ *      modules/kpconv/modules.py:104-225, so the outputs are bit-identical to calling the blocks one by one).
+ * Weights are device pointers into the model's own parameter tensors (nothing is copied or repacked); kernel points are HOST
+ * float[15*3] arrays.  A NULL `w` in a unary block means nn.Identity (modules.py:171,176).
+ *   points[4] f32[n_i,3]; neighbors[4] i32[n_i, limits[i]]; subsampling[3] i32[n_{i+1}, limits[i]]; order[4] i32[n_i] or NULL;
+ *   seg_len[4] i64[S] GroupNorm segments per stage (device); n_host[4], limits[4] on the host; feats0 f32[n_0] (C_in = 1);
+ *   out_feats[4]: f32[n_0,2d], [n_1,4d], [n_2,8d], [n_3,16d] (d = init_dim) — the four stage outputs (feats_list).
+ * ------------------------------------------------------------------------------------------------ */
+#define LCR_ENC_BLOCKS 10
+typedef struct LcrUnaryW {
+  const float *w, *b;          /* nn.Linear weight [cout,cin], bias [cout] */
+  const float *gn_w, *gn_b;    /* GroupNorm affine [cout] */
+} LcrUnaryW;
+typedef struct LcrBlockW {     /* ResidualBlock (modules.py:148-225) */
+  int   cin, cout, strided;
+  float sigma;
+  const float* kernel_points_host;
+  const float *kp_w, *kp_b;    /* KPConv weights [15, cout/4, cout/4], bias [cout/4] */
+  const float *normconv_w, *normconv_b;
+  LcrUnaryW unary1, unary2, shortcut;
+} LcrBlockW;
+typedef struct LcrEncoderW {
+  int   groups, c1_cout;
+  float c1_sigma;
+  const float* c1_kernel_points_host;
+  const float *c1_w, *c1_b;    /* encoder1_1 KPConv [15,1,c1_cout], bias */
+  const float *c1_gn_w, *c1_gn_b;
+  LcrBlockW blocks[LCR_ENC_BLOCKS];   /* encoder1_2, 2_1, 2_2, 2_3, 3_1, 3_2, 3_3, 4_1, 4_2, 4_3 */
+} LcrEncoderW;
+int lcr_encoder_ws_bytes(const LcrEncoderW* W, const int64_t* n_host, int S, size_t* bytes);
+int lcr_encoder_forward(const LcrEncoderW* W, const float* feats0, const float* const* points, const int32_t* const* neighbors,
+                        const int32_t* const* subsampling, const int32_t* const* order, const int64_t* const* seg_len, int S,
+                        const int64_t* n_host, const int* limits, float* const* out_feats, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a-7  global descriptor head: F.normalize -> NetVLADLoupe2 -> GatingContext -> F.normalize

@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#ifdef __cplusplus
+#include <mutex>
+#endif
 
 #include "../../include/lcr_hip.h"
 
@@ -186,6 +189,26 @@ __device__ __forceinline__ T wave_sum(T v) {
   return v;
 }
 #endif  // __HIPCC__
+
+// FIFO gate for the native drivers' launch sequences.  Two host threads that issue launches back to back contend for the
+// runtime's (unfair) locks: the encoder driver's 135-launch burst starved the pre-processing chain — a latency-bound sequence
+// of dependent launches — and the streams ended up running one after the other.  Each driver passes the gate once per
+// operation: a ticket lock, so the threads strictly alternate while both want to launch and neither waits when alone.
+struct LaunchTurn {
+  LaunchTurn();
+  ~LaunchTurn();
+};
+
+// ---- opt-in launch timing (bench.py's roofline leg) ------------------------------------------------
+// While enabled (lcr_ktimer_enable), instrumented entry points bracket their launch with HIP events on the launch stream and
+// log (kind, 5 integers of shape metadata); lcr_ktimer_read turns the log into durations.  Off by default: one relaxed load.
+constexpr int KT_GEMM = 0, KT_AGGREGATE = 1;
+struct KernelTimerScope {
+  int slot;
+  hipStream_t st;
+  KernelTimerScope(int kind, hipStream_t stream, int64_t m0, int64_t m1, int64_t m2, int64_t m3 = 0, int64_t m4 = 0);
+  ~KernelTimerScope();
+};
 
 // ---- device-wide exclusive scan of int32 (n known on the host as a capacity) ---------------------
 // out[i] = sum(in[0..i-1]); out may alias in; total (i64) written to *total if non-null.

@@ -1,5 +1,9 @@
 // common.hip — error plumbing + device-wide scan used by the grid/sort stages.
+#include <atomic>
 #include <cstdarg>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include <cstdio>
 #include <cstdlib>
 
@@ -14,6 +18,56 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+static std::atomic<unsigned> g_turn_next{0}, g_turn_serving{0};
+static const bool g_turns_on = getenv("LCR_NO_LAUNCH_TURNS") == nullptr;
+LaunchTurn::LaunchTurn() {
+  if (!g_turns_on) return;
+  const unsigned my = g_turn_next.fetch_add(1, std::memory_order_relaxed);
+  while (g_turn_serving.load(std::memory_order_acquire) != my) {
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+}
+LaunchTurn::~LaunchTurn() {
+  if (g_turns_on) g_turn_serving.fetch_add(1, std::memory_order_release);
+}
+
+// ---- opt-in launch timing ---------------------------------------------------------------------------------------------
+struct KtRec {
+  hipEvent_t a, b;
+  int        kind;
+  int64_t    meta[5];
+};
+static std::mutex g_kt_mu;
+static std::vector<KtRec> g_kt_log;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_kt_pool;
+static std::atomic<int> g_kt_on{0};
+
+KernelTimerScope::KernelTimerScope(int kind, hipStream_t stream, int64_t m0, int64_t m1, int64_t m2, int64_t m3, int64_t m4) : slot(-1), st(stream) {
+  if (!g_kt_on.load(std::memory_order_relaxed)) return;
+  std::lock_guard<std::mutex> lk(g_kt_mu);
+  KtRec r;
+  if (!g_kt_pool.empty()) {
+    r.a = g_kt_pool.back().first;
+    r.b = g_kt_pool.back().second;
+    g_kt_pool.pop_back();
+  } else {
+    hipEventCreate(&r.a);
+    hipEventCreate(&r.b);
+  }
+  r.kind = kind;
+  r.meta[0] = m0, r.meta[1] = m1, r.meta[2] = m2, r.meta[3] = m3, r.meta[4] = m4;
+  hipEventRecord(r.a, st);
+  slot = static_cast<int>(g_kt_log.size());
+  g_kt_log.push_back(r);
+}
+KernelTimerScope::~KernelTimerScope() {
+  if (slot < 0) return;
+  std::lock_guard<std::mutex> lk(g_kt_mu);
+  if (slot < static_cast<int>(g_kt_log.size())) hipEventRecord(g_kt_log[slot].b, st);
 }
 
 // ---- scan: tile = 256 threads x 16 items ----------------------------------------------------------
@@ -194,4 +248,33 @@ int exclusive_scan_i32_dev(const int32_t* in, int32_t* out, int64_t n, const int
 }  // namespace lcr
 
 extern "C" const char* lcr_last_error(void) { return lcr::g_err; }
+
+extern "C" void lcr_ktimer_enable(int on) {
+  std::lock_guard<std::mutex> lk(lcr::g_kt_mu);
+  if (on) {
+    for (auto& r : lcr::g_kt_log) lcr::g_kt_pool.push_back({r.a, r.b});
+    lcr::g_kt_log.clear();
+  }
+  lcr::g_kt_on.store(on ? 1 : 0);
+}
+
+// Durations (seconds) and metadata of the logged launches of one kind; synchronises on every logged stop event.  Returns the
+// number of records of that kind (which may exceed max_records: only the first max_records are written).
+extern "C" int lcr_ktimer_read(int kind, int max_records, double* seconds, int64_t* meta /* [max_records,5] */) {
+  std::lock_guard<std::mutex> lk(lcr::g_kt_mu);
+  int n = 0;
+  for (auto& r : lcr::g_kt_log) {
+    if (r.kind != kind) continue;
+    if (n < max_records) {
+      hipEventSynchronize(r.b);
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, r.a, r.b);
+      if (seconds) seconds[n] = static_cast<double>(ms) * 1e-3;
+      if (meta)
+        for (int k = 0; k < 5; ++k) meta[static_cast<size_t>(n) * 5 + k] = r.meta[k];
+    }
+    ++n;
+  }
+  return n;
+}
 extern "C" int lcr_version(void) { return 1; }

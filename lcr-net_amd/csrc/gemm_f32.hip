@@ -513,6 +513,7 @@ static int gemm_impl(const float* A, const float* B, float* C, int64_t M, int N,
     }
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
+  KernelTimerScope timed(KT_GEMM, st, M, N, K);
   // `stats` ACCUMULATES: the caller passes a zeroed table (one fill per forward pass for all layers, instead of a fill
   // launch in front of every GEMM)
   if (M == 0) return LCR_OK;

@@ -356,6 +356,7 @@ extern "C" int lcr_kpconv_aggregate(const float* s_feats, const uint8_t* s_pos, 
   if (M == 0) return LCR_OK;
   const KPoints kp = load_kp(kernel_points_host);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  KernelTimerScope timed(KT_AGGREGATE, st, M, Ns, H, C, idx_is_64 ? 8 : 4);
   return idx_is_64 ? launch_aggregate(s_feats, s_pos, q_pts, s_pts, static_cast<const int64_t*>(idx), M, Ns, H, C, kp, sigma, A, nn, order, st)
                    : launch_aggregate(s_feats, s_pos, q_pts, s_pts, static_cast<const int32_t*>(idx), M, Ns, H, C, kp, sigma, A, nn, order, st);
 }

@@ -10,11 +10,14 @@
 //
 // so a stage's grid build and searches overlap the next stage's subsampling.  Results land in one caller-provided arena whose
 // layout lcr_precompute_layout reports; capacities are bounded by the stage-0 point count (every stage is a subset sample).
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
 
 #include "common.h"
+
+#define TURN(call) ([&]() { LaunchTurn turn_; return (call); }())
 
 namespace lcr {
 
@@ -46,6 +49,7 @@ static PreCtx* acquire_ctx() {
   }
   PreCtx* c = new PreCtx();
   for (int i = 0; i < LCR_MAX_STAGES; ++i) {
+    // default priority on purpose: high-priority side streams made the whole pipeline 15-20 % slower (queue preemption)
     hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking);
     hipEventCreateWithFlags(&c->ready[i], hipEventDisableTiming);
     hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming);
@@ -177,31 +181,31 @@ extern "C" int lcr_precompute_batch(const float* points0, const int64_t* lengths
   for (int i = 0; i < S; ++i) {
     if (i > 0) {
       v *= 2.f;
-      rc = lcr_grid_subsample_ex(pts[i - 1], lens[i - 1], B, L->cap[i - 1], v, key_bits_hint, const_cast<float*>(pts[i]),
-                                 const_cast<int64_t*>(lens[i]), W.status, W.sub_ws[i], W.sub_bytes[i], main);
+      rc = TURN(lcr_grid_subsample_ex(pts[i - 1], lens[i - 1], B, L->cap[i - 1], v, key_bits_hint, const_cast<float*>(pts[i]),
+                                 const_cast<int64_t*>(lens[i]), W.status, W.sub_ws[i], W.sub_bytes[i], main));
       if (rc) return rc;
     }
     radii[i] = r;
     hipEventRecord(C.ready[i], main);
     hipStream_t s = C.side[i];
     hipStreamWaitEvent(s, C.ready[i], 0);
-    rc = lcr_support_grid_build(pts[i], lens[i], B, L->cap[i], r, W.status, W.grid_ws[i], W.grid_bytes[i], s);
+    rc = TURN(lcr_support_grid_build(pts[i], lens[i], B, L->cap[i], r, W.status, W.grid_ws[i], W.grid_bytes[i], s));
     if (rc) return rc;
-    rc = lcr_support_grid_order(W.grid_ws[i], L->cap[i], B, i32(L->off_order[i]), s);
+    rc = TURN(lcr_support_grid_order(W.grid_ws[i], L->cap[i], B, i32(L->off_order[i]), s));
     if (rc) return rc;
-    rc = lcr_radius_query(pts[i], lens[i], B, L->cap[i], W.grid_ws[i], L->cap[i], r, L->limits[i], nullptr, i32(L->off_neighbors[i]),
-                          nullptr, s);
+    rc = TURN(lcr_radius_query(pts[i], lens[i], B, L->cap[i], W.grid_ws[i], L->cap[i], r, L->limits[i], nullptr, i32(L->off_neighbors[i]),
+                          nullptr, s));
     if (rc) return rc;
     if (i > 0 && L->upsampling) {
-      rc = lcr_radius_query(pts[i - 1], lens[i - 1], B, L->cap[i - 1], W.grid_ws[i], L->cap[i], r, L->limits[i], nullptr,
-                            i32(L->off_upsampling[i - 1]), nullptr, s);
+      rc = TURN(lcr_radius_query(pts[i - 1], lens[i - 1], B, L->cap[i - 1], W.grid_ws[i], L->cap[i], r, L->limits[i], nullptr,
+                            i32(L->off_upsampling[i - 1]), nullptr, s));
       if (rc) return rc;
     }
     if (i > 0) {
       hipStream_t sp = C.side[i - 1];
       hipStreamWaitEvent(sp, C.ready[i], 0);
-      rc = lcr_radius_query(pts[i], lens[i], B, L->cap[i], W.grid_ws[i - 1], L->cap[i - 1], radii[i - 1], L->limits[i - 1], nullptr,
-                            i32(L->off_subsampling[i - 1]), nullptr, sp);
+      rc = TURN(lcr_radius_query(pts[i], lens[i], B, L->cap[i], W.grid_ws[i - 1], L->cap[i - 1], radii[i - 1], L->limits[i - 1], nullptr,
+                            i32(L->off_subsampling[i - 1]), nullptr, sp));
       if (rc) return rc;
     }
     r *= 2.f;

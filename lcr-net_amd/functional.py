@@ -13,40 +13,37 @@ GN_REPLICAS = 8   # must match csrc/common.h: statistics tables are [GN_REPLICAS
 
 
 class KernelTimer:
-    """Opt-in per-op timing with HIP events on the launch stream (bench.py's roofline leg).  `names`: ops to time, e.g.
-    {"kpconv_aggregate"}; each timed call records (start, stop) events around its launches; `.summary()` synchronises."""
+    """Opt-in per-launch timing of lcr_gemm_f32 ("gemm", meta (M,N,K)) and lcr_kpconv_aggregate ("kpconv_aggregate", meta
+    (M,Ns,H,C,index bytes)) with HIP events on the launch stream, recorded inside the library (so launches issued by the native
+    encoder driver are seen too).  set_timer(t) starts a fresh log, set_timer(None) stops logging, t.summary() synchronises."""
+    KINDS = {"gemm": 0, "kpconv_aggregate": 1}
 
     def __init__(self, names):
         self.names = set(names)
-        self.events = {n: [] for n in self.names}
-        self.meta = {n: [] for n in self.names}
-
-    def wrap(self, name, fn, meta=None):
-        if name not in self.names:
-            return fn()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        out = fn()
-        b.record()
-        self.events[name].append((a, b))
-        self.meta[name].append(meta)
-        return out
+        self._cache = None
 
     def summary(self):
-        torch.cuda.synchronize()
-        return {n: [(a.elapsed_time(b) * 1e-3, m) for (a, b), m in zip(ev, self.meta[n])] for n, ev in self.events.items()}
-
-
-_TIMER = None
+        if self._cache is None:
+            out = {}
+            L = _lib.lib()
+            for name in self.names:
+                kind = self.KINDS[name]
+                n = L.lcr_ktimer_read(kind, 0, None, None)
+                sec = (ctypes.c_double * max(n, 1))()
+                meta = (ctypes.c_int64 * (5 * max(n, 1)))()
+                L.lcr_ktimer_read(kind, n, ctypes.cast(sec, ctypes.c_void_p), ctypes.cast(meta, ctypes.c_void_p))
+                width = 3 if name == "gemm" else 5
+                out[name] = [(sec[i], tuple(int(meta[5 * i + k]) for k in range(width))) for i in range(n)]
+            self._cache = out
+        return self._cache
 
 
 def set_timer(timer):
-    global _TIMER
-    _TIMER = timer
+    _lib.lib().lcr_ktimer_enable(1 if timer is not None else 0)
 
 
 def _timed(name, fn, meta=None):
-    return fn() if _TIMER is None else _TIMER.wrap(name, fn, meta)
+    return fn()
 
 
 def _seg(seg_len, n, device):

@@ -1,0 +1,127 @@
+"""ctypes side of lcr_encoder_forward (csrc/encoder.hip): the weight table of a KPEncoder and the one-call forward.
+
+The table holds raw device pointers into the module's own parameters (nothing is copied), so it is rebuilt whenever a parameter
+tensor is replaced or modified in place (load_state_dict, .to(device)): the cache key is (data_ptr, _version) of every tensor.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ENC_BLOCKS = 10
+_BLOCK_NAMES = ["encoder1_2", "encoder2_1", "encoder2_2", "encoder2_3", "encoder3_1", "encoder3_2", "encoder3_3", "encoder4_1", "encoder4_2",
+                "encoder4_3"]
+_fp = ctypes.c_void_p
+
+
+class UnaryW(ctypes.Structure):
+    _fields_ = [("w", _fp), ("b", _fp), ("gn_w", _fp), ("gn_b", _fp)]
+
+
+class BlockW(ctypes.Structure):
+    _fields_ = [("cin", ctypes.c_int), ("cout", ctypes.c_int), ("strided", ctypes.c_int), ("sigma", ctypes.c_float),
+                ("kernel_points_host", _fp), ("kp_w", _fp), ("kp_b", _fp), ("normconv_w", _fp), ("normconv_b", _fp),
+                ("unary1", UnaryW), ("unary2", UnaryW), ("shortcut", UnaryW)]
+
+
+class EncoderW(ctypes.Structure):
+    _fields_ = [("groups", ctypes.c_int), ("c1_cout", ctypes.c_int), ("c1_sigma", ctypes.c_float), ("c1_kernel_points_host", _fp),
+                ("c1_w", _fp), ("c1_b", _fp), ("c1_gn_w", _fp), ("c1_gn_b", _fp), ("blocks", BlockW * ENC_BLOCKS)]
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _unary(u):
+    import torch.nn as nn
+    if isinstance(u, nn.Identity):
+        return UnaryW(None, None, None, None)
+    return UnaryW(_p(u.mlp.weight), _p(u.mlp.bias), _p(u.norm.norm.weight), _p(u.norm.norm.bias))
+
+
+class EncoderTable:
+    """Weight table + the host arrays it points to (kept alive here)."""
+
+    def __init__(self, enc):
+        self.keep = []
+        w = EncoderW()
+        c1 = enc.encoder1_1
+        w.groups, w.c1_cout, w.c1_sigma = int(c1.group_norm), int(c1.out_channels), float(c1.KPConv.sigma)
+        w.c1_kernel_points_host = self._kp(c1.KPConv)
+        w.c1_w, w.c1_b = _p(c1.KPConv.weights), _p(c1.KPConv.bias)
+        w.c1_gn_w, w.c1_gn_b = _p(c1.norm.norm.weight), _p(c1.norm.norm.bias)
+        for i, name in enumerate(_BLOCK_NAMES):
+            b = getattr(enc, name)
+            assert int(b.group_norm) == w.groups
+            blk = w.blocks[i]
+            blk.cin, blk.cout, blk.strided, blk.sigma = int(b.in_channels), int(b.out_channels), int(bool(b.strided)), float(b.KPConv.sigma)
+            blk.kernel_points_host = self._kp(b.KPConv)
+            blk.kp_w, blk.kp_b = _p(b.KPConv.weights), _p(b.KPConv.bias)
+            blk.normconv_w, blk.normconv_b = _p(b.norm_conv.norm.weight), _p(b.norm_conv.norm.bias)
+            blk.unary1, blk.unary2, blk.shortcut = _unary(b.unary1), _unary(b.unary2), _unary(b.unary_shortcut)
+        self.w = w
+        self.out_channels = [int(getattr(enc, n).out_channels) for n in ("encoder1_2", "encoder2_3", "encoder3_3", "encoder4_3")]
+
+    def _kp(self, kpconv):
+        a = np.ascontiguousarray(kpconv.kernel_points_host(), dtype=np.float32)
+        assert a.shape == (15, 3)
+        self.keep.append(a)
+        return ctypes.c_void_p(a.ctypes.data)
+
+
+def _key(enc):
+    return tuple((t.data_ptr(), t._version) for t in list(enc.parameters()) + list(enc.buffers()))
+
+
+def table_for(enc):
+    key = _key(enc)
+    cached = getattr(enc, "_native_table", None)
+    if cached is None or cached[0] != key:
+        cached = (key, EncoderTable(enc))
+        enc._native_table = cached
+    return cached[1]
+
+
+def eligible(feats, data_dict):
+    P, N, S = data_dict["points"], data_dict["neighbors"], data_dict["subsampling"]
+    return (feats.is_cuda and feats.dtype == torch.float32 and feats.dim() == 2 and feats.shape[1] == 1 and len(P) == 4 and len(N) == 4
+            and len(S) == 3 and all(t.dtype == torch.int32 and t.is_contiguous() for t in list(N) + list(S))
+            and all(t.dtype == torch.float32 and t.is_contiguous() for t in P))
+
+
+def forward(enc, feats, data_dict):
+    """KPEncoder.forward through lcr_encoder_forward: returns [f1, f2, f3, f4] like the module."""
+    tab = table_for(enc)
+    P, N, Sub = data_dict["points"], data_dict["neighbors"], data_dict["subsampling"]
+    dev = feats.device
+    n = [int(p.shape[0]) for p in P]
+    seg = data_dict.get("segment_lengths")
+    if seg is None:
+        seg = [torch.tensor([k], dtype=torch.int64, device=dev) for k in n]
+    seg = [s.contiguous() for s in seg]
+    nseg = int(seg[0].numel())
+    order = data_dict.get("order")
+    limits = [int(N[i].shape[1]) for i in range(4)]
+    for i in range(3):
+        assert int(Sub[i].shape[1]) == limits[i] and int(Sub[i].shape[0]) == n[i + 1]
+    L = _lib.lib()
+    n_host = (ctypes.c_int64 * 4)(*n)
+    lim = (ctypes.c_int * 4)(*limits)
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(L.lcr_encoder_ws_bytes(ctypes.byref(tab.w), n_host, nseg, ctypes.byref(nbytes)), "lcr_encoder_ws_bytes")
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    outs = [torch.empty((n[i], tab.out_channels[i]), dtype=torch.float32, device=dev) for i in range(4)]
+    vp4 = ctypes.c_void_p * 4
+    pts = vp4(*[p.data_ptr() for p in P])
+    nb = vp4(*[t.data_ptr() for t in N])
+    sb = vp4(*([t.data_ptr() for t in Sub] + [None]))
+    od = vp4(*[t.data_ptr() for t in order]) if order is not None else None
+    sg = vp4(*[t.data_ptr() for t in seg])
+    of = vp4(*[t.data_ptr() for t in outs])
+    f0 = feats.contiguous()
+    _lib.check(L.lcr_encoder_forward(ctypes.byref(tab.w), _lib.ptr(f0), pts, nb, sb, od, sg, nseg, n_host, lim, of, _lib.ptr(ws), ws.numel(),
+                                     _lib.stream_ptr(dev)), "lcr_encoder_forward")
+    return outs

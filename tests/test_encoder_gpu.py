@@ -204,3 +204,30 @@ def test_aggregate_rows_without_neighbours_and_single_column(C):
     A1, _ = F.kpconv_aggregate(feats.cuda(), pos, q_pts.cuda(), s_pts.cuda(), idx[:, :1].contiguous().cuda(), kp, 1.2)
     want1 = w[:, :, :1] @ sf[idx[:, :1].long()]
     assert (A1.cpu().view(M, 15, C) - want1).abs().max().item() < 1e-4 * max(1.0, want1.abs().max().item())
+
+
+def test_native_encoder_driver_is_bit_identical_to_the_module_tree(model, monkeypatch):
+    """lcr_encoder_forward issues the same launches in the same order as the Python module tree: identical stage outputs,
+    with and without per-scan GroupNorm segments / processing order."""
+    from lcrnet_amd.data import precompute_batch
+    scans = [load_scan(n) for n in ["003854", "000958", "004481"]]
+    pts = torch.from_numpy(np.concatenate(scans)).cuda()
+    lens = torch.tensor([len(s) for s in scans], dtype=torch.int64, device="cuda")
+    dd = precompute_batch(pts, lens, NUM_STAGES, VOXEL, RADIUS, LIMITS)
+    feats = torch.ones(pts.shape[0], 1, device="cuda")
+    enc = model.encoder
+    for variant in ("segments+order", "whole-stack"):
+        d = dict(dd)
+        if variant == "whole-stack":
+            d.pop("segment_lengths")
+            d.pop("order")
+        monkeypatch.delenv("LCR_NATIVE_ENCODER", raising=False)
+        enc.native = True
+        with torch.no_grad():
+            nat = [t.clone() for t in enc(feats, d)]
+        enc.native = False
+        with torch.no_grad():
+            ref = enc(feats, d)
+        torch.cuda.synchronize()
+        for a, b in zip(nat, ref):
+            assert a.shape == b.shape and torch.equal(a, b), variant
