@@ -104,19 +104,24 @@ int lcr_radius_search(const float* q, const float* s, const int64_t* qlen, const
 #define LCR_MAX_STAGES 8
 typedef struct LcrPrecomputeLayout {
   int     num_stages, B, upsampling;
+  int64_t n_raw;                               /* > 0: the input is a stack of RAW scans, voxelised first (stage 0 lives in `out`) */
   int     limits[LCR_MAX_STAGES];
   int64_t cap[LCR_MAX_STAGES];                 /* row capacity of every stage-i array */
-  size_t  off_points[LCR_MAX_STAGES];          /* f32[cap,3]            (i >= 1) */
-  size_t  off_lengths[LCR_MAX_STAGES];         /* i64[B]                (i >= 1) */
+  size_t  off_points[LCR_MAX_STAGES];          /* f32[cap,3]            (i >= 1; i == 0 too in raw mode: f32[n_raw,3]) */
+  size_t  off_lengths[LCR_MAX_STAGES];         /* i64[B]                (i >= 1; i == 0 too in raw mode) */
   size_t  off_order[LCR_MAX_STAGES];           /* i32[cap]  cell-sorted processing order */
   size_t  off_neighbors[LCR_MAX_STAGES];       /* i32[cap, limits[i]] */
   size_t  off_subsampling[LCR_MAX_STAGES];     /* i32[cap, limits[i]]   rows = stage i+1 points (i < num_stages-1) */
   size_t  off_upsampling[LCR_MAX_STAGES];      /* i32[cap, limits[i+1]] rows = stage i points   (i < num_stages-1, if enabled) */
   size_t  out_bytes, ws_bytes;
 } LcrPrecomputeLayout;
-int lcr_precompute_layout(int64_t n0, int B, int num_stages, const int* limits, int upsampling, LcrPrecomputeLayout* layout);
+/* n_raw > 0: raw-scan mode — the input of lcr_precompute_batch is then f32[n_raw,3] raw points + i64[B] raw lengths, voxelised
+ * with `raw_voxel` (replaces the offline Open3D step) into stage 0 inside the same call; n0 is the CAPACITY
+ * assumed for the voxel count (LCR_STATUS_LEN_MISMATCH in status_host if it was too small: retry with n0 = n_raw). */
+int lcr_precompute_layout(int64_t n0, int B, int num_stages, const int* limits, int upsampling, int64_t n_raw,
+                          LcrPrecomputeLayout* layout);
 int lcr_precompute_batch(const float* points0, const int64_t* lengths0, const LcrPrecomputeLayout* layout, float voxel_size,
-                         float radius, int key_bits_hint, void* out, size_t out_bytes, void* ws, size_t ws_bytes,
+                         float radius, float raw_voxel, int key_bits_hint, void* out, size_t out_bytes, void* ws, size_t ws_bytes,
                          int64_t* lengths_host, uint32_t* status_host, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -116,14 +116,14 @@ __global__ void k_gs_init(GsHeader* h, const int64_t* __restrict__ len, int B, i
   if (threadIdx.x == 0) {
     int64_t o = 0;
     for (int b = 0; b < B; ++b) {
-      h->in_off[b] = o;
-      o += len[b];
+      h->in_off[b] = o < n_cap ? o : n_cap;      // lengths that overrun the capacity are reported and clamped: every per-cloud
+      o += len[b];                               // slice of the work arrays stays inside its allocation
     }
-    h->in_off[B] = o;
     if (o > n_cap) {
       atomicOr(status, LCR_STATUS_LEN_MISMATCH);
       o = n_cap;
     }
+    h->in_off[B] = o;
     h->rx.n = o;
     h->B = B;
     h->n_cap = n_cap;

@@ -10,6 +10,7 @@
 //
 // so a stage's grid build and searches overlap the next stage's subsampling.  Results land in one caller-provided arena whose
 // layout lcr_precompute_layout reports; capacities are bounded by the stage-0 point count (every stage is a subset sample).
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -70,6 +71,8 @@ struct CtxLease {
 };
 
 struct PreWs {
+  void*     raw_ws;                       // workspace of the raw-scan voxelisation (raw mode)
+  size_t    raw_bytes;
   uint32_t* status;                       // [1] shared device status word
   void*     sub_ws[LCR_MAX_STAGES];       // workspace of the subsample that PRODUCES stage i (i >= 1)
   size_t    sub_bytes[LCR_MAX_STAGES];
@@ -81,6 +84,13 @@ struct PreWs {
 static int carve_ws(void* ws, const LcrPrecomputeLayout& L, PreWs* W) {
   Carver c(ws, ~size_t(0));
   W->status = c.take<uint32_t>(64);
+  W->raw_ws = nullptr;
+  W->raw_bytes = 0;
+  if (L.n_raw > 0) {
+    int rc = lcr_grid_subsample_ws_bytes(L.n_raw, L.B, &W->raw_bytes);
+    if (rc) return rc;
+    W->raw_ws = c.take<char>(W->raw_bytes);
+  }
   for (int i = 0; i < L.num_stages; ++i) {
     W->sub_ws[i] = nullptr;
     W->sub_bytes[i] = 0;
@@ -101,8 +111,9 @@ static int carve_ws(void* ws, const LcrPrecomputeLayout& L, PreWs* W) {
 
 using namespace lcr;
 
-extern "C" int lcr_precompute_layout(int64_t n0, int B, int num_stages, const int* limits, int upsampling, LcrPrecomputeLayout* L) {
-  if (!L || !limits || n0 < 0 || B < 1 || B > 64 || num_stages < 1 || num_stages > LCR_MAX_STAGES) {
+extern "C" int lcr_precompute_layout(int64_t n0, int B, int num_stages, const int* limits, int upsampling, int64_t n_raw,
+                                     LcrPrecomputeLayout* L) {
+  if (!L || !limits || n0 < 0 || n_raw < 0 || B < 1 || B > 64 || num_stages < 1 || num_stages > LCR_MAX_STAGES) {
     set_error("lcr_precompute_layout: bad argument (B <= 64, stages <= %d)", LCR_MAX_STAGES);
     return LCR_EARG;
   }
@@ -110,6 +121,7 @@ extern "C" int lcr_precompute_layout(int64_t n0, int B, int num_stages, const in
   L->num_stages = num_stages;
   L->B = B;
   L->upsampling = upsampling ? 1 : 0;
+  L->n_raw = n_raw;
   const int64_t cap = n0 > 0 ? n0 : 1;
   Carver c(nullptr, ~size_t(0));
   for (int i = 0; i < num_stages; ++i) {
@@ -121,10 +133,11 @@ extern "C" int lcr_precompute_layout(int64_t n0, int B, int num_stages, const in
     L->cap[i] = cap;
   }
   for (int i = 0; i < num_stages; ++i) {
-    L->off_points[i] = i > 0 ? c.off : 0;
-    if (i > 0) c.take<float>(3 * cap);
-    L->off_lengths[i] = i > 0 ? c.off : 0;
-    if (i > 0) c.take<int64_t>(B);
+    const bool own = i > 0 || n_raw > 0;      // stage 0 is the caller's input unless it is produced here from raw scans
+    L->off_points[i] = own ? c.off : 0;
+    if (own) c.take<float>(3 * (i == 0 ? std::max<int64_t>(n_raw, cap) : cap));   // the voxelisation may emit up to n_raw rows
+    L->off_lengths[i] = own ? c.off : 0;
+    if (own) c.take<int64_t>(B);
     L->off_order[i] = c.off;
     c.take<int32_t>(cap);
     L->off_neighbors[i] = c.off;
@@ -147,7 +160,7 @@ extern "C" int lcr_precompute_layout(int64_t n0, int B, int num_stages, const in
 }
 
 extern "C" int lcr_precompute_batch(const float* points0, const int64_t* lengths0, const LcrPrecomputeLayout* L, float voxel_size,
-                                    float radius, int key_bits_hint, void* out, size_t out_bytes, void* ws, size_t ws_bytes,
+                                    float radius, float raw_voxel, int key_bits_hint, void* out, size_t out_bytes, void* ws, size_t ws_bytes,
                                     int64_t* lengths_host, uint32_t* status_host, void* stream) {
   if (!points0 || !lengths0 || !L || !out || !ws || !lengths_host || !status_host || !(voxel_size > 0.f) || !(radius > 0.f)) {
     set_error("lcr_precompute_batch: bad argument");
@@ -167,15 +180,25 @@ extern "C" int lcr_precompute_batch(const float* points0, const int64_t* lengths
   char* o = static_cast<char*>(out);
   const float* pts[LCR_MAX_STAGES];
   const int64_t* lens[LCR_MAX_STAGES];
+  const bool raw = L->n_raw > 0;
+  if (raw && !(raw_voxel > 0.f)) {
+    set_error("lcr_precompute_batch: raw mode needs raw_voxel > 0");
+    return LCR_EARG;
+  }
   pts[0] = points0;
   lens[0] = lengths0;
-  for (int i = 1; i < S; ++i) {
+  for (int i = raw ? 0 : 1; i < S; ++i) {
     pts[i] = reinterpret_cast<const float*>(o + L->off_points[i]);
     lens[i] = reinterpret_cast<const int64_t*>(o + L->off_lengths[i]);
   }
   auto i32 = [&](size_t off) { return reinterpret_cast<int32_t*>(o + off); };
 
   hipMemsetAsync(W.status, 0, sizeof(uint32_t) * 64, main);
+  if (raw) {
+    rc = TURN(lcr_grid_subsample_ex(points0, lengths0, B, L->n_raw, raw_voxel, key_bits_hint, const_cast<float*>(pts[0]),
+                                    const_cast<int64_t*>(lens[0]), W.status, W.raw_ws, W.raw_bytes, main));
+    if (rc) return rc;
+  }
   float v = voxel_size, r = radius;
   float radii[LCR_MAX_STAGES];
   for (int i = 0; i < S; ++i) {

@@ -16,6 +16,7 @@ from . import _lib
 from .modules.ops import SupportGrid, grid_subsample, grid_subsample_device, radius_search
 
 STATUS_KEY_OVERFLOW = 1
+STATUS_LEN_MISMATCH = 2
 
 
 def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, neighbor_limits):
@@ -47,7 +48,7 @@ MAX_STAGES = 8
 
 class PrecomputeLayout(ctypes.Structure):
     """Mirror of LcrPrecomputeLayout (include/lcr_hip.h)."""
-    _fields_ = [("num_stages", ctypes.c_int), ("B", ctypes.c_int), ("upsampling", ctypes.c_int),
+    _fields_ = [("num_stages", ctypes.c_int), ("B", ctypes.c_int), ("upsampling", ctypes.c_int), ("n_raw", ctypes.c_int64),
                 ("limits", ctypes.c_int * MAX_STAGES), ("cap", ctypes.c_int64 * MAX_STAGES),
                 ("off_points", ctypes.c_size_t * MAX_STAGES), ("off_lengths", ctypes.c_size_t * MAX_STAGES),
                 ("off_order", ctypes.c_size_t * MAX_STAGES), ("off_neighbors", ctypes.c_size_t * MAX_STAGES),
@@ -55,29 +56,40 @@ class PrecomputeLayout(ctypes.Structure):
                 ("out_bytes", ctypes.c_size_t), ("ws_bytes", ctypes.c_size_t)]
 
 
-def precompute_batch_native(points, lengths, num_stages, voxel_size, radius, neighbor_limits, upsampling=True, key_bits_hint=32):
+def precompute_batch_native(points, lengths, num_stages, voxel_size, radius, neighbor_limits, upsampling=True, key_bits_hint=32,
+                            raw_voxel=None, capacity=None):
     """precompute_batch as ONE native call (csrc/precompute.hip): same dictionary, int32 indices.  The ~250 launches and the
-    length read-back are issued by C++ (fork-join over side streams) with the interpreter lock released throughout."""
+    length read-back are issued by C++ (fork-join over side streams) with the interpreter lock released throughout.
+
+    raw_voxel: `points` are RAW scans, voxelised at this size inside the same call (no extra host round trip); `capacity` is
+    the row capacity assumed for the voxelised stack (default: a quarter of the raw points; a too small guess is detected on
+    the device and the call is repeated with the safe bound)."""
     _lib.require_cuda(points, lengths)
     assert points.dtype == torch.float32 and points.is_contiguous() and lengths.dtype == torch.int64 and num_stages == len(neighbor_limits)
     dev = points.device
     lengths = lengths.contiguous()
-    n0, B, S = points.shape[0], lengths.numel(), num_stages
+    B, S = lengths.numel(), num_stages
+    raw = raw_voxel is not None
+    n_raw = points.shape[0] if raw else 0
+    n0 = (int(capacity) if capacity else max(n_raw // 4, min(n_raw, 65536))) if raw else points.shape[0]
     L = _lib.lib()
     lay = PrecomputeLayout()
     lim = (ctypes.c_int * S)(*[int(x) for x in neighbor_limits])
-    _lib.check(L.lcr_precompute_layout(n0, B, S, ctypes.cast(lim, ctypes.c_void_p), int(bool(upsampling)), ctypes.addressof(lay)),
+    _lib.check(L.lcr_precompute_layout(n0, B, S, ctypes.cast(lim, ctypes.c_void_p), int(bool(upsampling)), n_raw, ctypes.addressof(lay)),
                "lcr_precompute_layout")
     out = torch.empty(max(lay.out_bytes, 256), dtype=torch.uint8, device=dev)
     ws = torch.empty(max(lay.ws_bytes, 256), dtype=torch.uint8, device=dev)
     lens_host = (ctypes.c_int64 * (S * B))()
     status = ctypes.c_uint32(0)
     _lib.check(L.lcr_precompute_batch(_lib.ptr(points), _lib.ptr(lengths), ctypes.addressof(lay), float(voxel_size), float(radius),
-                                      int(key_bits_hint), _lib.ptr(out), out.numel(), _lib.ptr(ws), ws.numel(),
+                                      float(raw_voxel) if raw else 0.0, int(key_bits_hint), _lib.ptr(out), out.numel(), _lib.ptr(ws), ws.numel(),
                                       ctypes.addressof(lens_host), ctypes.addressof(status), _lib.stream_ptr(dev)), "lcr_precompute_batch")
     st = status.value
     if st & STATUS_KEY_OVERFLOW and key_bits_hint:
-        return precompute_batch_native(points, lengths, num_stages, voxel_size, radius, neighbor_limits, upsampling, 0)
+        return precompute_batch_native(points, lengths, num_stages, voxel_size, radius, neighbor_limits, upsampling, 0, raw_voxel, capacity)
+    if raw and st & STATUS_LEN_MISMATCH and n0 < n_raw:
+        return precompute_batch_native(points, lengths, num_stages, voxel_size, radius, neighbor_limits, upsampling, key_bits_hint,
+                                       raw_voxel, n_raw)            # the voxel count exceeded the guessed capacity
     if st:
         raise RuntimeError("precompute_batch: device status 0x%x" % st)
     lengths_host = [[int(lens_host[i * B + b]) for b in range(B)] for i in range(S)]
@@ -86,8 +98,9 @@ def precompute_batch_native(points, lengths, num_stages, voxel_size, radius, nei
     def view(off, rows, cols, dtype, esize):
         return out[off:off + rows * cols * esize].view(dtype).view(rows, cols)
 
-    pts = [points] + [view(lay.off_points[i], tot[i], 3, torch.float32, 4) for i in range(1, S)]
-    lens = [lengths] + [out[lay.off_lengths[i]:lay.off_lengths[i] + 8 * B].view(torch.int64) for i in range(1, S)]
+    first = 0 if raw else 1
+    pts = ([] if raw else [points]) + [view(lay.off_points[i], tot[i], 3, torch.float32, 4) for i in range(first, S)]
+    lens = ([] if raw else [lengths]) + [out[lay.off_lengths[i]:lay.off_lengths[i] + 8 * B].view(torch.int64) for i in range(first, S)]
     orders = [out[lay.off_order[i]:lay.off_order[i] + 4 * tot[i]].view(torch.int32) for i in range(S)]
     neighbors = [view(lay.off_neighbors[i], tot[i], lay.limits[i], torch.int32, 4) for i in range(S)]
     subsampling = [view(lay.off_subsampling[i], tot[i + 1], lay.limits[i], torch.int32, 4) for i in range(S - 1)]

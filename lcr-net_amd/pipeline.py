@@ -10,7 +10,7 @@ import os
 
 import torch
 
-from .data import precompute_batch, voxelize_raw_scans
+from .data import precompute_batch, precompute_batch_native, voxelize_raw_scans
 
 
 class DescriptorPipeline:
@@ -40,11 +40,16 @@ class DescriptorPipeline:
     # ---- stages -----------------------------------------------------------------------------------------------------
     def preprocess(self, points, lengths):
         """points f32[N,3] (stacked raw or voxelised scans), lengths i64[B] -> data dict (on the current stream)."""
-        if self.raw_voxel is not None:
-            points, lengths, _ = voxelize_raw_scans(points, lengths, self.raw_voxel)
-        dd = precompute_batch(points.contiguous(), lengths, self.num_stages, self.voxel_size, self.radius, self.limits,
-                              upsampling=self.upsampling)
-        dd["features"] = torch.ones(points.shape[0], 1, device=points.device)
+        if self.raw_voxel is not None and not os.environ.get("LCR_PRE_TWO_CALLS"):
+            # raw scans -> everything, one native call and ONE host round trip (the voxelisation's own read-back is gone)
+            dd = precompute_batch_native(points.contiguous(), lengths.to(points.device), self.num_stages, self.voxel_size, self.radius,
+                                         self.limits, upsampling=self.upsampling, raw_voxel=self.raw_voxel)
+        else:
+            if self.raw_voxel is not None:
+                points, lengths, _ = voxelize_raw_scans(points, lengths, self.raw_voxel)
+            dd = precompute_batch(points.contiguous(), lengths, self.num_stages, self.voxel_size, self.radius, self.limits,
+                                  upsampling=self.upsampling)
+        dd["features"] = torch.ones(dd["points"][0].shape[0], 1, device=points.device)
         dd["lengths_c_host"] = dd["lengths_host"][-1]
         return dd
 

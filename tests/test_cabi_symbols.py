@@ -40,7 +40,7 @@ def test_precompute_layout_is_a_host_function_with_a_consistent_arena():
     for n0, B, limits, ups in [(16963, 1, [74, 68, 70, 67], 1), (127812, 8, [64, 65, 74, 80], 1), (500, 3, [8, 9], 0), (0, 2, [4, 4, 4], 1)]:
         lay = PrecomputeLayout()
         lim = (ctypes.c_int * len(limits))(*limits)
-        rc = lib.lcr_precompute_layout(n0, B, len(limits), ctypes.cast(lim, ctypes.c_void_p), ups, ctypes.addressof(lay))
+        rc = lib.lcr_precompute_layout(n0, B, len(limits), ctypes.cast(lim, ctypes.c_void_p), ups, 0, ctypes.addressof(lay))
         assert rc == 0
         assert lay.num_stages == len(limits) and lay.B == B and lay.upsampling == ups
         cap = max(n0, 1)
@@ -60,8 +60,12 @@ def test_precompute_layout_is_a_host_function_with_a_consistent_arena():
         assert spans[-1][0] + spans[-1][1] <= lay.out_bytes and lay.ws_bytes > 0
     bad = PrecomputeLayout()
     lim = (ctypes.c_int * 2)(4, 0)
-    assert lib.lcr_precompute_layout(10, 1, 2, ctypes.cast(lim, ctypes.c_void_p), 1, ctypes.addressof(bad)) != 0     # limit < 1
-    assert lib.lcr_precompute_layout(10, 65, 2, ctypes.cast(lim, ctypes.c_void_p), 1, ctypes.addressof(bad)) != 0    # B > 64
+    assert lib.lcr_precompute_layout(10, 1, 2, ctypes.cast(lim, ctypes.c_void_p), 1, 0, ctypes.addressof(bad)) != 0     # limit < 1
+    assert lib.lcr_precompute_layout(10, 65, 2, ctypes.cast(lim, ctypes.c_void_p), 1, 0, ctypes.addressof(bad)) != 0    # B > 64
+    raw = PrecomputeLayout()
+    lim4 = (ctypes.c_int * 4)(8, 8, 8, 8)
+    assert lib.lcr_precompute_layout(3000, 2, 4, ctypes.cast(lim4, ctypes.c_void_p), 1, 20000, ctypes.addressof(raw)) == 0
+    assert raw.n_raw == 20000 and raw.off_points[0] % 256 == 0 and raw.off_lengths[0] >= raw.off_points[0] + 20000 * 12   # stage 0 in the arena
     assert MAX_STAGES == 8
 
 

@@ -81,3 +81,24 @@ def test_native_precompute_ragged_batches(sizes):
     for key in ("points", "lengths", "neighbors", "subsampling", "upsampling"):
         for x, y in zip(a[key], b[key]):
             assert x.shape == y.shape and torch.equal(x, y), key
+
+
+def test_raw_scan_mode_of_the_native_precompute():
+    """Raw scans -> stage 0 -> everything in ONE native call == voxelize_raw_scans followed by precompute_batch; a capacity guess
+    that is too small is detected on the device and the call repeats with the safe bound."""
+    import lcrnet_amd.synthetic as synthetic
+    from lcrnet_amd.data import precompute_batch, precompute_batch_native, voxelize_raw_scans
+    scans = [synthetic.synthetic_scan(i)[::3] for i in range(3)]
+    pts = torch.from_numpy(np.concatenate(scans)).cuda()
+    lens = torch.tensor([len(s) for s in scans], dtype=torch.int64, device="cuda")
+    limits = [40, 40, 40, 40]
+    p0, l0, _ = voxelize_raw_scans(pts, lens, 0.3)
+    a = precompute_batch(p0.contiguous(), l0, 4, 0.3, 1.275, limits, native=False)
+    for cap in (None, 100):                               # default guess; a guess far too small (forces the retry)
+        b = precompute_batch_native(pts, lens, 4, 0.3, 1.275, limits, raw_voxel=0.3, capacity=cap)
+        torch.cuda.synchronize()
+        assert a["lengths_host"] == b["lengths_host"]
+        for key in ("points", "lengths", "neighbors", "subsampling", "upsampling"):
+            assert len(a[key]) == len(b[key])
+            for x, y in zip(a[key], b[key]):
+                assert x.shape == y.shape and torch.equal(x, y), key
