@@ -215,6 +215,9 @@ struct KernelTimerScope {
 // ws needs scan_ws_bytes(n) bytes.
 size_t scan_ws_bytes(int64_t n);
 int exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int64_t* total, void* ws, hipStream_t st);
+// A caller that issues many scans back to back (the native pre-processing driver) can lend them a region it has ALREADY zeroed
+// for their tile-state words: each scan then skips its own fill launch.  Per host thread; nullptr / 0 ends the loan.
+void scan_state_pool(void* zeroed, size_t bytes);
 // same, over min(n, *n_dev + n_add) entries (n_dev: device-side count; launches are sized for n and exit early beyond it)
 int exclusive_scan_i32_dev(const int32_t* in, int32_t* out, int64_t n, const int32_t* n_dev, int n_add, int64_t* total, void* ws,
                            hipStream_t st);

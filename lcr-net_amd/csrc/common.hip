@@ -217,6 +217,14 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_lookback(const int32_t* __restr
   }
 }
 
+static thread_local char* t_pool_base = nullptr;
+static thread_local size_t t_pool_bytes = 0, t_pool_off = 0;
+void scan_state_pool(void* zeroed, size_t bytes) {
+  t_pool_base = static_cast<char*>(zeroed);
+  t_pool_bytes = bytes;
+  t_pool_off = 0;
+}
+
 size_t scan_ws_bytes(int64_t n) { return align_up(sizeof(uint64_t) * (static_cast<size_t>((n + SCAN_TILE - 1) / SCAN_TILE) + 2)); }
 
 int exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int64_t* total, void* ws, hipStream_t st) {
@@ -233,8 +241,14 @@ int exclusive_scan_i32_dev(const int32_t* in, int32_t* out, int64_t n, const int
   static const bool three_pass = getenv("LCR_SCAN_3PASS") != nullptr;     // the previous three-launch form, kept for A/B
   if (!three_pass) {
     uint64_t* state = static_cast<uint64_t*>(ws);                           // [nt] words + the ticket
+    const size_t need = sizeof(uint64_t) * (static_cast<size_t>(nt) + 1);
+    if (t_pool_base && t_pool_off + need <= t_pool_bytes) {
+      state = reinterpret_cast<uint64_t*>(t_pool_base + t_pool_off);        // lent, already zero
+      t_pool_off += align_up(need);
+    } else {
+      hipMemsetAsync(ws, 0, need, st);
+    }
     uint32_t* ticket = reinterpret_cast<uint32_t*>(state + nt);
-    hipMemsetAsync(ws, 0, sizeof(uint64_t) * (static_cast<size_t>(nt) + 1), st);
     hipLaunchKernelGGL(k_scan_lookback, dim3(nt), dim3(SCAN_T), 0, st, in, out, n, n_dev, n_add, total, state, ticket);
     return check_launch("exclusive_scan_i32");
   }

@@ -211,11 +211,14 @@ __device__ __forceinline__ const uint32_t* sorted_vals(const GsHeader* h, const 
 }
 
 __global__ __launch_bounds__(256) void k_gs_heads(const GsHeader* __restrict__ h, const uint64_t* __restrict__ kA,
-                                                  const uint64_t* __restrict__ kB, int32_t* __restrict__ head, int64_t n_cap) {
+                                                  const uint64_t* __restrict__ kB, int32_t* __restrict__ head, int32_t* __restrict__ first,
+                                                  int64_t n_cap) {
   const int64_t n = h->rx.n;
   const uint64_t* k = sorted_keys(h, kA, kB);
-  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i <= n_cap; i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i <= n_cap; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
     head[i] = (i < n && (i == 0 || k[i] != k[i - 1])) ? 1 : 0;
+    first[i] = 0;                                 // the first-occurrence flags k_gs_reduce sets (saves a separate fill launch)
+  }
 }
 
 __global__ __launch_bounds__(256) void k_gs_seg_starts(const GsHeader* __restrict__ h, const int32_t* __restrict__ head_scan,
@@ -599,10 +602,9 @@ extern "C" int lcr_grid_subsample_ex(const float* xyz, const int64_t* len, int B
   const int max_passes = key_bits_hint > 0 ? (key_bits_hint + 7) / 8 : 8;
   int rc = radix_sort_pairs(&L.hdr->rx, L.keyA, L.keyB, L.valA, L.valB, n_cap, max_passes, L.hist, L.scan_ws, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_gs_heads, dim3(nblk), dim3(256), 0, st, L.hdr, L.keyA, L.keyB, L.head, n_cap);
+  hipLaunchKernelGGL(k_gs_heads, dim3(nblk), dim3(256), 0, st, L.hdr, L.keyA, L.keyB, L.head, L.first, n_cap);
   rc = exclusive_scan_i32(L.head, L.head, n_cap + 1, nullptr, L.scan_ws, st);
   if (rc) return rc;
-  hipMemsetAsync(L.first, 0, sizeof(int32_t) * (n_cap + 1), st);
   hipLaunchKernelGGL(k_gs_seg_starts, dim3(nblk), dim3(256), 0, st, L.hdr, L.head, L.seg_start);
   hipLaunchKernelGGL(k_gs_reduce, dim3(nblk), dim3(256), 0, st, L.hdr, xyz, L.keyA, L.keyB, L.valA, L.valB, L.head, L.seg_start, L.bary,
                      L.seg_key, L.seg_first, L.first);

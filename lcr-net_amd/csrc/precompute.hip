@@ -22,6 +22,8 @@
 
 namespace lcr {
 
+constexpr size_t PRE_SCAN_POOL = 2u << 20;        // >= 60 scans of up to 4 M entries (8 B per 4096-entry tile)
+
 struct PreCtx {
   hipStream_t side[LCR_MAX_STAGES] = {};
   hipEvent_t  ready[LCR_MAX_STAGES] = {};
@@ -71,6 +73,7 @@ struct CtxLease {
 };
 
 struct PreWs {
+  void*     scan_pool;                    // zero-filled tile-state words lent to the scans of the call (common.h)
   void*     raw_ws;                       // workspace of the raw-scan voxelisation (raw mode)
   size_t    raw_bytes;
   uint32_t* status;                       // [1] shared device status word
@@ -84,6 +87,7 @@ struct PreWs {
 static int carve_ws(void* ws, const LcrPrecomputeLayout& L, PreWs* W) {
   Carver c(ws, ~size_t(0));
   W->status = c.take<uint32_t>(64);
+  W->scan_pool = c.take<char>(PRE_SCAN_POOL);   // directly behind the status words: one fill covers both
   W->raw_ws = nullptr;
   W->raw_bytes = 0;
   if (L.n_raw > 0) {
@@ -193,7 +197,11 @@ extern "C" int lcr_precompute_batch(const float* points0, const int64_t* lengths
   }
   auto i32 = [&](size_t off) { return reinterpret_cast<int32_t*>(o + off); };
 
-  hipMemsetAsync(W.status, 0, sizeof(uint32_t) * 64, main);
+  hipMemsetAsync(W.status, 0, static_cast<size_t>(static_cast<char*>(W.scan_pool) - reinterpret_cast<char*>(W.status)) + PRE_SCAN_POOL, main);
+  struct PoolLoan {
+    PoolLoan(void* p, size_t n) { scan_state_pool(p, n); }
+    ~PoolLoan() { scan_state_pool(nullptr, 0); }
+  } loan(W.scan_pool, PRE_SCAN_POOL);
   if (raw) {
     rc = TURN(lcr_grid_subsample_ex(points0, lengths0, B, L->n_raw, raw_voxel, key_bits_hint, const_cast<float*>(pts[0]),
                                     const_cast<int64_t*>(lens[0]), W.status, W.raw_ws, W.raw_bytes, main));
