@@ -83,6 +83,9 @@ int lcr_support_grid_build(const float* s, const int64_t* slen, int B, int64_t n
 int lcr_radius_query(const float* q, const int64_t* qlen, int B, int64_t nq_cap,
                      const void* grid_ws, int64_t ns_cap /* as passed to the build */, float radius, int limit,
                      int64_t* out_idx64, int32_t* out_idx32, int32_t* out_cnt, void* stream);
+/* Same build that also writes the cell-sorted processing order (what lcr_support_grid_order returns) into order i32[ns_cap]. */
+int lcr_support_grid_build_ex(const float* s, const int64_t* slen, int B, int64_t ns_cap, float radius,
+                              uint32_t* status, void* grid_ws, size_t grid_ws_bytes, int32_t* order, void* stream);
 /* order[i] = stacked row of the i-th support in cell-sorted order (a spatially coherent processing order for gather kernels). */
 int lcr_support_grid_order(const void* grid_ws, int64_t ns_cap, int B, int32_t* order, void* stream);
 int lcr_radius_search_ws_bytes(int64_t nq_cap, int64_t ns_cap, int B, size_t* bytes);

@@ -72,7 +72,17 @@ struct CtxLease {
   }
 };
 
+struct LenPtrs {
+  const int64_t* p[LCR_MAX_STAGES];
+};
+// gathers the per-stage length vectors and the status word into one staging block: one D2H copy instead of num_stages + 1
+__global__ void k_pack_lengths(LenPtrs lens, int S, int B, const uint32_t* __restrict__ status, int64_t* __restrict__ packed) {
+  for (int i = threadIdx.x; i < S * B; i += blockDim.x) packed[(i / B) * 64 + (i % B)] = lens.p[i / B][i % B];
+  if (threadIdx.x == 0) packed[LCR_MAX_STAGES * 64] = static_cast<int64_t>(*status);
+}
+
 struct PreWs {
+  int64_t*  packed;                       // [LCR_MAX_STAGES * 64 + 8] device staging of lengths + status
   void*     scan_pool;                    // zero-filled tile-state words lent to the scans of the call (common.h)
   void*     raw_ws;                       // workspace of the raw-scan voxelisation (raw mode)
   size_t    raw_bytes;
@@ -87,6 +97,7 @@ struct PreWs {
 static int carve_ws(void* ws, const LcrPrecomputeLayout& L, PreWs* W) {
   Carver c(ws, ~size_t(0));
   W->status = c.take<uint32_t>(64);
+  W->packed = c.take<int64_t>(LCR_MAX_STAGES * 64 + 8);
   W->scan_pool = c.take<char>(PRE_SCAN_POOL);   // directly behind the status words: one fill covers both
   W->raw_ws = nullptr;
   W->raw_bytes = 0;
@@ -220,9 +231,7 @@ extern "C" int lcr_precompute_batch(const float* points0, const int64_t* lengths
     hipEventRecord(C.ready[i], main);
     hipStream_t s = C.side[i];
     hipStreamWaitEvent(s, C.ready[i], 0);
-    rc = TURN(lcr_support_grid_build(pts[i], lens[i], B, L->cap[i], r, W.status, W.grid_ws[i], W.grid_bytes[i], s));
-    if (rc) return rc;
-    rc = TURN(lcr_support_grid_order(W.grid_ws[i], L->cap[i], B, i32(L->off_order[i]), s));
+    rc = TURN(lcr_support_grid_build_ex(pts[i], lens[i], B, L->cap[i], r, W.status, W.grid_ws[i], W.grid_bytes[i], i32(L->off_order[i]), s));
     if (rc) return rc;
     rc = TURN(lcr_radius_query(pts[i], lens[i], B, L->cap[i], W.grid_ws[i], L->cap[i], r, L->limits[i], nullptr, i32(L->off_neighbors[i]),
                           nullptr, s));
@@ -245,14 +254,16 @@ extern "C" int lcr_precompute_batch(const float* points0, const int64_t* lengths
     hipEventRecord(C.done[i], C.side[i]);
     hipStreamWaitEvent(main, C.done[i], 0);
   }
-  for (int i = 0; i < S; ++i) hipMemcpyAsync(C.pinned + i * 64, lens[i], sizeof(int64_t) * B, hipMemcpyDeviceToHost, main);
-  hipMemcpyAsync(C.pinned + LCR_MAX_STAGES * 64, W.status, sizeof(uint32_t), hipMemcpyDeviceToHost, main);
+  LenPtrs lp;
+  for (int i = 0; i < LCR_MAX_STAGES; ++i) lp.p[i] = i < S ? lens[i] : nullptr;
+  hipLaunchKernelGGL(k_pack_lengths, dim3(1), dim3(256), 0, main, lp, S, B, W.status, W.packed);
+  hipMemcpyAsync(C.pinned, W.packed, sizeof(int64_t) * (LCR_MAX_STAGES * 64 + 1), hipMemcpyDeviceToHost, main);
   hipError_t e = hipStreamSynchronize(main);
   if (e != hipSuccess) {
     set_error("lcr_precompute_batch: %s", hipGetErrorString(e));
     return LCR_EHIP;
   }
   for (int i = 0; i < S; ++i) std::memcpy(lengths_host + static_cast<size_t>(i) * B, C.pinned + i * 64, sizeof(int64_t) * B);
-  std::memcpy(status_host, C.pinned + LCR_MAX_STAGES * 64, sizeof(uint32_t));
+  *status_host = static_cast<uint32_t>(C.pinned[LCR_MAX_STAGES * 64]);
   return check_launch("lcr_precompute_batch");
 }

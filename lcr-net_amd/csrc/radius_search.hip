@@ -177,12 +177,13 @@ __global__ __launch_bounds__(256) void k_grid_count(GridHeader* h, const float* 
 
 __global__ __launch_bounds__(256) void k_grid_scatter(GridHeader* h, const float* __restrict__ s, int32_t* __restrict__ cell_cnt,
                                                       const int32_t* __restrict__ cell_start, const int32_t* __restrict__ pt_cell,
-                                                      float4* __restrict__ sorted) {
+                                                      float4* __restrict__ sorted, int32_t* __restrict__ order) {
   const int64_t n = min(h->ns_total, h->ns_cap);
   for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
     const int cell = pt_cell[i];
     const int slot = cell_start[cell] + atomicSub(&cell_cnt[cell], 1) - 1;   // counts return to zero
     sorted[slot] = make_float4(s[3 * i + 0], s[3 * i + 1], s[3 * i + 2], __uint_as_float(static_cast<uint32_t>(i)));
+    if (order) order[slot] = static_cast<int32_t>(i);       // the cell-sorted processing order, for free (lcr_support_grid_order)
   }
 }
 
@@ -367,6 +368,11 @@ extern "C" int lcr_support_grid_ws_bytes(int64_t ns_cap, int B, size_t* bytes) {
 
 extern "C" int lcr_support_grid_build(const float* s, const int64_t* slen, int B, int64_t ns_cap, float radius, uint32_t* status,
                                       void* grid_ws, size_t grid_ws_bytes, void* stream) {
+  return lcr_support_grid_build_ex(s, slen, B, ns_cap, radius, status, grid_ws, grid_ws_bytes, nullptr, stream);
+}
+
+extern "C" int lcr_support_grid_build_ex(const float* s, const int64_t* slen, int B, int64_t ns_cap, float radius, uint32_t* status,
+                                         void* grid_ws, size_t grid_ws_bytes, int32_t* order, void* stream) {
   if (!slen || !grid_ws || B < 1 || B > GRID_MAX_B || ns_cap < 0 || !(radius > 0.f)) {
     set_error("lcr_support_grid_build: bad argument");
     return LCR_EARG;
@@ -392,7 +398,7 @@ extern "C" int lcr_support_grid_build(const float* s, const int64_t* slen, int B
   hipLaunchKernelGGL(k_grid_count, dim3(nblk), dim3(256), 0, st, L.hdr, s, L.cell_cnt, L.pt_cell);
   int rc = exclusive_scan_i32_dev(L.cell_cnt, L.cell_start, cell_cap + 1, &L.hdr->n_cells, 1, nullptr, L.scan_ws, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_grid_scatter, dim3(nblk), dim3(256), 0, st, L.hdr, s, L.cell_cnt, L.cell_start, L.pt_cell, L.sorted);
+  hipLaunchKernelGGL(k_grid_scatter, dim3(nblk), dim3(256), 0, st, L.hdr, s, L.cell_cnt, L.cell_start, L.pt_cell, L.sorted, order);
   return check_launch("lcr_support_grid_build");
 }
 
