@@ -148,6 +148,8 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     F.set_timer(None)
+    if os.environ.get("LCR_PIPE_STATS") and rank == 0:
+        print("pipeline host threads:", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in pipe.stats.items()}, file=sys.stderr)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -7,6 +7,7 @@ batch k (throughput-bound MFMA/HBM kernels) run on stream B.  Ordering is by eve
 are `record_stream`ed so the caching allocator cannot recycle them early.
 """
 import os
+import time
 
 import torch
 
@@ -29,6 +30,7 @@ class DescriptorPipeline:
         prio = -1 if os.environ.get("LCR_PRE_PRIORITY", "1") != "0" else 0
         self.pre_stream = torch.cuda.Stream(dev, priority=prio) if overlap else None
         self.producer_thread, self.depth, self.pre_workers = producer_thread, depth, pre_workers
+        self.stats = {"pre_wait_s": 0.0, "pre_busy_s": 0.0, "enc_wait_s": 0.0, "batches": 0}   # where the two host threads wait
         self.enc_streams = None      # set by enable_dual_encoder(): consecutive batches' encoders on alternating streams
 
     def enable_dual_encoder(self, n=2):
@@ -120,7 +122,9 @@ class DescriptorPipeline:
                 torch.cuda.set_device(dev)
                 with torch.cuda.stream(st):
                     while True:
+                        t0 = time.perf_counter()
                         slots.acquire()
+                        t1 = time.perf_counter()
                         with it_lock:
                             nxt = next(it, None)
                         if nxt is None:
@@ -128,6 +132,9 @@ class DescriptorPipeline:
                             break
                         k, (pts, lens) = nxt
                         dd = self.preprocess(pts, lens)
+                        self.stats["pre_wait_s"] += t1 - t0           # blocked: the encoder side is behind
+                        self.stats["pre_busy_s"] += time.perf_counter() - t1
+                        self.stats["batches"] += 1
                         ev = torch.cuda.Event()
                         ev.record(st)
                         out.put((k, dd, ev))
@@ -144,7 +151,9 @@ class DescriptorPipeline:
         pending = None       # (descriptors, done event) of the previous batch when two encoder streams are used
         while True:
             while k not in ready and finished < W:
+                t0 = time.perf_counter()
                 item = out.get()
+                self.stats["enc_wait_s"] += time.perf_counter() - t0   # blocked: the pre-processing side is behind
                 if item is None:
                     finished += 1
                 elif isinstance(item, BaseException):
