@@ -360,7 +360,6 @@ __device__ void hm_scan_inplace(int32_t* a, int n, int* lds) {
 
 // Every pass below walks its index range in batches of HU entries per thread: the batch's loads are issued together, then
 // consumed — one workgroup per cloud is latency-bound, so the number of DEPENDENT memory round trips per pass is what counts.
-constexpr int HU = 4;
 
 // key % nb for nb < 2^31: 32-bit remainder when the key fits, else floor(key * (1/nb)) in fp64 (exact quotient within +-1 for
 // keys < 2^53, fixed up), else the 64-bit division.  The generic 64-bit urem costs ~100 instructions per element and phase.
@@ -376,6 +375,164 @@ __device__ __forceinline__ int hm_bucket(uint64_t key, uint64_t nb64, double inv
   return static_cast<int>(key % nb64);
 }
 
+// One phase of the replay with nb buckets: elements [0, hi) are in the table, those below `lo` carry their list position after
+// the previous phase in t[], the rest are new (timestamp = insertion rank).  Leaves the new list positions in bk[] (the caller
+// swaps t and bk).  The arrays may live in LDS (small phases) or in global memory; the code is the same.
+template <int HU>
+__device__ __forceinline__ void hm_phase(const uint64_t* __restrict__ key, int32_t* __restrict__ t, int32_t* __restrict__ bk,
+                                         int32_t* __restrict__ memt, int32_t* __restrict__ arrv, int32_t* __restrict__ at,
+                                         int32_t* __restrict__ gmin, int32_t* __restrict__ cnt, int32_t* __restrict__ start, int lo,
+                                         int hi, int nb, uint64_t nb64, int* lds) {
+  const int tid = threadIdx.x;
+  const double inv_nb = 1.0 / static_cast<double>(nb64);
+  // only buckets that can be hit matter, but all nb are scanned for the member offsets; nb <= 2.25 n + 64
+  for (int i = tid; i < nb; i += HM_T) {
+    gmin[i] = 0x7fffffff;
+    cnt[i] = 0;
+  }
+  __syncthreads();
+  // pass A: bucket of every element; per bucket the earliest member (group creation time) and the member count.  The
+  // counting atomic returns the element's arrival index inside its bucket (its slot in the member list, pass C).
+  for (int e0 = tid; e0 < hi; e0 += HU * HM_T) {
+    uint64_t kk[HU];
+    int tt[HU];
+#pragma unroll
+    for (int k = 0; k < HU; ++k) {
+      const int e = e0 + k * HM_T;
+      if (e < hi) {
+        kk[k] = key[e];
+        tt[k] = e >= lo ? e : t[e];            // new elements: timestamp = insertion rank
+      }
+    }
+    int bb[HU], arr[HU];
+#pragma unroll
+    for (int k = 0; k < HU; ++k) {
+      const int e = e0 + k * HM_T;
+      if (e < hi) {
+        bb[k] = hm_bucket(kk[k], nb64, inv_nb);
+        atomicMin(&gmin[bb[k]], tt[k]);
+        arr[k] = atomicAdd(&cnt[bb[k]], 1);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < HU; ++k) {
+      const int e = e0 + k * HM_T;
+      if (e < hi) {
+        bk[e] = bb[k];
+        if (e >= lo) t[e] = e;
+        at[e] = 0;
+        arrv[e] = arr[k];
+      }
+    }
+  }
+  __syncthreads();
+  // pass B: group sizes keyed by the group's creation time
+  for (int i0 = tid; i0 < nb; i0 += HU * HM_T) {
+    int c[HU], g[HU];
+#pragma unroll
+    for (int k = 0; k < HU; ++k) {
+      const int i = i0 + k * HM_T;
+      if (i < nb) {
+        c[k] = cnt[i];
+        g[k] = gmin[i];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < HU; ++k) {
+      const int i = i0 + k * HM_T;
+      if (i < nb) {
+        if (c[k] > 0) at[g[k]] = c[k];
+        start[i] = c[k];
+      }
+    }
+  }
+  __syncthreads();
+  hm_scan_inplace<true>(at, hi, lds);     // at[tt] = number of elements in groups created AFTER time tt
+  hm_scan_inplace<false>(start, nb, lds);  // member-list offsets per bucket
+  // pass C: member lists (timestamps), and per bucket the list position of its group (replaces gmin)
+  for (int e0 = tid; e0 < hi; e0 += HU * HM_T) {
+    int bb[HU], tt[HU], ar[HU], s0[HU];
+#pragma unroll
+    for (int k = 0; k < HU; ++k) {
+      const int e = e0 + k * HM_T;
+      if (e < hi) {
+        bb[k] = bk[e];
+        tt[k] = t[e];
+        ar[k] = arrv[e];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < HU; ++k) {
+      const int e = e0 + k * HM_T;
+      if (e < hi) s0[k] = start[bb[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < HU; ++k) {
+      const int e = e0 + k * HM_T;
+      if (e < hi) memt[s0[k] + ar[k]] = tt[k];
+    }
+  }
+  for (int i0 = tid; i0 < nb; i0 += HU * HM_T) {
+    int g[HU];
+#pragma unroll
+    for (int k = 0; k < HU; ++k) {
+      const int i = i0 + k * HM_T;
+      g[k] = i < nb ? gmin[i] : 0x7fffffff;
+    }
+#pragma unroll
+    for (int k = 0; k < HU; ++k) {
+      const int i = i0 + k * HM_T;
+      if (i < nb && g[k] != 0x7fffffff) gmin[i] = at[g[k]];
+    }
+  }
+  __syncthreads();
+  // pass D: new list position = (elements of groups created later) + (newer members of the own bucket)
+  for (int e0 = tid; e0 < hi; e0 += HU * HM_T) {
+    int bb[HU], te[HU], s0[HU], s1[HU], a0[HU], r[HU];
+#pragma unroll
+    for (int k = 0; k < HU; ++k) {
+      const int e = e0 + k * HM_T;
+      bb[k] = 0;
+      te[k] = 0;
+      if (e < hi) {
+        bb[k] = bk[e];
+        te[k] = t[e];
+      }
+    }
+    int maxlen = 0;
+#pragma unroll
+    for (int k = 0; k < HU; ++k) {
+      const int e = e0 + k * HM_T;
+      s0[k] = s1[k] = a0[k] = 0;
+      if (e < hi) {
+        s0[k] = start[bb[k]];
+        s1[k] = (bb[k] + 1 < nb) ? start[bb[k] + 1] : hi;
+        a0[k] = gmin[bb[k]];
+      }
+      r[k] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < HU; ++k) maxlen = max(maxlen, s1[k] - s0[k]);
+    for (int j = 0; j < maxlen; ++j) {        // buckets hold one or two elements almost always
+#pragma unroll
+      for (int k = 0; k < HU; ++k)
+        if (s0[k] + j < s1[k]) r[k] += memt[s0[k] + j] > te[k];   // newer members of the bucket come first
+    }
+#pragma unroll
+    for (int k = 0; k < HU; ++k) {
+      const int e = e0 + k * HM_T;
+      if (e < hi) bk[e] = a0[k] + r[k];        // position in the list after this phase
+    }
+  }
+  __syncthreads();
+}
+
+// The first HM_LDS_PHASES phases (up to 2357 buckets) run on LDS-resident arrays: a phase is eight block-wide passes with a
+// barrier between them, full of scattered accesses and atomics — one CU issues those ~30x faster to LDS than to L2/HBM.
+constexpr int HM_LDS_PHASES = 8;
+constexpr int HM_LC = 2357 + 3;         // entries per LDS array (c_sched[HM_LDS_PHASES - 1], padded)
+constexpr size_t HM_LDS_BYTES = static_cast<size_t>(HM_LC) * (8 * sizeof(int32_t) + sizeof(uint64_t));
+
 __global__ __launch_bounds__(HM_T) void k_gs_hashorder(const GsHeader* __restrict__ h, const uint64_t* __restrict__ ins_key,
                                                        const int32_t* __restrict__ ins_seg, const float* __restrict__ bary,
                                                        int32_t* __restrict__ hm_t, int32_t* __restrict__ hm_bk,
@@ -383,11 +540,57 @@ __global__ __launch_bounds__(HM_T) void k_gs_hashorder(const GsHeader* __restric
                                                        int32_t* __restrict__ hm_arr, int32_t* __restrict__ hm_gmin, int32_t* __restrict__ hm_cnt,
                                                        int32_t* __restrict__ hm_start, float* __restrict__ out_xyz) {
   __shared__ int lds[HM_T / 64];
+  extern __shared__ __align__(16) unsigned char hm_dyn[];
   const int b = blockIdx.x;
   const int n = h->M[b];
   if (n <= 0) return;
   const int64_t o = h->out_off[b];
   const uint64_t* key = ins_key + o;
+  const int tid = threadIdx.x;
+
+  int lo = 0, p = 0;
+  {
+    uint64_t* lkey = reinterpret_cast<uint64_t*>(hm_dyn);
+    int32_t* lt = reinterpret_cast<int32_t*>(lkey + HM_LC);
+    int32_t* lbk = lt + HM_LC;
+    int32_t* lmem = lbk + HM_LC;
+    int32_t* larr = lmem + HM_LC;
+    int32_t* lat = larr + HM_LC;
+    int32_t* lgmin = lat + HM_LC;
+    int32_t* lcnt = lgmin + HM_LC;
+    int32_t* lstart = lcnt + HM_LC;
+    const int nl = min(n, static_cast<int>(c_sched[HM_LDS_PHASES - 1]));
+    for (int e = tid; e < nl; e += HM_T) lkey[e] = key[e];
+    __syncthreads();
+    bool done = false;
+    for (; p < HM_LDS_PHASES; ++p) {
+      const int nb = static_cast<int>(c_sched[p]);
+      const int hi = min(n, nb);
+      hm_phase<4>(lkey, lt, lbk, lmem, larr, lat, lgmin, lcnt, lstart, lo, hi, nb, static_cast<uint64_t>(nb), lds);
+      int32_t* sw = lt;                          // the new positions become the next phase's timestamps
+      lt = lbk;
+      lbk = sw;
+      lo = hi;
+      if (hi >= n) {
+        done = true;
+        break;
+      }
+    }
+    if (done) {
+      // lt[rank] = position in iteration order
+      for (int e = tid; e < n; e += HM_T) {
+        const int seg = ins_seg[o + e];
+        const int64_t dst = o + lt[e];
+        out_xyz[3 * dst + 0] = bary[3 * seg + 0];
+        out_xyz[3 * dst + 1] = bary[3 * seg + 1];
+        out_xyz[3 * dst + 2] = bary[3 * seg + 2];
+      }
+      return;
+    }
+    for (int e = tid; e < lo; e += HM_T) hm_t[o + e] = lt[e];
+    __syncthreads();
+  }
+
   int32_t* t = hm_t + o;         // list position of every element after the previous phase (ping-pongs with bk)
   int32_t* bk = hm_bk + o;       // bucket of every element in this phase, then its new list position
   int32_t* memt = hm_mem + o;    // member lists: the TIMESTAMPS of every bucket's elements, bucket after bucket
@@ -397,155 +600,12 @@ __global__ __launch_bounds__(HM_T) void k_gs_hashorder(const GsHeader* __restric
   int32_t* gmin = hm_gmin + bo;  // earliest member (group creation time); after pass B2: list position of the group's head
   int32_t* cnt = hm_cnt + bo;
   int32_t* start = hm_start + bo;
-  const int tid = threadIdx.x;
-
-  int lo = 0;
-  for (int p = 0; p < N_SCHED; ++p) {
+  for (; p < N_SCHED; ++p) {
     const int64_t nb64 = c_sched[p];
-    const double inv_nb = 1.0 / static_cast<double>(nb64);
     const int hi = static_cast<int>(min(static_cast<int64_t>(n), nb64));
     const int nb = static_cast<int>(min(nb64, static_cast<int64_t>(2147483647)));
-    // only buckets that can be hit matter, but all nb are scanned for the member offsets; nb <= 2.25 n + 64
-    for (int i = tid; i < nb; i += HM_T) {
-      gmin[i] = 0x7fffffff;
-      cnt[i] = 0;
-    }
-    __syncthreads();
-    // pass A: bucket of every element; per bucket the earliest member (group creation time) and the member count.  The
-    // counting atomic returns the element's arrival index inside its bucket (its slot in the member list, pass C).
-    for (int e0 = tid; e0 < hi; e0 += HU * HM_T) {
-      uint64_t kk[HU];
-      int tt[HU];
-#pragma unroll
-      for (int k = 0; k < HU; ++k) {
-        const int e = e0 + k * HM_T;
-        if (e < hi) {
-          kk[k] = key[e];
-          tt[k] = e >= lo ? e : t[e];            // new elements: timestamp = insertion rank
-        }
-      }
-      int bb[HU], arr[HU];
-#pragma unroll
-      for (int k = 0; k < HU; ++k) {
-        const int e = e0 + k * HM_T;
-        if (e < hi) {
-          bb[k] = hm_bucket(kk[k], static_cast<uint64_t>(nb64), inv_nb);
-          atomicMin(&gmin[bb[k]], tt[k]);
-          arr[k] = atomicAdd(&cnt[bb[k]], 1);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < HU; ++k) {
-        const int e = e0 + k * HM_T;
-        if (e < hi) {
-          bk[e] = bb[k];
-          if (e >= lo) t[e] = e;
-          at[e] = 0;
-          arrv[e] = arr[k];
-        }
-      }
-    }
-    __syncthreads();
-    // pass B: group sizes keyed by the group's creation time
-    for (int i0 = tid; i0 < nb; i0 += HU * HM_T) {
-      int c[HU], g[HU];
-#pragma unroll
-      for (int k = 0; k < HU; ++k) {
-        const int i = i0 + k * HM_T;
-        if (i < nb) {
-          c[k] = cnt[i];
-          g[k] = gmin[i];
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < HU; ++k) {
-        const int i = i0 + k * HM_T;
-        if (i < nb) {
-          if (c[k] > 0) at[g[k]] = c[k];
-          start[i] = c[k];
-        }
-      }
-    }
-    __syncthreads();
-    hm_scan_inplace<true>(at, hi, lds);     // at[tt] = number of elements in groups created AFTER time tt
-    hm_scan_inplace<false>(start, nb, lds);  // member-list offsets per bucket
-    // pass C: member lists (timestamps), and per bucket the list position of its group (replaces gmin)
-    for (int e0 = tid; e0 < hi; e0 += HU * HM_T) {
-      int bb[HU], tt[HU], ar[HU], s0[HU];
-#pragma unroll
-      for (int k = 0; k < HU; ++k) {
-        const int e = e0 + k * HM_T;
-        if (e < hi) {
-          bb[k] = bk[e];
-          tt[k] = t[e];
-          ar[k] = arrv[e];
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < HU; ++k) {
-        const int e = e0 + k * HM_T;
-        if (e < hi) s0[k] = start[bb[k]];
-      }
-#pragma unroll
-      for (int k = 0; k < HU; ++k) {
-        const int e = e0 + k * HM_T;
-        if (e < hi) memt[s0[k] + ar[k]] = tt[k];
-      }
-    }
-    for (int i0 = tid; i0 < nb; i0 += HU * HM_T) {
-      int g[HU];
-#pragma unroll
-      for (int k = 0; k < HU; ++k) {
-        const int i = i0 + k * HM_T;
-        g[k] = i < nb ? gmin[i] : 0x7fffffff;
-      }
-#pragma unroll
-      for (int k = 0; k < HU; ++k) {
-        const int i = i0 + k * HM_T;
-        if (i < nb && g[k] != 0x7fffffff) gmin[i] = at[g[k]];
-      }
-    }
-    __syncthreads();
-    // pass D: new list position = (elements of groups created later) + (newer members of the own bucket)
-    for (int e0 = tid; e0 < hi; e0 += HU * HM_T) {
-      int bb[HU], te[HU], s0[HU], s1[HU], a0[HU], r[HU];
-#pragma unroll
-      for (int k = 0; k < HU; ++k) {
-        const int e = e0 + k * HM_T;
-        bb[k] = 0;
-        te[k] = 0;
-        if (e < hi) {
-          bb[k] = bk[e];
-          te[k] = t[e];
-        }
-      }
-      int maxlen = 0;
-#pragma unroll
-      for (int k = 0; k < HU; ++k) {
-        const int e = e0 + k * HM_T;
-        s0[k] = s1[k] = a0[k] = 0;
-        if (e < hi) {
-          s0[k] = start[bb[k]];
-          s1[k] = (bb[k] + 1 < nb) ? start[bb[k] + 1] : hi;
-          a0[k] = gmin[bb[k]];
-        }
-        r[k] = 0;
-      }
-#pragma unroll
-      for (int k = 0; k < HU; ++k) maxlen = max(maxlen, s1[k] - s0[k]);
-      for (int j = 0; j < maxlen; ++j) {        // buckets hold one or two elements almost always
-#pragma unroll
-        for (int k = 0; k < HU; ++k)
-          if (s0[k] + j < s1[k]) r[k] += memt[s0[k] + j] > te[k];   // newer members of the bucket come first
-      }
-#pragma unroll
-      for (int k = 0; k < HU; ++k) {
-        const int e = e0 + k * HM_T;
-        if (e < hi) bk[e] = a0[k] + r[k];        // position in the list after this phase
-      }
-    }
-    __syncthreads();
-    int32_t* sw = t;                             // the new positions become the next phase's timestamps
+    hm_phase<4>(key, t, bk, memt, arrv, at, gmin, cnt, start, lo, hi, nb, static_cast<uint64_t>(nb64), lds);
+    int32_t* sw = t;
     t = bk;
     bk = sw;
     lo = hi;
@@ -612,7 +672,13 @@ extern "C" int lcr_grid_subsample_ex(const float* xyz, const int64_t* len, int B
   if (rc) return rc;
   hipLaunchKernelGGL(k_gs_offsets, dim3(1), dim3(64), 0, st, L.hdr, L.head, out_len);
   hipLaunchKernelGGL(k_gs_insertion, dim3(nblk), dim3(256), 0, st, L.hdr, L.first, L.seg_key, L.seg_first, L.ins_key, L.ins_seg);
-  hipLaunchKernelGGL(k_gs_hashorder, dim3(B), dim3(HM_T), 0, st, L.hdr, L.ins_key, L.ins_seg, L.bary, L.hm_t, L.hm_bk, L.hm_mem, L.hm_at, L.hm_arr,
+  static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gs_hashorder),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(HM_LDS_BYTES));
+  if (lds_ok != hipSuccess) {
+    set_error("lcr_grid_subsample: cannot reserve %zu B of LDS for the hash-order kernel", HM_LDS_BYTES);
+    return LCR_EHIP;
+  }
+  hipLaunchKernelGGL(k_gs_hashorder, dim3(B), dim3(HM_T), HM_LDS_BYTES, st, L.hdr, L.ins_key, L.ins_seg, L.bary, L.hm_t, L.hm_bk, L.hm_mem, L.hm_at, L.hm_arr,
                      L.hm_gmin, L.hm_cnt, L.hm_start, out_xyz);
   return check_launch("lcr_grid_subsample");
 }
