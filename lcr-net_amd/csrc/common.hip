@@ -163,11 +163,13 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_lookback(const int32_t* __restr
   __shared__ int lds[8];
   __shared__ int s_tile, s_prefix;
   if (n_dev) n = min(n, static_cast<int64_t>(*n_dev) + n_add);
+  // launched for the capacity: workgroups beyond the tiles in use leave before touching the ticket (one same-address atomic per
+  // workgroup is what a mostly empty launch would otherwise spend its time on); the others draw exactly the tickets in use
+  if (static_cast<int64_t>(blockIdx.x) * SCAN_TILE >= n) return;
   if (threadIdx.x == 0) s_tile = static_cast<int>(atomicAdd(ticket, 1u));
   __syncthreads();
   const int tile = s_tile;
   const int64_t base = static_cast<int64_t>(tile) * SCAN_TILE + threadIdx.x * SCAN_I;
-  if (static_cast<int64_t>(tile) * SCAN_TILE >= n) return;      // every later ticket is beyond n as well: nobody waits for this tile
   int v[SCAN_I];
   int s = 0;
 #pragma unroll

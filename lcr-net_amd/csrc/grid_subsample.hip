@@ -180,7 +180,7 @@ __global__ void k_gs_params(GsHeader* h, float voxel, float inv_voxel, int key_b
     kbits = max(total - cbits, 1);
   }
   h->kbits = kbits;
-  h->rx.num_passes = (total + 7) / 8;
+  h->rx.num_passes = radix_passes(total);
 }
 
 __global__ __launch_bounds__(256) void k_gs_keys(GsHeader* h, const float* __restrict__ xyz, float voxel, uint64_t* __restrict__ keyA,
@@ -659,7 +659,7 @@ extern "C" int lcr_grid_subsample_ex(const float* xyz, const int64_t* len, int B
   hipLaunchKernelGGL(k_gs_bbox, dim3(n_cap > 0 ? min(div_up(n_cap, 1024), 512) : 1), dim3(256), 0, st, L.hdr, xyz);
   hipLaunchKernelGGL(k_gs_params, dim3(1), dim3(64), 0, st, L.hdr, voxel, inv_voxel, key_bits_hint, status);
   hipLaunchKernelGGL(k_gs_keys, dim3(nblk), dim3(256), 0, st, L.hdr, xyz, voxel, L.keyA, L.valA, status);
-  const int max_passes = key_bits_hint > 0 ? (key_bits_hint + 7) / 8 : 8;
+  const int max_passes = radix_passes(key_bits_hint > 0 ? key_bits_hint : 64);
   int rc = radix_sort_pairs(&L.hdr->rx, L.keyA, L.keyB, L.valA, L.valB, n_cap, max_passes, L.hist, L.scan_ws, st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_gs_heads, dim3(nblk), dim3(256), 0, st, L.hdr, L.keyA, L.keyB, L.head, L.first, n_cap);

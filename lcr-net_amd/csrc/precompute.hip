@@ -12,6 +12,7 @@
 // layout lcr_precompute_layout reports; capacities are bounded by the stage-0 point count (every stage is a subset sample).
 #include <algorithm>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -186,6 +187,17 @@ extern "C" int lcr_precompute_batch(const float* points0, const int64_t* lengths
     return LCR_ESPACE;
   }
   const int S = L->num_stages, B = L->B;
+  // LCR_PRE_HOST_STATS=1: where this call's host time goes (issuing the launches vs waiting for the stream), printed at exit
+  struct HostStats {
+    double launch_s = 0, wait_s = 0;
+    long calls = 0;
+    bool on = getenv("LCR_PRE_HOST_STATS") != nullptr;
+    ~HostStats() {
+      if (on && calls) fprintf(stderr, "lcr_precompute_batch: %ld calls, issuing %.3f ms, waiting %.3f ms per call\n", calls, launch_s / calls * 1e3, wait_s / calls * 1e3);
+    }
+  };
+  static HostStats hs;
+  const auto t_in = std::chrono::steady_clock::now();
   PreWs W;
   int rc = carve_ws(ws, *L, &W);
   if (rc) return rc;
@@ -262,7 +274,14 @@ extern "C" int lcr_precompute_batch(const float* points0, const int64_t* lengths
   for (int i = 0; i < LCR_MAX_STAGES; ++i) lp.p[i] = i < S ? lens[i] : nullptr;
   hipLaunchKernelGGL(k_pack_lengths, dim3(1), dim3(256), 0, main, lp, S, B, W.status, W.packed);
   hipMemcpyAsync(C.pinned, W.packed, sizeof(int64_t) * (LCR_MAX_STAGES * 64 + 1), hipMemcpyDeviceToHost, main);
+  const auto t_issued = std::chrono::steady_clock::now();
   hipError_t e = hipStreamSynchronize(main);
+  if (hs.on) {
+    const auto t_done = std::chrono::steady_clock::now();
+    hs.launch_s += std::chrono::duration<double>(t_issued - t_in).count();
+    hs.wait_s += std::chrono::duration<double>(t_done - t_issued).count();
+    ++hs.calls;
+  }
   if (e != hipSuccess) {
     set_error("lcr_precompute_batch: %s", hipGetErrorString(e));
     return LCR_EHIP;

@@ -3,15 +3,15 @@
 
 namespace lcr {
 
-__device__ __forceinline__ uint32_t digit_of(uint64_t k, int pass) { return static_cast<uint32_t>(k >> (8 * pass)) & 255u; }
+__device__ __forceinline__ uint32_t digit_of(uint64_t k, int pass) { return static_cast<uint32_t>(k >> (RX_BITS * pass)) & (RX_D - 1u); }
 
 __global__ __launch_bounds__(RX_T) void k_rx_hist(const RadixCtl* __restrict__ ctl, const uint64_t* __restrict__ kA,
                                                   const uint64_t* __restrict__ kB, int pass, int32_t* __restrict__ hist, int ntiles) {
-  __shared__ int s_h[256];
+  __shared__ int s_h[RX_D];
   if (pass >= ctl->num_passes) return;
   const int64_t n = ctl->n;
   const uint64_t* keys = (pass & 1) ? kB : kA;
-  s_h[threadIdx.x] = 0;
+  for (int d = threadIdx.x; d < RX_D; d += RX_T) s_h[d] = 0;
   __syncthreads();
   const int64_t base = static_cast<int64_t>(blockIdx.x) * RX_TILE;
   for (int k = 0; k < RX_I; ++k) {
@@ -19,14 +19,14 @@ __global__ __launch_bounds__(RX_T) void k_rx_hist(const RadixCtl* __restrict__ c
     if (i < n) atomicAdd(&s_h[digit_of(keys[i], pass)], 1);
   }
   __syncthreads();
-  hist[static_cast<int64_t>(threadIdx.x) * ntiles + blockIdx.x] = s_h[threadIdx.x];   // digit-major
+  for (int d = threadIdx.x; d < RX_D; d += RX_T) hist[static_cast<int64_t>(d) * ntiles + blockIdx.x] = s_h[d];   // digit-major
 }
 
 __global__ __launch_bounds__(RX_T) void k_rx_scatter(const RadixCtl* __restrict__ ctl, const uint64_t* __restrict__ kA,
                                                      uint64_t* __restrict__ kB_, const uint32_t* __restrict__ vA,
                                                      uint32_t* __restrict__ vB_, int pass, const int32_t* __restrict__ hist_scan,
                                                      int ntiles) {
-  __shared__ int s_cnt[RX_T / 64][256];   // per-wave digit totals
+  __shared__ int s_cnt[RX_T / 64][RX_D];   // per-wave digit totals
   if (pass >= ctl->num_passes) return;
   const int64_t n = ctl->n;
   // ping-pong: even passes read A write B
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(RX_T) void k_rx_scatter(const RadixCtl* __restrict_
   uint32_t* vout = (pass & 1) ? const_cast<uint32_t*>(vA) : vB_;
 
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
-  for (int d = lane; d < 256; d += 64) s_cnt[w][d] = 0;
+  for (int d = lane; d < RX_D; d += 64) s_cnt[w][d] = 0;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -52,11 +52,11 @@ __global__ __launch_bounds__(RX_T) void k_rx_scatter(const RadixCtl* __restrict_
     const bool ok = i < n;
     key[k] = ok ? kin[i] : ~0ull;
     val[k] = ok ? vin[i] : 0u;
-    const uint32_t d = ok ? digit_of(key[k], pass) : 256u;
+    const uint32_t d = ok ? digit_of(key[k], pass) : static_cast<uint32_t>(RX_D);
     // lanes with the same digit
     uint64_t m = __ballot(ok);
 #pragma unroll
-    for (int bit = 0; bit < 8; ++bit) {
+    for (int bit = 0; bit < RX_BITS; ++bit) {
       const uint64_t bm = __ballot((d >> bit) & 1u);
       m &= ((d >> bit) & 1u) ? bm : ~bm;
     }
@@ -93,7 +93,7 @@ int radix_sort_pairs(const RadixCtl* ctl, uint64_t* keysA, uint64_t* keysB, uint
   for (int p = 0; p < max_passes; ++p) {
     hipLaunchKernelGGL(k_rx_hist, dim3(ntiles), dim3(RX_T), 0, st, ctl, keysA, keysB, p, hist, ntiles);
     // scanning stale histograms on skipped passes is harmless (the scatter exits first)
-    int rc = exclusive_scan_i32(hist, hist, static_cast<int64_t>(ntiles) * 256, nullptr, scan_ws, st);
+    int rc = exclusive_scan_i32(hist, hist, static_cast<int64_t>(ntiles) * RX_D, nullptr, scan_ws, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_rx_scatter, dim3(ntiles), dim3(RX_T), 0, st, ctl, keysA, keysB, valsA, valsB, p, hist, ntiles);
   }

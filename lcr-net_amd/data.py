@@ -9,6 +9,7 @@ Two entry points:
     shared by the 10 searches (7 if the decoder-only upsampling lists are skipped), int32 indices, ONE host sync at the end.
 """
 import ctypes
+import threading
 
 import torch
 
@@ -56,14 +57,68 @@ class PrecomputeLayout(ctypes.Structure):
                 ("out_bytes", ctypes.c_size_t), ("ws_bytes", ctypes.c_size_t)]
 
 
-def precompute_batch_native(points, lengths, num_stages, voxel_size, radius, neighbor_limits, upsampling=True, key_bits_hint=32,
-                            raw_voxel=None, capacity=None):
-    """precompute_batch as ONE native call (csrc/precompute.hip): same dictionary, int32 indices.  The ~250 launches and the
-    length read-back are issued by C++ (fork-join over side streams) with the interpreter lock released throughout.
+class PrecomputedArena:
+    """Result of one native pre-processing call before any tensor view exists: the output arena, its layout and the host copy
+    of the per-stage lengths.  `views()` builds the data dictionary.  The split lets a producer thread hand the arena over
+    with almost no interpreter work (the ~25 tensor views cost more host time than issuing the 140 launches)."""
+    __slots__ = ("out", "lay", "lengths_host", "points", "lengths", "raw", "upsampling", "B", "S")
 
-    raw_voxel: `points` are RAW scans, voxelised at this size inside the same call (no extra host round trip); `capacity` is
-    the row capacity assumed for the voxelised stack (default: a quarter of the raw points; a too small guess is detected on
-    the device and the call is repeated with the safe bound)."""
+    def __init__(self, out, lay, lengths_host, points, lengths, raw, upsampling):
+        self.out, self.lay, self.lengths_host, self.points, self.lengths = out, lay, lengths_host, points, lengths
+        self.raw, self.upsampling, self.B, self.S = raw, upsampling, lay.B, lay.num_stages
+
+    def views(self):
+        out, lay, S, B = self.out, self.lay, self.S, self.B
+        tot = [sum(l) for l in self.lengths_host]
+
+        def view(off, rows, cols, dtype, esize):
+            return out[off:off + rows * cols * esize].view(dtype).view(rows, cols)
+
+        first = 0 if self.raw else 1
+        pts = ([] if self.raw else [self.points]) + [view(lay.off_points[i], tot[i], 3, torch.float32, 4) for i in range(first, S)]
+        lens = ([] if self.raw else [self.lengths]) + [out[lay.off_lengths[i]:lay.off_lengths[i] + 8 * B].view(torch.int64) for i in range(first, S)]
+        orders = [out[lay.off_order[i]:lay.off_order[i] + 4 * tot[i]].view(torch.int32) for i in range(S)]
+        neighbors = [view(lay.off_neighbors[i], tot[i], lay.limits[i], torch.int32, 4) for i in range(S)]
+        subsampling = [view(lay.off_subsampling[i], tot[i + 1], lay.limits[i], torch.int32, 4) for i in range(S - 1)]
+        upsamp = [view(lay.off_upsampling[i], tot[i], lay.limits[i + 1], torch.int32, 4) for i in range(S - 1)] if self.upsampling else []
+        return {"order": orders, "points": pts, "lengths": lens, "neighbors": neighbors, "subsampling": subsampling, "upsampling": upsamp,
+                "lengths_host": self.lengths_host, "segment_lengths": lens}
+
+
+_layout_cache = {}
+_ws_cache = threading.local()
+
+
+def _layout_for(n0, B, S, neighbor_limits, upsampling, n_raw):
+    key = (n0, B, S, tuple(int(x) for x in neighbor_limits), bool(upsampling), n_raw)
+    lay = _layout_cache.get(key)
+    if lay is None:
+        lay = PrecomputeLayout()
+        lim = (ctypes.c_int * S)(*key[3])
+        _lib.check(_lib.lib().lcr_precompute_layout(n0, B, S, ctypes.cast(lim, ctypes.c_void_p), int(bool(upsampling)), n_raw,
+                                                    ctypes.addressof(lay)), "lcr_precompute_layout")
+        if len(_layout_cache) > 64:
+            _layout_cache.clear()
+        _layout_cache[key] = lay
+    return lay
+
+
+def _workspace(nbytes, dev, stream):
+    """Scratch of the native call, reused by a (thread, stream): it is dead when the call returns (the call ends with a stream
+    synchronisation), so consecutive calls on the same stream can share it."""
+    cache = getattr(_ws_cache, "ws", None)
+    if cache is None:
+        cache = _ws_cache.ws = {}
+    key = (dev, stream.value)
+    ws = cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = cache[key] = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+    return ws
+
+
+def precompute_batch_arena(points, lengths, num_stages, voxel_size, radius, neighbor_limits, upsampling=True, key_bits_hint=32,
+                           raw_voxel=None, capacity=None):
+    """The native pre-processing call (csrc/precompute.hip) without the tensor views: returns a PrecomputedArena."""
     _lib.require_cuda(points, lengths)
     assert points.dtype == torch.float32 and points.is_contiguous() and lengths.dtype == torch.int64 and num_stages == len(neighbor_limits)
     dev = points.device
@@ -72,41 +127,38 @@ def precompute_batch_native(points, lengths, num_stages, voxel_size, radius, nei
     raw = raw_voxel is not None
     n_raw = points.shape[0] if raw else 0
     n0 = (int(capacity) if capacity else max(n_raw // 4, min(n_raw, 65536))) if raw else points.shape[0]
-    L = _lib.lib()
-    lay = PrecomputeLayout()
-    lim = (ctypes.c_int * S)(*[int(x) for x in neighbor_limits])
-    _lib.check(L.lcr_precompute_layout(n0, B, S, ctypes.cast(lim, ctypes.c_void_p), int(bool(upsampling)), n_raw, ctypes.addressof(lay)),
-               "lcr_precompute_layout")
+    lay = _layout_for(n0, B, S, neighbor_limits, upsampling, n_raw)
+    stream = _lib.stream_ptr(dev)
     out = torch.empty(max(lay.out_bytes, 256), dtype=torch.uint8, device=dev)
-    ws = torch.empty(max(lay.ws_bytes, 256), dtype=torch.uint8, device=dev)
+    ws = _workspace(lay.ws_bytes, dev, stream)
     lens_host = (ctypes.c_int64 * (S * B))()
     status = ctypes.c_uint32(0)
-    _lib.check(L.lcr_precompute_batch(_lib.ptr(points), _lib.ptr(lengths), ctypes.addressof(lay), float(voxel_size), float(radius),
-                                      float(raw_voxel) if raw else 0.0, int(key_bits_hint), _lib.ptr(out), out.numel(), _lib.ptr(ws), ws.numel(),
-                                      ctypes.addressof(lens_host), ctypes.addressof(status), _lib.stream_ptr(dev)), "lcr_precompute_batch")
+    _lib.check(_lib.lib().lcr_precompute_batch(_lib.ptr(points), _lib.ptr(lengths), ctypes.addressof(lay), float(voxel_size), float(radius),
+                                               float(raw_voxel) if raw else 0.0, int(key_bits_hint), _lib.ptr(out), out.numel(), _lib.ptr(ws),
+                                               ws.numel(), ctypes.addressof(lens_host), ctypes.addressof(status), stream),
+               "lcr_precompute_batch")
     st = status.value
     if st & STATUS_KEY_OVERFLOW and key_bits_hint:
-        return precompute_batch_native(points, lengths, num_stages, voxel_size, radius, neighbor_limits, upsampling, 0, raw_voxel, capacity)
+        return precompute_batch_arena(points, lengths, num_stages, voxel_size, radius, neighbor_limits, upsampling, 0, raw_voxel, capacity)
     if raw and st & STATUS_LEN_MISMATCH and n0 < n_raw:
-        return precompute_batch_native(points, lengths, num_stages, voxel_size, radius, neighbor_limits, upsampling, key_bits_hint,
-                                       raw_voxel, n_raw)            # the voxel count exceeded the guessed capacity
+        return precompute_batch_arena(points, lengths, num_stages, voxel_size, radius, neighbor_limits, upsampling, key_bits_hint,
+                                      raw_voxel, n_raw)             # the voxel count exceeded the guessed capacity
     if st:
         raise RuntimeError("precompute_batch: device status 0x%x" % st)
-    lengths_host = [[int(lens_host[i * B + b]) for b in range(B)] for i in range(S)]
-    tot = [sum(l) for l in lengths_host]
+    flat = list(lens_host)
+    return PrecomputedArena(out, lay, [flat[i * B:(i + 1) * B] for i in range(S)], points, lengths, raw, bool(upsampling))
 
-    def view(off, rows, cols, dtype, esize):
-        return out[off:off + rows * cols * esize].view(dtype).view(rows, cols)
 
-    first = 0 if raw else 1
-    pts = ([] if raw else [points]) + [view(lay.off_points[i], tot[i], 3, torch.float32, 4) for i in range(first, S)]
-    lens = ([] if raw else [lengths]) + [out[lay.off_lengths[i]:lay.off_lengths[i] + 8 * B].view(torch.int64) for i in range(first, S)]
-    orders = [out[lay.off_order[i]:lay.off_order[i] + 4 * tot[i]].view(torch.int32) for i in range(S)]
-    neighbors = [view(lay.off_neighbors[i], tot[i], lay.limits[i], torch.int32, 4) for i in range(S)]
-    subsampling = [view(lay.off_subsampling[i], tot[i + 1], lay.limits[i], torch.int32, 4) for i in range(S - 1)]
-    upsamp = [view(lay.off_upsampling[i], tot[i], lay.limits[i + 1], torch.int32, 4) for i in range(S - 1)] if upsampling else []
-    return {"order": orders, "points": pts, "lengths": lens, "neighbors": neighbors, "subsampling": subsampling, "upsampling": upsamp,
-            "lengths_host": lengths_host, "segment_lengths": lens}
+def precompute_batch_native(points, lengths, num_stages, voxel_size, radius, neighbor_limits, upsampling=True, key_bits_hint=32,
+                            raw_voxel=None, capacity=None):
+    """precompute_batch as ONE native call (csrc/precompute.hip): same dictionary, int32 indices.  The ~140 launches and the
+    length read-back are issued by C++ with the interpreter lock released throughout.
+
+    raw_voxel: `points` are RAW scans, voxelised at this size inside the same call (no extra host round trip); `capacity` is
+    the row capacity assumed for the voxelised stack (default: a quarter of the raw points; a too small guess is detected on
+    the device and the call is repeated with the safe bound)."""
+    return precompute_batch_arena(points, lengths, num_stages, voxel_size, radius, neighbor_limits, upsampling, key_bits_hint,
+                                  raw_voxel, capacity).views()
 
 
 def precompute_batch(points, lengths, num_stages, voxel_size, radius, neighbor_limits, upsampling=True,

@@ -11,7 +11,7 @@ import time
 
 import torch
 
-from .data import precompute_batch, precompute_batch_native, voxelize_raw_scans
+from .data import precompute_batch, precompute_batch_arena, voxelize_raw_scans
 
 
 class DescriptorPipeline:
@@ -31,6 +31,7 @@ class DescriptorPipeline:
         self.pre_stream = torch.cuda.Stream(dev, priority=prio) if overlap else None
         self.producer_thread, self.depth, self.pre_workers = producer_thread, depth, pre_workers
         self.stats = {"pre_wait_s": 0.0, "pre_busy_s": 0.0, "enc_wait_s": 0.0, "batches": 0}   # where the two host threads wait
+        self._ones_buf = None
         self.enc_streams = None      # set by enable_dual_encoder(): consecutive batches' encoders on alternating streams
 
     def enable_dual_encoder(self, n=2):
@@ -40,20 +41,33 @@ class DescriptorPipeline:
         return self
 
     # ---- stages -----------------------------------------------------------------------------------------------------
-    def preprocess(self, points, lengths):
-        """points f32[N,3] (stacked raw or voxelised scans), lengths i64[B] -> data dict (on the current stream)."""
+    def preprocess_arena(self, points, lengths):
+        """The device work of `preprocess` with (almost) no interpreter work: returns a PrecomputedArena (raw one-call mode) or
+        the finished dictionary (two-call / pre-voxelised modes).  `finish` turns either into the encoder's input."""
         if self.raw_voxel is not None and not os.environ.get("LCR_PRE_TWO_CALLS"):
             # raw scans -> everything, one native call and ONE host round trip (the voxelisation's own read-back is gone)
-            dd = precompute_batch_native(points.contiguous(), lengths.to(points.device), self.num_stages, self.voxel_size, self.radius,
-                                         self.limits, upsampling=self.upsampling, raw_voxel=self.raw_voxel)
-        else:
-            if self.raw_voxel is not None:
-                points, lengths, _ = voxelize_raw_scans(points, lengths, self.raw_voxel)
-            dd = precompute_batch(points.contiguous(), lengths, self.num_stages, self.voxel_size, self.radius, self.limits,
-                                  upsampling=self.upsampling)
-        dd["features"] = torch.ones(dd["points"][0].shape[0], 1, device=points.device)
+            return precompute_batch_arena(points.contiguous(), lengths.to(points.device), self.num_stages, self.voxel_size, self.radius,
+                                          self.limits, upsampling=self.upsampling, raw_voxel=self.raw_voxel)
+        if self.raw_voxel is not None:
+            points, lengths, _ = voxelize_raw_scans(points, lengths, self.raw_voxel)
+        return precompute_batch(points.contiguous(), lengths, self.num_stages, self.voxel_size, self.radius, self.limits,
+                                upsampling=self.upsampling)
+
+    def _ones(self, n):
+        if self._ones_buf is None or self._ones_buf.shape[0] < n:
+            self._ones_buf = torch.ones(max(n, 1 << 18), 1, device=self.device)
+            torch.cuda.current_stream(self.device).synchronize()      # rare: read from other streams afterwards
+        return self._ones_buf[:n]
+
+    def finish(self, arena):
+        dd = arena if isinstance(arena, dict) else arena.views()
+        dd["features"] = self._ones(dd["points"][0].shape[0])
         dd["lengths_c_host"] = dd["lengths_host"][-1]
         return dd
+
+    def preprocess(self, points, lengths):
+        """points f32[N,3] (stacked raw or voxelised scans), lengths i64[B] -> data dict (on the current stream)."""
+        return self.finish(self.preprocess_arena(points, lengths))
 
     def encode(self, dd):
         with torch.no_grad():
@@ -131,7 +145,7 @@ class DescriptorPipeline:
                             slots.release()
                             break
                         k, (pts, lens) = nxt
-                        dd = self.preprocess(pts, lens)
+                        dd = self.preprocess_arena(pts, lens)
                         self.stats["pre_wait_s"] += t1 - t0           # blocked: the encoder side is behind
                         self.stats["pre_busy_s"] += time.perf_counter() - t1
                         self.stats["batches"] += 1
@@ -162,13 +176,17 @@ class DescriptorPipeline:
                     ready[item[0]] = item[1:]
             if k not in ready:
                 break
-            dd, ev = ready.pop(k)
+            arena, ev = ready.pop(k)
             slots.release()
             es = main if self.enc_streams is None else self.enc_streams[k % len(self.enc_streams)]
-            for v in dd.values():
-                for t in (v if isinstance(v, (list, tuple)) else [v]):
-                    if torch.is_tensor(t) and t.is_cuda:
-                        t.record_stream(es)
+            if isinstance(arena, dict):
+                for v in arena.values():
+                    for t in (v if isinstance(v, (list, tuple)) else [v]):
+                        if torch.is_tensor(t) and t.is_cuda:
+                            t.record_stream(es)
+            else:
+                arena.out.record_stream(es)                 # every view shares this one allocation
+            dd = self.finish(arena)                         # tensor views are built here, off the pre-processing thread
             es.wait_event(ev)
             if self.enc_streams is None:
                 yield self.encode(dd)
