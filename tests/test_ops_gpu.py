@@ -179,3 +179,68 @@ def test_sixty_four_clouds_and_the_limit_beyond():
     assert np.array_equal(got.cpu().numpy(), want)
     with pytest.raises(RuntimeError):
         grid_subsample(dev(xyz), dev(np.concatenate([lens, [0]])), 1.0)        # 65 clouds
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_output_order_at_every_rehash_boundary(seed):
+    """Clouds whose voxel counts sit on, just below and just above the bucket counts of libstdc++'s rehash schedule (13, 29,
+    ..., 2357 | 5087, 10273): the first eight replay phases run in LDS, the later ones in global memory, and the clouds of one
+    call cross the hand-over at different phases.  Bit-exact points, order included, against std::unordered_map (the oracle)."""
+    from lcrnet_amd.modules.ops import grid_subsample
+    rng = np.random.default_rng(100 + seed)
+    sizes = [1, 12, 13, 14, 29, 30, 58, 59, 60, 127, 128, 257, 541, 542, 1109, 1110, 2356, 2357, 2358, 5086, 5087, 5088, 10273, 10274]
+    pick = list(rng.permutation(sizes)[:12]) + [2357, 2358, 5088][seed % 3:seed % 3 + 1]
+    clouds = []
+    for n_vox in pick:
+        # n_vox distinct voxels of a 64^3 lattice, 1-3 points each, in random order (so insertion order != key order)
+        cells = rng.choice(64 ** 3, size=int(n_vox), replace=False)
+        ijk = np.stack([cells % 64, (cells // 64) % 64, cells // 4096], 1).astype(np.float32)
+        reps = rng.integers(1, 4, size=int(n_vox))
+        base = np.repeat(ijk, reps, axis=0)
+        pts = (base + rng.random(base.shape).astype(np.float32) * 0.9 + 0.05) * np.float32(0.5) + rng.normal(0, 20, 3).astype(np.float32)
+        clouds.append(pts[rng.permutation(len(pts))].astype(np.float32))
+    xyz = np.concatenate(clouds)
+    lens = np.array([len(c) for c in clouds], dtype=np.int64)
+    want, wl = oracle_ops.grid_subsample(xyz, lens, 0.5)
+    got, gl = grid_subsample(dev(xyz), dev(lens), 0.5)
+    assert np.array_equal(gl.cpu().numpy(), wl)
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_clouds_subsample_and_search(seed):
+    """Randomised shapes the fixed fixtures do not have: duplicates, points exactly on voxel faces, a plane, a line, tight
+    clusters, far-apart clouds in one stack; subsample and both kinds of search bit-exact against the oracle."""
+    from lcrnet_amd.modules.ops import grid_subsample, radius_search
+    rng = np.random.default_rng(500 + seed)
+    clouds = []
+    for _ in range(int(rng.integers(2, 7))):
+        n = int(rng.integers(1, 4000))
+        kind = int(rng.integers(0, 6))
+        if kind == 0:
+            p = rng.random((n, 3)) * rng.uniform(1, 60, 3)
+        elif kind == 1:
+            p = np.round(rng.random((n, 3)) * 40) * 0.25                     # lattice: duplicates and points on voxel faces
+        elif kind == 2:
+            p = np.concatenate([rng.random((n, 2)) * 50, np.zeros((n, 1))], 1)   # plane
+        elif kind == 3:
+            p = np.outer(rng.random(n) * 80, rng.standard_normal(3))             # line
+        elif kind == 4:
+            p = rng.standard_normal((n, 3)) * 0.3 + rng.integers(0, 5, (n, 1)) * 7.0   # tight clusters
+        else:
+            p = rng.standard_normal((n, 3)) * 15
+        clouds.append((p + rng.normal(0, 200, 3)).astype(np.float32))
+    xyz = np.concatenate(clouds)
+    lens = np.array([len(c) for c in clouds], dtype=np.int64)
+    voxel = float(rng.choice([0.25, 0.5, 0.77, 1.3]))
+    want_p, want_l = oracle_ops.grid_subsample(xyz, lens, voxel)
+    got_p, got_l = grid_subsample(dev(xyz), dev(lens), voxel)
+    assert np.array_equal(got_l.cpu().numpy(), want_l)
+    assert np.array_equal(got_p.cpu().numpy().view(np.uint32), want_p.view(np.uint32))
+    radius, limit = voxel * 4.25, int(rng.integers(8, 70))
+    want = oracle_ops.radius_search(want_p, xyz, want_l, lens, radius, limit)               # coarse queries, fine supports
+    got = radius_search(got_p.contiguous(), dev(xyz), got_l, dev(lens), radius, limit)
+    assert np.array_equal(got.cpu().numpy(), want)
+    want = oracle_ops.radius_search(want_p, want_p, want_l, want_l, radius, limit)          # self search
+    got = radius_search(got_p.contiguous(), got_p.contiguous(), got_l, got_l, radius, limit)
+    assert np.array_equal(got.cpu().numpy(), want)
