@@ -156,7 +156,11 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate_vec(const fl
 }
 
 // encoder1_1: scalar input feature per point; out[m][o] = (sum_k (sum_h w[k][h] f[h]) W[k][o]) / count + bias[o]
-template <typename IdxT>
+// One wavefront per query, lanes = neighbours.  A query is three DEPENDENT memory round trips (order -> point + index row ->
+// neighbour coordinates) and ~250 instructions, so the kernel is latency-bound: the header of query t+2 and the neighbour
+// gathers of query t+1 are in flight while query t is computed (clamped, unconditional loads: one basic block per trip), and
+// the register budget (MAXO output channels per lane) is sized by the launch so that 8 wavefronts per SIMD stay resident.
+template <typename IdxT, int MAXO>
 __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_cin1(const float* __restrict__ s_feats, const float* __restrict__ q_pts,
                                                                const float* __restrict__ s_pts, const IdxT* __restrict__ idx, int64_t M,
                                                                int64_t Ns, int H, KPoints kp, float sigma, const float* __restrict__ W,
@@ -165,7 +169,6 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_cin1(const float* __re
   __shared__ float s_a[KP_WAVES][16];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
   // this lane's output channel(s): the (15, Cout) weights and the bias stay in registers for every query of the wavefront
-  constexpr int MAXO = 4;                       // Cout <= 256
   float wreg[MAXO][KP_K], breg[MAXO];
 #pragma unroll
   for (int q = 0; q < MAXO; ++q) {
@@ -174,25 +177,62 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_cin1(const float* __re
 #pragma unroll
     for (int k = 0; k < KP_K; ++k) wreg[q][k] = o < Cout ? W[k * Cout + o] : 0.f;
   }
-  for (int64_t t = static_cast<int64_t>(blockIdx.x) * KP_WAVES + w; t < M; t += static_cast<int64_t>(gridDim.x) * KP_WAVES) {
-    const int64_t m = order ? order[t] : t;
-    const float qx = q_pts[3 * m], qy = q_pts[3 * m + 1], qz = q_pts[3 * m + 2];
-    const float inv_sigma = 1.f / sigma;
+  const float inv_sigma = 1.f / sigma;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * KP_WAVES;
+  int64_t t = static_cast<int64_t>(blockIdx.x) * KP_WAVES + w;
+  if (t >= M) return;                                   // wavefront-level synchronisation only below
+  struct Row {
+    int64_t m, j;
+    float   qx, qy, qz;
+  };
+  struct Nb {
+    float f, x, y, z;
+  };
+  auto load_row = [&](int64_t tt, Row& r) {
+    const int64_t tc = tt < M ? tt : M - 1;             // beyond the end: a valid row whose values are never used
+    r.m = order ? order[tc] : tc;
+    r.qx = q_pts[3 * r.m];
+    r.qy = q_pts[3 * r.m + 1];
+    r.qz = q_pts[3 * r.m + 2];
+    r.j = lane < H ? static_cast<int64_t>(idx[r.m * H + lane]) : Ns;
+  };
+  auto gather = [&](const Row& r, Nb& nb) {
+    const int64_t jc = (r.j >= 0 && r.j < Ns) ? r.j : 0;
+    nb.f = nb.x = nb.y = nb.z = 0.f;
+    if (Ns > 0) {                                       // uniform
+      nb.f = s_feats[jc];
+      nb.x = s_pts[3 * jc];
+      nb.y = s_pts[3 * jc + 1];
+      nb.z = s_pts[3 * jc + 2];
+    }
+  };
+  Row r0, r1;
+  Nb n0, n1;
+  load_row(t, r0);
+  gather(r0, n0);
+  load_row(t + stride, r1);
+  for (; t < M; t += stride) {
+    Row r2;
+    gather(r1, n1);
+    load_row(t + 2 * stride, r2);
+    const int64_t m = r0.m;
+    const float qx = r0.qx, qy = r0.qy, qz = r0.qz;
     float a[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) a[k] = 0.f;
-    for (int h = lane; h < H; h += 64) {
-      const int64_t j = static_cast<int64_t>(idx[m * H + h]);
-      if (j >= 0 && j < Ns) {
-        const float f = s_feats[j];
-        a[15] += f > 0.f ? 1.f : 0.f;            // neighbour count rides along as the 16th value (exact: small integers)
-        const float dx = s_pts[3 * j + 0] - qx, dy = s_pts[3 * j + 1] - qy, dz = s_pts[3 * j + 2] - qz;
+    auto add = [&](float f, float px, float py, float pz) {
+      a[15] += f > 0.f ? 1.f : 0.f;              // neighbour count rides along as the 16th value (exact: small integers)
+      const float dx = px - qx, dy = py - qy, dz = pz - qz;
 #pragma unroll
-        for (int k = 0; k < KP_K; ++k) {
-          const float ex = dx - kp.p[k][0], ey = dy - kp.p[k][1], ez = dz - kp.p[k][2];
-          a[k] = fmaf(fmaxf(1.f - __builtin_amdgcn_sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * inv_sigma, 0.f), f, a[k]);
-        }
+      for (int k = 0; k < KP_K; ++k) {
+        const float ex = dx - kp.p[k][0], ey = dy - kp.p[k][1], ez = dz - kp.p[k][2];
+        a[k] = fmaf(fmaxf(1.f - __builtin_amdgcn_sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * inv_sigma, 0.f), f, a[k]);
       }
+    };
+    if (r0.j >= 0 && r0.j < Ns) add(n0.f, n0.x, n0.y, n0.z);
+    for (int h = lane + 64; h < H; h += 64) {      // neighbour columns beyond 64: not prefetched
+      const int64_t j = static_cast<int64_t>(idx[m * H + h]);
+      if (j >= 0 && j < Ns) add(s_feats[j], s_pts[3 * j], s_pts[3 * j + 1], s_pts[3 * j + 2]);
     }
     // reduce-scatter of the 16 per-lane partials over the wavefront: each exchange halves the values a lane is responsible
     // for (8 + 4 + 2 + 1 exchanges, then two plain ones) instead of 16 full six-step reductions.  Lane l ends with the total
@@ -230,6 +270,9 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_cin1(const float* __re
       }
     }
     wave_lds_sync();
+    r0 = r1;
+    n0 = n1;
+    r1 = r2;
   }
 }
 
@@ -372,10 +415,16 @@ extern "C" int lcr_kpconv_cin1(const float* s_feats, const float* q_pts, const f
   const KPoints kp = load_kp(kernel_points_host);
   hipStream_t st = static_cast<hipStream_t>(stream);
   dim3 grid(grid_for(M, KP_WAVES)), block(KP_WAVES * 64);
-  if (idx_is_64)
-    hipLaunchKernelGGL((k_kpconv_cin1<int64_t>), grid, block, 0, st, s_feats, q_pts, s_pts, static_cast<const int64_t*>(idx), M, Ns, H, kp, sigma, W, bias, Cout, out, order);
-  else
-    hipLaunchKernelGGL((k_kpconv_cin1<int32_t>), grid, block, 0, st, s_feats, q_pts, s_pts, static_cast<const int32_t*>(idx), M, Ns, H, kp, sigma, W, bias, Cout, out, order);
+#define LCR_CIN1(IDX, MAXO) \
+  hipLaunchKernelGGL((k_kpconv_cin1<IDX, MAXO>), grid, block, 0, st, s_feats, q_pts, s_pts, static_cast<const IDX*>(idx), M, Ns, H, kp, sigma, W, bias, Cout, out, order)
+  if (idx_is_64) {
+    if (Cout <= 64) LCR_CIN1(int64_t, 1);
+    else LCR_CIN1(int64_t, 4);
+  } else {
+    if (Cout <= 64) LCR_CIN1(int32_t, 1);
+    else LCR_CIN1(int32_t, 4);
+  }
+#undef LCR_CIN1
   return check_launch("lcr_kpconv_cin1");
 }
 
