@@ -208,3 +208,90 @@ class DescriptorPipeline:
             yield pending[0]
         for th in threads:
             th.join()
+
+
+class PairPipeline:
+    """Registration pairs (BASELINE config 5, reference loop: experiments/inference/infer_registration.py) through the full pair
+    model, `workers` pairs in flight: one host thread + one HIP stream per worker, results handed back in input order.
+
+    One pair is ~1000 short, dependent launches and four host round trips (NMS sizes, match counts, ...), i.e. bound by the host
+    and by launch latency, not by the GPU; a second pair in flight fills the gaps (78 -> 108 pairs/s on the demo pair).  More than
+    two workers lose to interpreter-lock contention (59 pairs/s with three)."""
+
+    def __init__(self, model, voxel_size=0.3, radius=1.275, num_stages=4, neighbor_limits=(74, 68, 70, 67), workers=2):
+        self.model, self.workers = model, max(1, int(workers))
+        self.voxel_size, self.radius, self.num_stages, self.limits = voxel_size, radius, num_stages, list(neighbor_limits)
+        self.device = next(model.parameters()).device
+
+    def one(self, points, lengths):
+        """points f32[N,3] = the two clouds of a pair stacked (already voxelised), lengths i64[2] -> the model's output dict."""
+        dd = precompute_batch(points.contiguous(), lengths, self.num_stages, self.voxel_size, self.radius, self.limits, upsampling=True)
+        del dd["segment_lengths"]            # pair semantics of the reference: GroupNorm statistics over BOTH clouds
+        dd["features"] = torch.ones(points.shape[0], 1, device=points.device)
+        dd["lengths_c_host"] = dd["lengths_host"][-1]
+        with torch.no_grad():
+            return self.model(dd)
+
+    def run(self, pairs):
+        """pairs: iterable of (points, lengths) device tensors.  Yields one output dict per pair, in order, valid on the caller's
+        current stream."""
+        import queue
+        import threading
+        if self.workers == 1:
+            for pts, lens in pairs:
+                yield self.one(pts, lens)
+            return
+        dev = self.device
+        main = torch.cuda.current_stream(dev)
+        it = enumerate(iter(pairs))
+        it_lock = threading.Lock()
+        out = queue.Queue()
+        slots = threading.Semaphore(2 * self.workers)       # finished pairs not yet consumed
+
+        def worker():
+            try:
+                torch.cuda.set_device(dev)
+                st = torch.cuda.Stream(dev)
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    while True:
+                        slots.acquire()
+                        with it_lock:
+                            nxt = next(it, None)
+                        if nxt is None:
+                            slots.release()
+                            break
+                        k, (pts, lens) = nxt
+                        res = self.one(pts, lens)
+                        ev = torch.cuda.Event()
+                        ev.record(st)
+                        out.put((k, res, ev))
+                out.put(None)
+            except BaseException as e:
+                out.put(e)
+
+        threads = [threading.Thread(target=worker, daemon=True) for _ in range(self.workers)]
+        for th in threads:
+            th.start()
+        ready, finished, k = {}, 0, 0
+        while True:
+            while k not in ready and finished < self.workers:
+                item = out.get()
+                if item is None:
+                    finished += 1
+                elif isinstance(item, BaseException):
+                    raise item
+                else:
+                    ready[item[0]] = item[1:]
+            if k not in ready:
+                break
+            res, ev = ready.pop(k)
+            slots.release()
+            main.wait_event(ev)
+            for v in res.values():
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(main)
+            yield res
+            k += 1
+        for th in threads:
+            th.join()

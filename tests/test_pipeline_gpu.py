@@ -102,3 +102,33 @@ def test_raw_scan_mode_of_the_native_precompute():
             assert len(a[key]) == len(b[key])
             for x, y in zip(a[key], b[key]):
                 assert x.shape == y.shape and torch.equal(x, y), key
+
+
+def test_pair_pipeline_two_in_flight_equals_sequential():
+    """Registration pairs with two pairs in flight (two host threads / streams): same outputs, same order, as one at a time."""
+    import os
+    from conftest import load_scan
+    from lcrnet_amd.config import make_cfg
+    from lcrnet_amd.model_family import LCRNet
+    from lcrnet_amd.pipeline import PairPipeline
+    from lcrnet_amd.weights import seeded_state_dict
+    dev = torch.device("cuda", 0)
+    cfg = make_cfg()
+    cfg["neighbor_limits"] = [74, 68, 70, 67]
+    m = LCRNet(cfg).eval()
+    m.load_state_dict(seeded_state_dict(m.state_dict(), 7351))
+    m = m.to(dev)
+    a, b = load_scan("003854"), load_scan("000958")
+    stacks = []
+    for k in range(5):                       # five different pairs: the demo pair, swapped, and cropped variants
+        x, y = (a, b) if k % 2 == 0 else (b, a)
+        x, y = x[: len(x) - 700 * k], y[: len(y) - 500 * k]
+        stacks.append((torch.from_numpy(np.concatenate([x, y])).to(dev), torch.tensor([len(x), len(y)], dtype=torch.int64, device=dev)))
+    seq = list(PairPipeline(m, workers=1).run(stacks))
+    par = list(PairPipeline(m, workers=2).run(stacks))
+    torch.cuda.synchronize()
+    assert len(seq) == len(par) == 5
+    for s, p in zip(seq, par):
+        assert s["length"].tolist() == p["length"].tolist()
+        assert torch.equal(s["pos_node_corr_indices"], p["pos_node_corr_indices"])
+        assert torch.allclose(s["estimated_transform"], p["estimated_transform"], atol=1e-5)

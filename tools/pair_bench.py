@@ -18,7 +18,7 @@ def main():
     from lcrnet_amd.weights import seeded_state_dict
     import lcrnet_amd.synthetic as synthetic
     from lcrnet_amd.data import voxelize_raw_scans
-    dev = torch.device("cuda")
+    dev = torch.device("cuda", 0)
     limits = [74, 68, 70, 67]
     cfg = make_cfg()
     cfg["neighbor_limits"] = limits
@@ -50,6 +50,17 @@ def main():
         out = one()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
+    from lcrnet_amd.pipeline import PairPipeline
+    pp = PairPipeline(m, neighbor_limits=limits, workers=2)
+    list(pp.run([(pts, lens)] * 4))
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    n2 = 40
+    for _ in pp.run([(pts, lens)] * n2):
+        pass
+    torch.cuda.synchronize()
+    dt2 = (time.perf_counter() - t1) / n2
+    print(f"PairPipeline, 2 pairs in flight: {dt2*1e3:.2f} ms/pair = {1/dt2:.1f} pairs/s")
     print(f"pair model end to end: {dt*1e3:.2f} ms/pair = {1/dt:.1f} pairs/s; nodes {out['length'].tolist()}, "
           f"node corr {out['pos_node_corr_indices'].shape[0]}, point corr {out['corr_scores'].shape[0]}")
     print("estimated_transform\n", out["estimated_transform"].cpu().numpy())
