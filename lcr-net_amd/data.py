@@ -11,6 +11,7 @@ Two entry points:
 import ctypes
 import threading
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -209,6 +210,59 @@ def precompute_batch(points, lengths, num_stages, voxel_size, radius, neighbor_l
     orders = [orders[i][:tot[i]] for i in range(num_stages)]
     return {"order": orders, "points": pts, "lengths": lens, "neighbors": neighbors, "subsampling": subsampling, "upsampling": upsamp,
             "lengths_host": lengths_host, "segment_lengths": lens}
+
+
+def _merge_samples(data_dicts):
+    """Lists of per-sample values keyed like the samples (numpy arrays become tensors)."""
+    merged = {}
+    for sample in data_dicts:
+        for key, value in sample.items():
+            merged.setdefault(key, []).append(torch.from_numpy(value) if isinstance(value, np.ndarray) else value)
+    return merged
+
+
+def _finish_collate(merged, feats, points_list, batch_size, num_stages, voxel_size, search_radius, neighbor_limits, precompute_data, device):
+    lengths = torch.tensor([int(p.shape[0]) for p in points_list], dtype=torch.int64)
+    points = torch.cat(points_list, dim=0)
+    if batch_size == 1:                                   # the reference unwraps single-sample batches
+        merged = {k: v[0] for k, v in merged.items()}
+    merged["features"] = feats
+    if precompute_data:
+        dev = torch.device(device)
+        merged["features"] = feats.to(dev)
+        merged.update(precompute_data_stack_mode(points.to(dev, torch.float32).contiguous(), lengths.to(dev), num_stages, voxel_size,
+                                                 search_radius, neighbor_limits))
+    else:
+        merged["points"], merged["lengths"] = points, lengths
+    merged["batch_size"] = batch_size
+    return merged
+
+
+def registration_collate_fn_stack_mode(data_dicts, num_stages, voxel_size, search_radius, neighbor_limits, precompute_data=True,
+                                       device="cuda"):
+    """Pair collate of experiments/lcrnet/data.py:77-127: clouds stacked [ref_1..ref_B, src_1..src_B], features concatenated
+    the same way, every other key a per-sample list (unwrapped for B = 1), `batch_size` added.  With precompute_data the five
+    lists of precompute_data_stack_mode are computed on `device` (the reference does it in DataLoader workers on the CPU) and
+    `features` is moved there; without it `points` / `lengths` stay on the host like the reference's."""
+    merged = _merge_samples(data_dicts)
+    feats = torch.cat(merged.pop("ref_feats") + merged.pop("src_feats"), dim=0)
+    points_list = merged.pop("ref_points") + merged.pop("src_points")
+    return _finish_collate(merged, feats, points_list, len(data_dicts), num_stages, voxel_size, search_radius, neighbor_limits,
+                           precompute_data, device)
+
+
+def test_loop_detection_collate_fn_stack_mode_online(data_dicts, num_stages, voxel_size, search_radius, neighbor_limits,
+                                                     precompute_data=True, device="cuda"):
+    """Single-scan collate of data.py:350-406 (loop-detection inference): `anc_points` of every sample stacked, `features` =
+    the FIRST sample's `anc_feats` (as the reference does — it is only ever used with batch size 1)."""
+    merged = _merge_samples(data_dicts)
+    feats = merged.pop("anc_feats")[0]
+    points_list = merged.pop("anc_points")
+    return _finish_collate(merged, feats, points_list, len(data_dicts), num_stages, voxel_size, search_radius, neighbor_limits,
+                           precompute_data, device)
+
+
+test_loop_detection_collate_fn_stack_mode_online.__test__ = False     # a collate of the reference's name, not a pytest case
 
 
 def voxelize_raw_scans(points, lengths, voxel_size, key_bits_hint=32):

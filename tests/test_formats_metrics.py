@@ -47,3 +47,25 @@ def test_lcr_output_line():
     parts = line.split()
     assert parts[0] == "3854" and parts[1] == "958" and parts[2] == "16.00" and len(parts) == 15
     assert parts[3] == "1.000000" and parts[6] == "1.500000"
+
+
+def test_collates_mirror_the_reference_layout_without_precompute():
+    """registration / loop-detection collates (data.py:77-127, :350-406): stacking order, features, unwrapping, batch_size."""
+    import torch
+    from lcrnet_amd.data import registration_collate_fn_stack_mode, test_loop_detection_collate_fn_stack_mode_online
+    rng = np.random.default_rng(0)
+    def sample(nr, ns, tag):
+        return {"ref_points": rng.random((nr, 3)).astype(np.float32), "src_points": rng.random((ns, 3)).astype(np.float32),
+                "ref_feats": np.ones((nr, 1), np.float32), "src_feats": np.full((ns, 1), 2, np.float32),
+                "transform": np.eye(4, dtype=np.float32) * tag, "seq_id": tag}
+    s0, s1 = sample(5, 7, 1), sample(3, 4, 2)
+    one = registration_collate_fn_stack_mode([s0], 4, 0.3, 1.275, [8, 8, 8, 8], precompute_data=False)
+    assert one["batch_size"] == 1 and one["lengths"].tolist() == [5, 7] and one["points"].shape == (12, 3)
+    assert torch.equal(one["points"][:5], torch.from_numpy(s0["ref_points"])) and one["features"].flatten().tolist() == [1.0] * 5 + [2.0] * 7
+    assert one["seq_id"] == 1 and one["transform"].shape == (4, 4)                 # unwrapped for a single sample
+    two = registration_collate_fn_stack_mode([s0, s1], 4, 0.3, 1.275, [8, 8, 8, 8], precompute_data=False)
+    assert two["lengths"].tolist() == [5, 3, 7, 4]                                  # [ref_1, ref_2, src_1, src_2]
+    assert two["features"].flatten().tolist() == [1.0] * 8 + [2.0] * 11 and two["seq_id"] == [1, 2] and two["batch_size"] == 2
+    a = {"anc_points": rng.random((6, 3)).astype(np.float32), "anc_feats": np.ones((6, 1), np.float32), "frame": 17}
+    got = test_loop_detection_collate_fn_stack_mode_online([a], 4, 0.3, 1.275, [8, 8, 8, 8], precompute_data=False)
+    assert got["lengths"].tolist() == [6] and got["features"].shape == (6, 1) and got["frame"] == 17 and got["batch_size"] == 1

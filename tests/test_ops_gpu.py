@@ -244,3 +244,20 @@ def test_random_clouds_subsample_and_search(seed):
     want = oracle_ops.radius_search(want_p, want_p, want_l, want_l, radius, limit)          # self search
     got = radius_search(got_p.contiguous(), got_p.contiguous(), got_l, got_l, radius, limit)
     assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_registration_collate_precomputes_the_pair_stack(ops_golden):
+    """The pair collate with precompute_data=True: the reference's dictionary for the demo pair, computed on the device."""
+    from lcrnet_amd.data import registration_collate_fn_stack_mode
+    a, b = load_scan("003854"), load_scan("000958")
+    sample = {"ref_points": a, "src_points": b, "ref_feats": np.ones((len(a), 1), np.float32), "src_feats": np.ones((len(b), 1), np.float32),
+              "transform": np.eye(4, dtype=np.float32)}
+    dd = registration_collate_fn_stack_mode([sample], NUM_STAGES, VOXEL, RADIUS, LIMITS)
+    assert dd["batch_size"] == 1 and dd["features"].is_cuda and dd["features"].shape == (len(a) + len(b), 1)
+    assert [len(dd[k]) for k in ("points", "lengths", "neighbors", "subsampling", "upsampling")] == [4, 4, 4, 3, 3]
+    assert sha(dd["points"][1].cpu().numpy()) == str(ops_golden["pair_003854_000958/points1_sha"])
+    assert sha(dd["neighbors"][0].cpu().numpy()) == str(ops_golden["pair_003854_000958/neighbors0_sha_canon"])
+    want = oracle_ops.precompute_data_stack_mode(np.concatenate([a, b]), np.array([len(a), len(b)]), NUM_STAGES, VOXEL, RADIUS, LIMITS)
+    for key in ("points", "lengths", "neighbors", "subsampling", "upsampling"):
+        for got_t, want_t in zip(dd[key], want[key]):
+            assert np.array_equal(got_t.cpu().numpy(), want_t), key
