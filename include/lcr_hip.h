@@ -142,6 +142,12 @@ int lcr_gemm_f32(const float* A, const float* B, float* C, int64_t M, int N, int
                  void* stream);
 /* Tuning hook for tools/gemm_bench.py: 0 = heuristic tile choice, 1..5 = force 128x128 / 128x64 / 128x32 / 64x64 / 64x128. */
 void lcr_gemm_debug_force_tile(int tile);
+/* K-deep problems (A [M,K] x B [K,N], K >= 480) whose 64x64 tiles do not divide evenly over the CUs can run as stream-K:
+ * persistent workgroups with equal contiguous (tile, K-step) ranges, partial tiles parked and folded — in ascending workgroup
+ * order, by whichever workgroup parks a tile's last piece — without anybody waiting.  Opt-in (+3..7 % on those shapes).
+ * Test / tuning hook: -1 = LCR_GEMM_STREAMK (default 0 = off, 1 = heuristic), 0 = never, 2 = whenever the kernel is applicable.
+ * The scratch (two 16-KB pieces per workgroup + one counter per tile) is library-owned, one per stream. */
+void lcr_gemm_debug_streamk(int mode);
 /* Batched C_z[M,N] = A_z^T · B_z with A_z stored [K_z, M] (per-entry K and element offsets, HOST arrays, count <= 64). */
 int lcr_gemm_f32_batched_ta(const float* A, const float* B, float* C, int64_t M, int N, int count, const int* k_host,
                             const int64_t* a_off_host, const int64_t* b_off_host, const int64_t* c_off_host, void* stream);

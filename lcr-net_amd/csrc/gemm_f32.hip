@@ -14,6 +14,8 @@
 // tile shape is chosen so that >= ~400 workgroups exist (two per CU) even for the short-M stages.
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -142,6 +144,126 @@ __device__ __forceinline__ int seg_of_row(const int64_t* __restrict__ seg_len, i
     end += seg_len[s];
   }
   return s;
+}
+
+// Epilogue shared by the tile-per-workgroup kernel and the stream-K kernel: C = acc [/ rowdiv] [+ bias], GroupNorm statistics.
+template <int BM, int BN, int WM, int WN, int NT>
+__device__ __forceinline__ void gemm_epilogue(floatx16 (&acc)[NT], float* __restrict__ C, int64_t M, int N, int64_t m0, int n0, int64_t m_tile,
+                                              const GemmEpilogue& ep, const float (&bias_v)[NT], int blk_first, int64_t blk_seg_start,
+                                              int64_t blk_seg_end, int wm, int wn, int lane) {
+  const bool want_stats = ep.stats != nullptr;
+  const int gs = want_stats ? N / ep.groups : 1;   // channels per group
+  const int64_t wrow0 = m0 + wm * 32;
+
+  // store (and keep the final values in the accumulators for the statistics pass)
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + wn * (32 * NT) + j * 32 + (lane & 31);
+    const float bv = bias_v[j];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      float v = acc[j][r];
+      if (row < M) {
+        if (ep.rowdiv) v = v / ep.rowdiv[row];
+        v += bv;
+        if (col < N) C[row * N + col] = v;
+      } else {
+        v = 0.f;
+      }
+      acc[j][r] = v;
+    }
+  }
+
+  // GroupNorm statistics.  Fast path (all BM rows of the workgroup in one segment — all but B-1 workgroups): every lane parks
+  // the fp32 sums of its 16 values per column in LDS, one thread per column folds the 2*WM row slices in fp64, the gs lanes of
+  // a group are folded with shuffles in the BN/64 wavefronts that hold the columns, and the workgroup issues one pair of
+  // global fp64 atomics per group into the statistics replica (row block % GN_REPLICAS).  (A version with fp64 shuffles in
+  // every wavefront + LDS fp64 atomics cost 8-9 us per unary GEMM.)  Slow path (a segment boundary inside the tile): per
+  // wavefront, per segment present in its 32 rows, straight to global memory.
+  if (want_stats) {
+    __shared__ float s_part[2][2 * WM][BN];
+    double* rep = ep.stats + static_cast<int64_t>(m_tile % GN_REPLICAS) * ep.S * ep.groups * 2;
+    int64_t seg_start = blk_seg_start, seg_end = blk_seg_end;
+    const int64_t blk_last_row = min(m0 + BM - 1, M - 1);
+    const bool uniform = blk_last_row < seg_end;      // block-uniform
+    if (uniform) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float s = 0.f, ss = 0.f;                      // rows beyond M hold zeros in the accumulators
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s += acc[j][r];
+          ss = fmaf(acc[j][r], acc[j][r], ss);
+        }
+        const int cl = wn * (32 * NT) + j * 32 + (lane & 31);
+        s_part[0][2 * wm + (lane >> 5)][cl] = s;
+        s_part[1][2 * wm + (lane >> 5)][cl] = ss;
+      }
+      __syncthreads();
+      if (threadIdx.x < BN) {
+        const int cl = threadIdx.x;
+        double ds = 0.0, dss = 0.0;
+#pragma unroll
+        for (int r = 0; r < 2 * WM; ++r) {
+          ds += static_cast<double>(s_part[0][r][cl]);
+          dss += static_cast<double>(s_part[1][r][cl]);
+        }
+        const int span = gs < 64 ? gs : 64;           // gs is a power of two; groups wider than 64 columns add per wavefront
+        for (int d = 1; d < span; d <<= 1) {
+          ds += __shfl_xor(ds, d);
+          dss += __shfl_xor(dss, d);
+        }
+        const int col = n0 + cl;
+        if ((cl & (span - 1)) == 0 && col < N) {
+          double* d = rep + (static_cast<int64_t>(blk_first) * ep.groups + col / gs) * 2;
+          atomicAdd(d, ds);
+          atomicAdd(d + 1, dss);
+        }
+      }
+    } else if (wrow0 < M) {
+      const int64_t wlast = min(wrow0 + 31, M - 1);
+      int sg = blk_first;
+      while (sg + 1 < ep.S && wrow0 >= seg_end) {
+        ++sg;
+        seg_start = seg_end;
+        seg_end += ep.seg_len[sg];
+      }
+      while (true) {   // wave-uniform loop over the segments that intersect [wrow0, wlast]
+        const bool whole = seg_start <= wrow0 && wlast < seg_end;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int col = n0 + wn * (32 * NT) + j * 32 + (lane & 31);
+          float s = 0.f, ss = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float v = (whole || (row >= seg_start && row < seg_end)) ? acc[j][r] : 0.f;
+            s += v;
+            ss = fmaf(v, v, ss);
+          }
+          double ds = s, dss = ss;
+          // fold the two row-halves, then the lanes of one group (gs consecutive columns, capped at the 32-column tile)
+          ds += __shfl_xor(ds, 32);
+          dss += __shfl_xor(dss, 32);
+          const int span = gs < 32 ? gs : 32;
+          for (int d = 1; d < span; d <<= 1) {
+            ds += __shfl_xor(ds, d);
+            dss += __shfl_xor(dss, d);
+          }
+          if (lane < 32 && (lane & (span - 1)) == 0 && col < N) {
+            double* d = rep + (static_cast<int64_t>(sg) * ep.groups + col / gs) * 2;
+            atomicAdd(d, ds);
+            atomicAdd(d + 1, dss);
+          }
+        }
+        if (wlast < seg_end || sg + 1 >= ep.S) break;
+        ++sg;
+        seg_start = seg_end;
+        seg_end += ep.seg_len[sg];
+      }
+    }
+  }
 }
 
 // SHORT = the light form for K <= 128 (the unary Linears of the big stages): such a problem is all prologue — load, one to four
@@ -349,118 +471,194 @@ __global__ __launch_bounds__(GM_T, SHORT ? 6 : 2) void k_gemm_f32(const float* _
       for (int r = 0; r < 16; ++r) acc[j][r] += acc2[j][r];
   }
 
-  // ---- epilogue -------------------------------------------------------------------------------------------------
-  const int gs = want_stats ? N / ep.groups : 1;   // channels per group
-  const int64_t wrow0 = m0 + wm * 32;
+  gemm_epilogue<BM, BN, WM, WN, NT>(acc, C, M, N, m0, n0, m_tile, ep, bias_v, blk_first, blk_seg_start, blk_seg_end, wm, wn, lane);
+}
 
-  // store (and keep the final values in the accumulators for the statistics pass)
+// ---- stream-K form of the K-deep contractions ---------------------------------------------------------------------------
+// With one tile per workgroup, 408 / 596 / 806 tiles of 64x64 on 256 CUs (<= 3 resident workgroups each) leave some CUs with one
+// tile more than others: the deepest KPConv contractions lose ~20 % to that quantisation.  Here the grid is a fixed number of
+// persistent workgroups (a multiple of the CU count) and every workgroup takes an equal, CONTIGUOUS range of (tile, K-step)
+// iterations, so it touches at most two partial tiles.  Nobody waits for anybody: a workgroup parks every partial tile it
+// computes (16 KB, device-coherent stores), then bumps the tile's arrival counter; the workgroup that arrives LAST folds all the
+// pieces of the tile in ascending workgroup order (its own included, read back like the others: the sum is the same whoever
+// folds), runs the epilogue and resets the counter for the next launch.  (Two earlier protocols with an owner waiting for the
+// others' flags: in range order the waits chain up — 20x slower; with the shared pieces computed first an owner still idles
+// whenever its neighbour's piece is the longer one — erratic, 0.8-1.4x.)  Tiles are dealt to the XCDs as in k_gemm_f32 (row
+// block % 8) and the iteration ranges are cut inside one XCD's band, so the column tiles of a row block stay on one L2.
+struct GemmStreamK {
+  float*    partial;   // [grid][2][NT * 16][GM_T]: slot 0 = the piece a workgroup's range starts with, slot 1 = any later piece
+  uint32_t* arrived;   // [tiles] pieces parked so far; zero between launches
+  int       U;         // workgroups per XCD band (grid = 8 * U)
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(GM_T, 3) void k_gemm_f32_sk(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                         int64_t M, int N, int K, GemmEpilogue ep, GemmStreamK sk) {
+  static_assert(WM * WN == 4 && BM == 32 * WM, "one 32-row MFMA tile per wavefront along M");
+  constexpr int LDA = BM + 1, LDB = BN + 4;
+  constexpr int NT = BN / (32 * WN);
+  __shared__ __attribute__((aligned(16))) float As[2][GM_BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][GM_BK * LDB];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = w / WN, wn = w % WN;
+  const int ntn = (N + BN - 1) / BN;
+  const int64_t mt = (M + BM - 1) / BM;
+  const int xcd = blockIdx.x & 7, u = blockIdx.x >> 3;
+  const int64_t mt_x = mt > xcd ? (mt - xcd + 7) / 8 : 0;          // row blocks of this XCD's band: m_tile = 8 * i + xcd
+  const int nk = (K + GM_BK - 1) / GM_BK;
+  const int64_t I = mt_x * ntn * nk;                                // iterations of the band
+  auto first_it = [&](int uu) { return static_cast<int64_t>(uu) * I / sk.U; };
+  const int64_t it_begin = first_it(u), it_end = first_it(u + 1);
+  LoaderT<BM, LDA, true> la[2];
+  LoaderN<BN, LDB, true> lb[2];
+  const int a_off = (lane >> 5) * LDA + wm * 32 + (lane & 31);
+  const int b_off = (lane >> 5) * LDB + wn * (32 * NT) + (lane & 31);
+  constexpr int PIECE = NT * 16 * GM_T;                             // floats of one parked partial tile
+  __shared__ unsigned s_arrived;
+
+  int64_t it = it_begin;
+  while (it < it_end) {
+    const int64_t lt = it / nk;
+    const int ks = static_cast<int>(it - lt * nk);
+    const int ns = static_cast<int>(min(static_cast<int64_t>(nk - ks), it_end - it));        // K-steps of this segment
+    const int64_t m_tile = (lt / ntn) * 8 + xcd;
+    const int64_t m0 = m_tile * BM;
+    const int n0 = static_cast<int>(lt % ntn) * BN;
+    const int k_begin = ks * GM_BK;
+    auto gload = [&](int k0, int r) {
+      la[r].load(A, M, K, m0, k0);
+      lb[r].load(B, N, K, n0, k0);
+    };
+    floatx16 acc[NT];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int col = n0 + wn * (32 * NT) + j * 32 + (lane & 31);
-    const float bv = bias_v[j];
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      float v = acc[j][r];
-      if (row < M) {
-        if (ep.rowdiv) v = v / ep.rowdiv[row];
-        v += bv;
-        if (col < N) C[row * N + col] = v;
-      } else {
-        v = 0.f;
-      }
-      acc[j][r] = v;
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    gload(k_begin, 0);
+    gload(k_begin + GM_BK, 1);
+    const bool covers_end = ks + ns == nk, covers_start = ks == 0;
+    float bias_v[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + wn * (32 * NT) + j * 32 + (lane & 31);
+      bias_v[j] = (ep.bias && col < N) ? ep.bias[col] : 0.f;
     }
-  }
+    int blk_first = 0;
+    int64_t blk_seg_start = 0, blk_seg_end = 0;
+    la[0].store(As[0]);
+    lb[0].store(Bs[0]);
+    __syncthreads();
 
-  // GroupNorm statistics.  Fast path (all BM rows of the workgroup in one segment — all but B-1 workgroups): every lane parks
-  // the fp32 sums of its 16 values per column in LDS, one thread per column folds the 2*WM row slices in fp64, the gs lanes of
-  // a group are folded with shuffles in the BN/64 wavefronts that hold the columns, and the workgroup issues one pair of
-  // global fp64 atomics per group into the statistics replica (row block % GN_REPLICAS).  (A version with fp64 shuffles in
-  // every wavefront + LDS fp64 atomics cost 8-9 us per unary GEMM.)  Slow path (a segment boundary inside the tile): per
-  // wavefront, per segment present in its 32 rows, straight to global memory.
-  if (want_stats) {
-    __shared__ float s_part[2][2 * WM][BN];
-    double* rep = ep.stats + static_cast<int64_t>(m_tile % GN_REPLICAS) * ep.S * ep.groups * 2;
-    int64_t seg_start = blk_seg_start, seg_end = blk_seg_end;
-    const int64_t blk_last_row = min(m0 + BM - 1, M - 1);
-    const bool uniform = blk_last_row < seg_end;      // block-uniform
-    if (uniform) {
+    // the K-step of k_gemm_f32 (see there): fragments PF K-pairs ahead, next tile's LDS stores between the MFMAs
+    constexpr int KK = GM_BK / 2;
+    constexpr int PF = NT == 1 ? KK : (NT == 2 ? 8 : 4);
+    constexpr int PA = BM * 8 / GM_T, PB = BN * 8 / GM_T;
+    constexpr int ST0 = KK - (PA + PB) - 1 > 2 ? (KK - (PA + PB)) / 2 : 1;
+    auto step = [&](auto buf_c, auto full_c, int t) {
+      constexpr int BUF = decltype(buf_c)::value;
+      constexpr bool FULL = decltype(full_c)::value;
+      if (FULL || t + 2 < ns) gload(k_begin + (t + 2) * GM_BK, BUF);
+      const bool do_store = FULL || t + 1 < ns;
+      const float* as = As[BUF] + a_off;
+      const float* bs = Bs[BUF] + b_off;
+      float af[PF], bf[PF][NT];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        float s = 0.f, ss = 0.f;                      // rows beyond M hold zeros in the accumulators
+      for (int d = 0; d < PF; ++d) {
+        af[d] = as[d * 2 * LDA];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          s += acc[j][r];
-          ss = fmaf(acc[j][r], acc[j][r], ss);
+        for (int j = 0; j < NT; ++j) bf[d][j] = bs[d * 2 * LDB + j * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        const int sl = kk % PF;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[sl], bf[sl][j], acc[j], 0, 0, 0);
+        if (kk + PF < KK) {
+          af[sl] = as[(kk + PF) * 2 * LDA];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) bf[sl][j] = bs[(kk + PF) * 2 * LDB + j * 32];
         }
-        const int cl = wn * (32 * NT) + j * 32 + (lane & 31);
-        s_part[0][2 * wm + (lane >> 5)][cl] = s;
-        s_part[1][2 * wm + (lane >> 5)][cl] = ss;
+        const int piece = kk - ST0;
+        if (do_store && piece >= 0 && piece < PA + PB) {
+          if (piece < PA) la[1 - BUF].store_piece(As[1 - BUF], piece);
+          else lb[1 - BUF].store_piece(Bs[1 - BUF], piece - PA);
+        }
       }
       __syncthreads();
-      if (threadIdx.x < BN) {
-        const int cl = threadIdx.x;
-        double ds = 0.0, dss = 0.0;
+    };
+    int t = 0;
+    for (; t + 3 < ns; t += 2) {
+      step(std::integral_constant<int, 0>{}, std::true_type{}, t);
+      step(std::integral_constant<int, 1>{}, std::true_type{}, t + 1);
+    }
+    for (; t < ns; t += 2) {
+      step(std::integral_constant<int, 0>{}, std::false_type{}, t);
+      if (t + 1 >= ns) break;
+      step(std::integral_constant<int, 1>{}, std::false_type{}, t + 1);
+    }
+
+    bool finish = true;
+    if (!(covers_start && covers_end)) {
+      // park this piece: device-coherent stores (a device-scope release FENCE per workgroup would write back the XCD's whole L2:
+      // measured 2x slower overall), then count it in once every lane's stores are acknowledged
+      float* mine = sk.partial + (static_cast<int64_t>(blockIdx.x) * 2 + (it == it_begin ? 0 : 1)) * PIECE;
 #pragma unroll
-        for (int r = 0; r < 2 * WM; ++r) {
-          ds += static_cast<double>(s_part[0][r][cl]);
-          dss += static_cast<double>(s_part[1][r][cl]);
-        }
-        const int span = gs < 64 ? gs : 64;           // gs is a power of two; groups wider than 64 columns add per wavefront
-        for (int d = 1; d < span; d <<= 1) {
-          ds += __shfl_xor(ds, d);
-          dss += __shfl_xor(dss, d);
-        }
-        const int col = n0 + cl;
-        if ((cl & (span - 1)) == 0 && col < N) {
-          double* d = rep + (static_cast<int64_t>(blk_first) * ep.groups + col / gs) * 2;
-          atomicAdd(d, ds);
-          atomicAdd(d + 1, dss);
-        }
-      }
-    } else if (wrow0 < M) {
-      const int64_t wlast = min(wrow0 + 31, M - 1);
-      int sg = blk_first;
-      while (sg + 1 < ep.S && wrow0 >= seg_end) {
-        ++sg;
-        seg_start = seg_end;
-        seg_end += ep.seg_len[sg];
-      }
-      while (true) {   // wave-uniform loop over the segments that intersect [wrow0, wlast]
-        const bool whole = seg_start <= wrow0 && wlast < seg_end;
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int col = n0 + wn * (32 * NT) + j * 32 + (lane & 31);
-          float s = 0.f, ss = 0.f;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int64_t row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const float v = (whole || (row >= seg_start && row < seg_end)) ? acc[j][r] : 0.f;
-            s += v;
-            ss = fmaf(v, v, ss);
-          }
-          double ds = s, dss = ss;
-          // fold the two row-halves, then the lanes of one group (gs consecutive columns, capped at the 32-column tile)
-          ds += __shfl_xor(ds, 32);
-          dss += __shfl_xor(dss, 32);
-          const int span = gs < 32 ? gs : 32;
-          for (int d = 1; d < span; d <<= 1) {
-            ds += __shfl_xor(ds, d);
-            dss += __shfl_xor(dss, d);
-          }
-          if (lane < 32 && (lane & (span - 1)) == 0 && col < N) {
-            double* d = rep + (static_cast<int64_t>(sg) * ep.groups + col / gs) * 2;
-            atomicAdd(d, ds);
-            atomicAdd(d + 1, dss);
-          }
+        for (int r = 0; r < 16; ++r)
+          __hip_atomic_store(&mine[(j * 16 + r) * GM_T + threadIdx.x], acc[j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // the workgroups that hold pieces of this tile: uf .. ul of this band (those with a non-empty range)
+      const int64_t tile_it0 = lt * nk, tile_it1 = tile_it0 + nk;
+      int uf = static_cast<int>(tile_it0 * sk.U / I);
+      while (uf > 0 && first_it(uf) > tile_it0) --uf;
+      while (first_it(uf + 1) <= tile_it0) ++uf;
+      int ul = uf, pieces = 0;
+      for (int uu = uf; uu < sk.U && first_it(uu) < tile_it1; ++uu)
+        if (first_it(uu + 1) > first_it(uu)) {
+          ul = uu;
+          ++pieces;
         }
-        if (wlast < seg_end || sg + 1 >= ep.S) break;
-        ++sg;
-        seg_start = seg_end;
-        seg_end += ep.seg_len[sg];
+      __builtin_amdgcn_s_waitcnt(0);                                       // THIS wavefront's parked values are acknowledged ...
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();                                                     // ... and so are the other three's, before the count
+      uint32_t* cnt = sk.arrived + (m_tile * ntn + lt % ntn);
+      if (threadIdx.x == 0) s_arrived = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      finish = s_arrived == static_cast<unsigned>(pieces - 1);           // block-uniform: the last piece to arrive folds the tile
+      if (finish) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int uu = uf; uu <= ul; ++uu) {
+          if (first_it(uu + 1) <= first_it(uu)) continue;
+          const float* pp = sk.partial + (static_cast<int64_t>(uu * 8 + xcd) * 2 + (first_it(uu) >= tile_it0 ? 0 : 1)) * PIECE;
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              acc[j][r] += __hip_atomic_load(&pp[(j * 16 + r) * GM_T + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    if (finish) {
+      if (ep.stats != nullptr) {                                           // GroupNorm segment of this row block
+        blk_first = 0;
+        blk_seg_start = 0;
+        blk_seg_end = ep.seg_len[0];
+        while (blk_first + 1 < ep.S && m0 >= blk_seg_end) {
+          ++blk_first;
+          blk_seg_start = blk_seg_end;
+          blk_seg_end += ep.seg_len[blk_first];
+        }
+      }
+      gemm_epilogue<BM, BN, WM, WN, NT>(acc, C, M, N, m0, n0, m_tile, ep, bias_v, blk_first, blk_seg_start, blk_seg_end, wm, wn, lane);
+    }
+    it += ns;
+    __syncthreads();                                                       // LDS is reused by the next segment
   }
 }
 
@@ -479,6 +677,69 @@ static int launch_gemm(const float* A, const float* B, float* C, int64_t M, int 
   return check_launch("lcr_gemm_f32");
 }
 
+// Scratch of the stream-K launches, one per stream (launches on one stream are ordered, so they can share it): the parked
+// partial tiles (two per workgroup) and the per-tile arrival counters (left at zero by every launch).
+struct SkScratch {
+  float*    partial = nullptr;
+  uint32_t* arrived = nullptr;
+};
+static std::mutex g_sk_mu;
+static std::map<std::pair<int, hipStream_t>, SkScratch> g_sk_scratch;
+constexpr int SK_MAX_GRID = 1024;
+constexpr int SK_MAX_TILES = 8192;
+
+static int sk_cu_count() {
+  static const int n = [] {
+    int dev = 0, cus = 0;
+    hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return cus;
+  }();
+  return n;
+}
+
+// Stream-K pays when whole-tile scheduling leaves the busiest CU with >= 10 % more work than the average one.
+static bool sk_worth(int64_t M, int N, int K) {
+  const int cus = sk_cu_count();
+  const int64_t tiles = static_cast<int64_t>(div_up(M, 64)) * div_up(N, 64);
+  if (K < 480 || tiles < cus / 2 || tiles > 6 * static_cast<int64_t>(cus) || tiles > SK_MAX_TILES) return false;
+  const double avg = static_cast<double>(tiles) / cus;
+  const double worst = static_cast<double>((tiles + cus - 1) / cus);
+  return worst / avg >= 1.10;
+}
+
+static int launch_gemm_sk(const float* A, const float* B, float* C, int64_t M, int N, int K, const GemmEpilogue& ep, hipStream_t st) {
+  const int cus = sk_cu_count();
+  const int64_t iters = static_cast<int64_t>(div_up(M, 64)) * div_up(N, 64) * div_up(K, GM_BK);
+  // persistent workgroups: 3, 2 or 1 per CU — as many as still get >= 24 K-steps each
+  int per_cu = 3;
+  while (per_cu > 1 && iters / (static_cast<int64_t>(cus) * per_cu) < 24) --per_cu;
+  if (getenv("LCR_SK_PER_CU")) per_cu = atoi(getenv("LCR_SK_PER_CU"));
+  int U = cus * per_cu / 8;
+  if (U < 1) U = 1;
+  if (8 * U > SK_MAX_GRID) U = SK_MAX_GRID / 8;
+  int dev = 0;
+  hipGetDevice(&dev);
+  GemmStreamK sk;
+  {
+    std::lock_guard<std::mutex> lk(g_sk_mu);
+    SkScratch& sc = g_sk_scratch[{dev, st}];
+    if (!sc.partial) {
+      if (hipMalloc(reinterpret_cast<void**>(&sc.partial), sizeof(float) * 2 * 16 * GM_T * SK_MAX_GRID) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void**>(&sc.arrived), sizeof(uint32_t) * SK_MAX_TILES) != hipSuccess) {
+        set_error("lcr_gemm_f32: cannot allocate the stream-K scratch");
+        return LCR_EHIP;
+      }
+      hipMemsetAsync(sc.arrived, 0, sizeof(uint32_t) * SK_MAX_TILES, st);     // once: every launch leaves the counters at zero
+    }
+    sk.partial = sc.partial;
+    sk.arrived = sc.arrived;
+    sk.U = U;
+  }
+  hipLaunchKernelGGL((k_gemm_f32_sk<64, 64, 2, 2>), dim3(8 * U), dim3(GM_T), 0, st, A, B, C, M, N, K, ep, sk);
+  return check_launch("lcr_gemm_f32");
+}
+
 }  // namespace lcr
 
 using namespace lcr;
@@ -486,6 +747,9 @@ using namespace lcr;
 // tuning hook (tools/gemm_bench.py): 0 = heuristic, 1..5 = force a tile shape
 static int g_force_tile = 0;
 extern "C" void lcr_gemm_debug_force_tile(int t) { g_force_tile = t; }
+// tuning / test hook: -1 = LCR_GEMM_STREAMK (default 1 = heuristic), 0 = never, 2 = whenever the stream-K kernel is legal
+static int g_force_streamk = -1;
+extern "C" void lcr_gemm_debug_streamk(int mode) { g_force_streamk = mode; }
 
 static int gemm_impl(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB, const float* bias,
                      const float* rowdiv, const int64_t* seg_len, int S, int groups, double* stats, void* stream);
@@ -542,6 +806,13 @@ static int gemm_impl(const float* A, const float* B, float* C, int64_t M, int N,
     return launch_gemm<64, 64, 2, 2, true, true>(A, B, C, M, N, K, transA, transB, ep, st);
   }
   if (N <= 32) return launch_gemm<128, 32, 4, 1, true>(A, B, C, M, N, K, transA, transB, ep, st);
+  // Stream-K is opt-in: measured +3 / +5 / +7 % on the three deepest KPConv contractions alone (93.6 vs 96, 121 vs 128, 153 vs
+  // 164 us) — far from the 20 % a CU-count model predicts, because one or two workgroups per CU already reach 40 / 60 % of the
+  // matrix-pipe rate that three reach (65 %), so an unevenly loaded CU is slower per tile but not idle pro rata.
+  static const int sk_env = getenv("LCR_GEMM_STREAMK") ? atoi(getenv("LCR_GEMM_STREAMK")) : 0;   // 0 off, 1 heuristic, 2 whenever legal
+  const int sk_mode = g_force_streamk >= 0 ? g_force_streamk : sk_env;
+  const bool sk_legal = !transA && !transB && K >= 64 && static_cast<int64_t>(div_up(M, 64)) * div_up(N, 64) <= SK_MAX_TILES;
+  if (sk_mode && sk_legal && (sk_mode == 2 || sk_worth(M, N, K))) return launch_gemm_sk(A, B, C, M, N, K, ep, st);
   if (K >= 512 && b128 * nb128 >= 512) return launch_gemm<128, 128, 4, 1, true>(A, B, C, M, N, K, transA, transB, ep, st);
   return launch_gemm<64, 64, 2, 2, true>(A, B, C, M, N, K, transA, transB, ep, st);
 }

@@ -231,3 +231,38 @@ def test_native_encoder_driver_is_bit_identical_to_the_module_tree(model, monkey
         torch.cuda.synchronize()
         for a, b in zip(nat, ref):
             assert a.shape == b.shape and torch.equal(a, b), variant
+
+
+def test_stream_k_gemm_matches_tile_per_workgroup_gemm():
+    """The stream-K form of the K-deep contractions (partial tiles parked + folded by the tile's owner) against the
+    tile-per-workgroup kernel on the same inputs: outputs within fp32 re-association error, GroupNorm sums likewise, and
+    bit-identical from run to run (the fold order is fixed by the grid)."""
+    import ctypes
+    from lcrnet_amd import _lib
+    from lcrnet_amd import functional as F
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    shapes = [(6479, 256, 3840), (19061, 128, 1920), (5000, 64, 960), (700, 64, 480), (64, 64, 64), (1, 64, 3200), (130, 128, 1000),
+              (40000, 64, 96)]
+    try:
+        for M, N, K in shapes:
+            A = torch.randn(M, K, device="cuda", generator=g)
+            W = torch.randn(K, N, device="cuda", generator=g) * 0.05
+            bias = torch.randn(N, device="cuda", generator=g)
+            rowdiv = torch.randint(1, 40, (M,), device="cuda", generator=g).float()
+            cuts = sorted(set([0, M // 3, M // 2, M]))
+            seg = torch.tensor([b - a for a, b in zip(cuts[:-1], cuts[1:])], dtype=torch.int64, device="cuda")
+            lib.lcr_gemm_debug_streamk(0)
+            want, wstats = F.gemm(A, W, bias=bias, rowdiv=rowdiv, seg_len=seg, groups=32)
+            lib.lcr_gemm_debug_streamk(2)
+            got, gstats = F.gemm(A, W, bias=bias, rowdiv=rowdiv, seg_len=seg, groups=32)
+            again, _ = F.gemm(A, W, bias=bias, rowdiv=rowdiv, seg_len=seg, groups=32)
+            torch.cuda.synchronize()
+            scale = float(want.abs().max())
+            assert float((got - want).abs().max()) <= 2e-5 * scale + 1e-6, (M, N, K)
+            assert torch.equal(got, again), (M, N, K)
+            ws = wstats.view(-1, seg.numel(), 32, 2).sum(0)
+            gs = gstats.view(-1, seg.numel(), 32, 2).sum(0)
+            assert torch.allclose(ws, gs, rtol=1e-5, atol=1e-3), (M, N, K)
+    finally:
+        lib.lcr_gemm_debug_streamk(-1)
