@@ -159,7 +159,8 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate_vec(const fl
 // One wavefront per query, lanes = neighbours.  A query is three DEPENDENT memory round trips (order -> point + index row ->
 // neighbour coordinates) and ~250 instructions, so the kernel is latency-bound: the header of query t+2 and the neighbour
 // gathers of query t+1 are in flight while query t is computed (clamped, unconditional loads: one basic block per trip), and
-// the register budget (MAXO output channels per lane) is sized by the launch so that 8 wavefronts per SIMD stay resident.
+// the register budget (MAXO output channels per lane) is sized by the launch: 91 VGPRs / 5 wavefronts per SIMD for C_out <= 64
+// instead of 124 / 4.  With that the kernel sits at its VALU bound (15 influences x ~11 operations per neighbour, one lane each).
 template <typename IdxT, int MAXO>
 __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_cin1(const float* __restrict__ s_feats, const float* __restrict__ q_pts,
                                                                const float* __restrict__ s_pts, const IdxT* __restrict__ idx, int64_t M,
