@@ -49,7 +49,9 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 
 // R x 32 tile of a row-major [rows_total x K] matrix -> S[k][r]   (transposing loader; src contiguous along k).
 // Branch-free: out-of-range pieces read a valid clamped address and are zeroed by a select.
-template <int R, int LD, bool VEC>
+// RM: the LDS tile is kept ROW-major instead (S[r][k], LD = 36): the store is one 16-B write per piece instead of four
+// transposing 4-B ones, and an MFMA operand fetch becomes one 16-B read per FOUR MFMAs (see the K pairing in k_gemm_f32).
+template <int R, int LD, bool VEC, bool RM = false>
 struct LoaderT {
   static constexpr int PIECES = R * 8 / GM_T;   // float4 pieces per thread
   float4 reg[PIECES];
@@ -83,6 +85,10 @@ struct LoaderT {
     const int f = threadIdx.x + GM_T * j;
     const int row = f >> 3, c4 = f & 7;
     const bool ok = (okmask >> j) & 1u;
+    if (RM) {
+      *reinterpret_cast<float4*>(&S[row * LD + c4 * 4]) = ok ? reg[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      return;
+    }
     S[(c4 * 4 + 0) * LD + row] = ok ? reg[j].x : 0.f;
     S[(c4 * 4 + 1) * LD + row] = ok ? reg[j].y : 0.f;
     S[(c4 * 4 + 2) * LD + row] = ok ? reg[j].z : 0.f;
@@ -289,12 +295,21 @@ __global__ __launch_bounds__(GM_T, SHORT ? 6 : 2) void k_gemm_f32(const float* _
       K = batch.k[z];
     }
   }
-  constexpr int LDA = TA ? BM + 4 : BM + 1;
-  constexpr int LDB = TB ? BN + 1 : BN + 4;
   constexpr int NT = BN / (32 * WN);
   constexpr int NBUF = SHORT ? 1 : 2;
-  __shared__ __attribute__((aligned(16))) float As[NBUF][GM_BK * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[NBUF][GM_BK * LDB];
+  // K pairing.  A 32x32x2 MFMA consumes two K indices (lanes 0-31 one, lanes 32-63 the other); which two is free as long as A
+  // and B agree.  With one accumulator per wavefront (NT == 1: every encoder GEMM) MFMA j of a 32-deep K-step takes (j, j + 16):
+  // a lane then needs 16 CONSECUTIVE k of its row, so an operand whose global layout is k-contiguous (A [M,K]; B = nn.Linear
+  // weight [N,K]) stays row-major in LDS — stored with one 16-B write per piece, fetched with four 16-B reads per K-step instead
+  // of sixteen 4-B ones.  (Before: (2j, 2j+1) on K-major tiles, 48 LDS instructions per wavefront and K-step; now 12 for the
+  // unary Linears, 24 for the KPConv contraction whose B [K,N] stays K-major.)  Multi-accumulator tiles keep the old scheme.
+  constexpr bool NEWP = NT == 1;
+  constexpr bool ARM = NEWP && !TA, BRM = NEWP && TB;
+  constexpr int LDR = GM_BK + 4;
+  constexpr int LDA = ARM ? LDR : (TA ? BM + 4 : BM + 1);
+  constexpr int LDB = BRM ? LDR : (TB ? BN + 1 : BN + 4);
+  __shared__ __attribute__((aligned(16))) float As[NBUF][ARM ? BM * LDR : GM_BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[NBUF][BRM ? BN * LDR : GM_BK * LDB];
 
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
   const int wm = w / WN, wn = w % WN;
@@ -310,9 +325,9 @@ __global__ __launch_bounds__(GM_T, SHORT ? 6 : 2) void k_gemm_f32(const float* _
 
   // two register stages: the tile for K-step t+2 is requested while step t computes and step t+1 already sits in registers,
   // so a global load has two full MFMA phases (~2 x 1024 cycles) to land before it is needed for the LDS store
-  LoaderT<BM, LDA, VEC> la_t[NBUF];
+  LoaderT<BM, LDA, VEC, ARM> la_t[NBUF];
   LoaderN<BM, LDA, VEC> la_n[NBUF];
-  LoaderT<BN, LDB, VEC> lb_t[NBUF];
+  LoaderT<BN, LDB, VEC, BRM> lb_t[NBUF];
   LoaderN<BN, LDB, VEC> lb_n[NBUF];
 
   auto gload = [&](int k0, int r) {
@@ -366,8 +381,28 @@ __global__ __launch_bounds__(GM_T, SHORT ? 6 : 2) void k_gemm_f32(const float* _
   }
   sstore(0, 0);
   __syncthreads();
-  const int a_off = (lane >> 5) * LDA + wm * 32 + (lane & 31);
-  const int b_off = (lane >> 5) * LDB + wn * (32 * NT) + (lane & 31);
+  const int half = lane >> 5;
+  const int a_off = ARM ? (wm * 32 + (lane & 31)) * LDR + half * 16 : half * (NEWP ? 16 : 1) * LDA + wm * 32 + (lane & 31);
+  const int b_off = BRM ? (wn * (32 * NT) + (lane & 31)) * LDR + half * 16 : half * (NEWP ? 16 : 1) * LDB + wn * (32 * NT) + (lane & 31);
+  // operands of MFMAs 4q .. 4q+3 of a K-step (NEWP only)
+  auto fetch4_a = [&](const float* as, int q, float (&o)[4]) {
+    if (ARM) {
+      const float4 v = *reinterpret_cast<const float4*>(as + 4 * q);
+      o[0] = v.x, o[1] = v.y, o[2] = v.z, o[3] = v.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = as[(4 * q + i) * LDA];
+    }
+  };
+  auto fetch4_b = [&](const float* bs, int q, float (&o)[4]) {
+    if (BRM) {
+      const float4 v = *reinterpret_cast<const float4*>(bs + 4 * q);
+      o[0] = v.x, o[1] = v.y, o[2] = v.z, o[3] = v.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = bs[(4 * q + i) * LDB];
+    }
+  };
   if constexpr (SHORT) {
     constexpr int KKS = GM_BK / 2, PFS = 4;
     for (int t = 0; t < nk; ++t) {
@@ -379,22 +414,19 @@ __global__ __launch_bounds__(GM_T, SHORT ? 6 : 2) void k_gemm_f32(const float* _
       }
       const float* as = As[0] + a_off;
       const float* bs = Bs[0] + b_off;
-      float af[PFS], bf[PFS][NT];
+      static_assert(NEWP, "the light form is only instantiated for single-accumulator tiles");
+      float af[2][4], bf[2][4];                               // two groups of four MFMAs in flight
+      fetch4_a(as, 0, af[0]);
+      fetch4_b(bs, 0, bf[0]);
+      fetch4_a(as, 1, af[1]);
+      fetch4_b(bs, 1, bf[1]);
 #pragma unroll
-      for (int d = 0; d < PFS; ++d) {
-        af[d] = as[d * 2 * LDA];
+      for (int q = 0; q < KKS / 4; ++q) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bf[d][j] = bs[d * 2 * LDB + j * 32];
-      }
-#pragma unroll
-      for (int kk = 0; kk < KKS; ++kk) {
-        const int sl = kk % PFS;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[sl], bf[sl][j], acc[j], 0, 0, 0);
-        if (kk + PFS < KKS) {
-          af[sl] = as[(kk + PFS) * 2 * LDA];
-#pragma unroll
-          for (int j = 0; j < NT; ++j) bf[sl][j] = bs[(kk + PFS) * 2 * LDB + j * 32];
+        for (int i = 0; i < 4; ++i) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][i], bf[q & 1][i], acc[0], 0, 0, 0);
+        if (q + 2 < KKS / 4) {
+          fetch4_a(as, q + 2, af[q & 1]);
+          fetch4_b(bs, q + 2, bf[q & 1]);
         }
       }
     }
@@ -418,11 +450,25 @@ __global__ __launch_bounds__(GM_T, SHORT ? 6 : 2) void k_gemm_f32(const float* _
     const float* as = As[BUF] + a_off;
     const float* bs = Bs[BUF] + b_off;
     float af[PF], bf[PF][NT];
+    if constexpr (NEWP) {                                         // PF == KK: the whole K-step's operands, in 16-B reads where row-major
 #pragma unroll
-    for (int d = 0; d < PF; ++d) {
-      af[d] = as[d * 2 * LDA];
+      for (int q = 0; q < KK / 4; ++q) {
+        float a4[4], b4[4];
+        fetch4_a(as, q, a4);
+        fetch4_b(bs, q, b4);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bf[d][j] = bs[d * 2 * LDB + j * 32];
+        for (int i = 0; i < 4; ++i) {
+          af[4 * q + i] = a4[i];
+          bf[4 * q + i][0] = b4[i];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int d = 0; d < PF; ++d) {
+        af[d] = as[d * 2 * LDA];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[d][j] = bs[d * 2 * LDB + j * 32];
+      }
     }
     __builtin_amdgcn_sched_barrier(0);                            // keep the fragment reads ahead of the MFMA chain
 #pragma unroll
