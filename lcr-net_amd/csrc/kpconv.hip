@@ -36,6 +36,23 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+// Query -> workgroup mapping of the gather kernels.  Workgroups go round-robin to the 8 XCDs (id % 8), each with its own,
+// non-coherent L2.  With a plain grid-stride walk all XCDs sweep the (spatially ordered) query list side by side, so every XCD
+// pulls the SAME support rows into its own L2 — the gathered table crosses the fabric up to eight times (PMC: max-pool fetched
+// 445 MB for a 65 MB table).  Here XCD x walks the x-th CONTIGUOUS eighth of the list: its L2 only ever holds that region's rows.
+struct XcdBand {
+  int64_t begin, end, stride;   // this wavefront's first query, the end of its band, the step
+};
+__device__ __forceinline__ XcdBand xcd_band(int64_t M, int wave_in_block, int waves_per_block) {
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;      // the grid is a multiple of 8
+  const int64_t per = (M + 7) / 8;
+  XcdBand b;
+  b.begin = xcd * per + static_cast<int64_t>(slot) * waves_per_block + wave_in_block;
+  b.end = min(M, (xcd + 1) * per);
+  b.stride = static_cast<int64_t>(nslots) * waves_per_block;
+  return b;
+}
+
 // The aggregation kernel.  A lane fetches V = 4 (C >= 64)
 // or 2 (C = 32) CONSECUTIVE channels of its neighbour's row with one 16-B / 8-B load, so a 4-neighbour step of C = 64 is one
 // load instruction per lane (4 full 256-B rows per wavefront instruction) instead of four, and the V components feed V MFMA tiles
@@ -72,7 +89,8 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate_vec(const fl
       kz = kp.p[k][2];
     }
   const bool real_k = col < KP_K;
-  for (int64_t t = static_cast<int64_t>(blockIdx.x) * KP_WAVES + w; t < M; t += static_cast<int64_t>(gridDim.x) * KP_WAVES) {
+  const XcdBand band = xcd_band(M, w, KP_WAVES);
+  for (int64_t t = band.begin; t < band.end; t += band.stride) {
     const int64_t m = order ? order[t] : t;
     const float qx = q_pts[3 * m], qy = q_pts[3 * m + 1], qz = q_pts[3 * m + 2];
     int n = 0, cnt = 0;
@@ -283,7 +301,8 @@ __global__ __launch_bounds__(256) void k_maxpool(const float* __restrict__ x, co
                                                  float* __restrict__ out, const int32_t* __restrict__ order) {
   __shared__ int32_t s_idx[4][KP_HMAX];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
-  for (int64_t t = static_cast<int64_t>(blockIdx.x) * 4 + w; t < M; t += static_cast<int64_t>(gridDim.x) * 4) {
+  const XcdBand band = xcd_band(M, w, 4);
+  for (int64_t t = band.begin; t < band.end; t += band.stride) {
     const int64_t m = order ? order[t] : t;
     int n = 0;
     bool any_shadow = false;
@@ -370,11 +389,16 @@ static KPoints load_kp(const float* kp_host) {
 }
 
 static int grid_for(int64_t rows, int per_block) { return static_cast<int>(std::min<int64_t>((rows + per_block - 1) / per_block, 256 * 16)); }
+// gather kernels (xcd_band): a multiple of 8 workgroups, enough for every XCD's eighth of the rows
+static int grid_for_xcd(int64_t rows, int per_block) {
+  const int64_t per_xcd = ((rows + 7) / 8 + per_block - 1) / per_block;
+  return 8 * static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(per_xcd, 256 * 2)));
+}
 
 template <typename IdxT>
 static int launch_aggregate(const float* s_feats, const uint8_t* s_pos, const float* q_pts, const float* s_pts, const IdxT* idx, int64_t M,
                             int64_t Ns, int H, int C, const KPoints& kp, float sigma, float* A, float* nn, const int32_t* order, hipStream_t st) {
-  dim3 grid(grid_for(M, KP_WAVES)), block(KP_WAVES * 64);
+  dim3 grid(grid_for_xcd(M, KP_WAVES)), block(KP_WAVES * 64);
   switch (C) {
     case 32: hipLaunchKernelGGL((k_kpconv_aggregate_vec<IdxT, 32>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
     case 64: hipLaunchKernelGGL((k_kpconv_aggregate_vec<IdxT, 64>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
@@ -437,7 +461,7 @@ extern "C" int lcr_maxpool(const float* x, const void* idx, int idx_is_64, int64
   }
   if (M == 0) return LCR_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  dim3 grid(grid_for(M, 4)), block(256);
+  dim3 grid(grid_for_xcd(M, 4)), block(256);
   if (idx_is_64) hipLaunchKernelGGL((k_maxpool<int64_t>), grid, block, 0, st, x, static_cast<const int64_t*>(idx), M, Ns, H, C, out, order);
   else hipLaunchKernelGGL((k_maxpool<int32_t>), grid, block, 0, st, x, static_cast<const int32_t*>(idx), M, Ns, H, C, out, order);
   return check_launch("lcr_maxpool");
