@@ -58,6 +58,15 @@ def main():
             timed("subsampling[%d]" % i, lambda: grids[i].query(P[i + 1], L[i + 1], bench.LIMITS[i]))
             timed("upsampling[%d]" % i, lambda: grids[i + 1].query(P[i], L[i], bench.LIMITS[i + 1]))
     print("total %.1f us" % total)
+    # the same searches with the QUERIES permuted into their own grid's cell order (spatially coherent wavefronts)
+    total = 0.0
+    Pc = [P[i][grids[i].order().long()].contiguous() for i in range(bench.NUM_STAGES)]
+    for i in range(bench.NUM_STAGES):
+        timed("cell-order neighbors[%d]" % i, lambda: grids[i].query(Pc[i], L[i], bench.LIMITS[i]))
+        if i < bench.NUM_STAGES - 1:
+            timed("cell-order subsampling[%d]" % i, lambda: grids[i].query(Pc[i + 1], L[i + 1], bench.LIMITS[i]))
+            timed("cell-order upsampling[%d]" % i, lambda: grids[i + 1].query(Pc[i], L[i], bench.LIMITS[i + 1]))
+    print("total with cell-ordered queries %.1f us" % total)
 
 
 if __name__ == "__main__":
