@@ -83,6 +83,12 @@ int lcr_support_grid_build(const float* s, const int64_t* slen, int B, int64_t n
 int lcr_radius_query(const float* q, const int64_t* qlen, int B, int64_t nq_cap,
                      const void* grid_ws, int64_t ns_cap /* as passed to the build */, float radius, int limit,
                      int64_t* out_idx64, int32_t* out_idx32, int32_t* out_cnt, void* stream);
+/* lcr_radius_query with a processing order for the queries (q_order i32[nq]: a permutation of the query rows, e.g. the query set's
+ * own cell order from lcr_support_grid_build_ex; NULL = row order).  Results are identical; spatially coherent wavefronts re-use
+ * their candidate cells from cache. */
+int lcr_radius_query_ordered(const float* q, const int64_t* qlen, int B, int64_t nq_cap,
+                             const void* grid_ws, int64_t ns_cap, float radius, int limit,
+                             int64_t* out_idx64, int32_t* out_idx32, int32_t* out_cnt, const int32_t* q_order, void* stream);
 /* Same build that also writes the cell-sorted processing order (what lcr_support_grid_order returns) into order i32[ns_cap]. */
 int lcr_support_grid_build_ex(const float* s, const int64_t* slen, int B, int64_t ns_cap, float radius,
                               uint32_t* status, void* grid_ws, size_t grid_ws_bytes, int32_t* order, void* stream);

@@ -249,19 +249,20 @@ extern "C" int lcr_precompute_batch(const float* points0, const int64_t* lengths
     if (!no_fork) hipStreamWaitEvent(s, C.ready[i], 0);
     rc = TURN(lcr_support_grid_build_ex(pts[i], lens[i], B, L->cap[i], r, W.status, W.grid_ws[i], W.grid_bytes[i], i32(L->off_order[i]), s));
     if (rc) return rc;
-    rc = TURN(lcr_radius_query(pts[i], lens[i], B, L->cap[i], W.grid_ws[i], L->cap[i], r, L->limits[i], nullptr, i32(L->off_neighbors[i]),
-                          nullptr, s));
+    // every search walks its queries in the QUERY set's own cell order (written by that stage's grid build, earlier in the chain)
+    rc = TURN(lcr_radius_query_ordered(pts[i], lens[i], B, L->cap[i], W.grid_ws[i], L->cap[i], r, L->limits[i], nullptr,
+                                       i32(L->off_neighbors[i]), nullptr, i32(L->off_order[i]), s));
     if (rc) return rc;
     if (i > 0 && L->upsampling) {
-      rc = TURN(lcr_radius_query(pts[i - 1], lens[i - 1], B, L->cap[i - 1], W.grid_ws[i], L->cap[i], r, L->limits[i], nullptr,
-                            i32(L->off_upsampling[i - 1]), nullptr, s));
+      rc = TURN(lcr_radius_query_ordered(pts[i - 1], lens[i - 1], B, L->cap[i - 1], W.grid_ws[i], L->cap[i], r, L->limits[i], nullptr,
+                                         i32(L->off_upsampling[i - 1]), nullptr, i32(L->off_order[i - 1]), s));
       if (rc) return rc;
     }
     if (i > 0) {
       hipStream_t sp = no_fork ? main : C.side[i - 1];
       if (!no_fork) hipStreamWaitEvent(sp, C.ready[i], 0);
-      rc = TURN(lcr_radius_query(pts[i], lens[i], B, L->cap[i], W.grid_ws[i - 1], L->cap[i - 1], radii[i - 1], L->limits[i - 1], nullptr,
-                            i32(L->off_subsampling[i - 1]), nullptr, sp));
+      rc = TURN(lcr_radius_query_ordered(pts[i], lens[i], B, L->cap[i], W.grid_ws[i - 1], L->cap[i - 1], radii[i - 1], L->limits[i - 1],
+                                         nullptr, i32(L->off_subsampling[i - 1]), nullptr, no_fork ? i32(L->off_order[i]) : nullptr, sp));   // forked: order[i] is written on another stream
       if (rc) return rc;
     }
     r *= 2.f;
