@@ -228,13 +228,30 @@ __global__ __launch_bounds__(256) void k_gs_seg_starts(const GsHeader* __restric
     if (head_scan[i + 1] != head_scan[i]) seg_start[head_scan[i]] = static_cast<int32_t>(i);
 }
 
+// per-cloud output counts and offsets from the scanned run heads (one thread)
+__device__ __forceinline__ void gs_offsets(GsHeader* h, const int32_t* __restrict__ head_scan, int64_t* __restrict__ out_len) {
+  int64_t o = 0;
+  for (int b = 0; b < h->B; ++b) {
+    // the sort key carries the cloud id in its top bits, so cloud b owns sorted positions [in_off[b], in_off[b+1]) and its
+    // number of distinct voxels is the number of run heads in that range (no per-run atomics)
+    const int64_t lo = min(h->in_off[b], h->rx.n), hi = min(h->in_off[b + 1], h->rx.n);
+    h->M[b] = head_scan ? head_scan[hi] - head_scan[lo] : 0;
+    h->out_off[b] = o;
+    out_len[b] = h->M[b];
+    o += h->M[b];
+  }
+  h->out_off[h->B] = o;
+  h->n_seg = o;
+}
+
 // one lane per voxel run: in-order fp32 sums (.h:17-20), barycentre = sum * float(1.0 / count) (:46)
 __global__ __launch_bounds__(256) void k_gs_reduce(GsHeader* h, const float* __restrict__ xyz, const uint64_t* __restrict__ kA,
                                                    const uint64_t* __restrict__ kB, const uint32_t* __restrict__ vA,
                                                    const uint32_t* __restrict__ vB, const int32_t* __restrict__ head_scan,
                                                    const int32_t* __restrict__ seg_start, float* __restrict__ bary,
                                                    uint64_t* __restrict__ seg_key, uint32_t* __restrict__ seg_first,
-                                                   int32_t* __restrict__ first_flag) {
+                                                   int32_t* __restrict__ first_flag, int64_t* __restrict__ out_len) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) gs_offsets(h, head_scan, out_len);   // read by the insertion / hash-order kernels (later launches)
   const int64_t n = h->rx.n;
   const int64_t nseg = n > 0 ? head_scan[n] : 0;   // exclusive scan of the head flags: total at index n
   const uint64_t* k = sorted_keys(h, kA, kB);
@@ -281,20 +298,8 @@ __global__ __launch_bounds__(256) void k_gs_reduce(GsHeader* h, const float* __r
   }
 }
 
-__global__ void k_gs_offsets(GsHeader* h, const int32_t* __restrict__ head_scan, int64_t* __restrict__ out_len) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  int64_t o = 0;
-  for (int b = 0; b < h->B; ++b) {
-    // the sort key carries the cloud id in its top bits, so cloud b owns sorted positions [in_off[b], in_off[b+1]) and its
-    // number of distinct voxels is the number of run heads in that range (no per-run atomics)
-    const int64_t lo = min(h->in_off[b], h->rx.n), hi = min(h->in_off[b + 1], h->rx.n);
-    h->M[b] = head_scan ? head_scan[hi] - head_scan[lo] : 0;
-    h->out_off[b] = o;
-    out_len[b] = h->M[b];
-    o += h->M[b];
-  }
-  h->out_off[h->B] = o;
-  h->n_seg = o;
+__global__ void k_gs_offsets(GsHeader* h, const int32_t* __restrict__ head_scan, int64_t* __restrict__ out_len) {   // empty input only
+  if (threadIdx.x == 0 && blockIdx.x == 0) gs_offsets(h, head_scan, out_len);
 }
 
 __global__ __launch_bounds__(256) void k_gs_insertion(const GsHeader* __restrict__ h, const int32_t* __restrict__ first_scan,
@@ -667,10 +672,9 @@ extern "C" int lcr_grid_subsample_ex(const float* xyz, const int64_t* len, int B
   if (rc) return rc;
   hipLaunchKernelGGL(k_gs_seg_starts, dim3(nblk), dim3(256), 0, st, L.hdr, L.head, L.seg_start);
   hipLaunchKernelGGL(k_gs_reduce, dim3(nblk), dim3(256), 0, st, L.hdr, xyz, L.keyA, L.keyB, L.valA, L.valB, L.head, L.seg_start, L.bary,
-                     L.seg_key, L.seg_first, L.first);
+                     L.seg_key, L.seg_first, L.first, out_len);
   rc = exclusive_scan_i32(L.first, L.first, n_cap + 1, nullptr, L.scan_ws, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_gs_offsets, dim3(1), dim3(64), 0, st, L.hdr, L.head, out_len);
   hipLaunchKernelGGL(k_gs_insertion, dim3(nblk), dim3(256), 0, st, L.hdr, L.first, L.seg_key, L.seg_first, L.ins_key, L.ins_seg);
   static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gs_hashorder),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(HM_LDS_BYTES));
