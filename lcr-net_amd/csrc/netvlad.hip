@@ -93,10 +93,21 @@ __global__ __launch_bounds__(1024) void k_vlad_finalize(float* __restrict__ V, c
   const int k = threadIdx.x & 63, q = threadIdx.x >> 6;   // 16 row-groups x 64 clusters
   const float ak = as[k];
   float ss = 0.f;
-  for (int c = q; c < NV_F; c += 16) {
-    const float t = v[c * NV_K + k] - ak * Wc2[c * NV_K + k];
-    v[c * NV_K + k] = t;
-    ss = fmaf(t, t, ss);
+  constexpr int FB = 8;                           // rows requested per trip: one workgroup per scan, latency is all there is to hide
+  static_assert((NV_F / 16) % FB == 0, "row batches");
+  for (int c0 = q; c0 < NV_F; c0 += 16 * FB) {
+    float vv[FB], ww[FB];
+#pragma unroll
+    for (int u = 0; u < FB; ++u) {
+      vv[u] = v[(c0 + 16 * u) * NV_K + k];
+      ww[u] = Wc2[(c0 + 16 * u) * NV_K + k];
+    }
+#pragma unroll
+    for (int u = 0; u < FB; ++u) {
+      const float t = vv[u] - ak * ww[u];
+      v[(c0 + 16 * u) * NV_K + k] = t;
+      ss = fmaf(t, t, ss);
+    }
   }
   s_col[q][k] = ss;
   __syncthreads();
@@ -115,7 +126,13 @@ __global__ __launch_bounds__(1024) void k_vlad_finalize(float* __restrict__ V, c
   __syncthreads();
   const float g = 1.f / fmaxf(sqrtf(s_tot), 1e-6f);
   const float f = s_inv[k] * g;
-  for (int c = q; c < NV_F; c += 16) v[c * NV_K + k] *= f;
+  for (int c0 = q; c0 < NV_F; c0 += 16 * FB) {
+    float vv[FB];
+#pragma unroll
+    for (int u = 0; u < FB; ++u) vv[u] = v[(c0 + 16 * u) * NV_K + k];
+#pragma unroll
+    for (int u = 0; u < FB; ++u) v[(c0 + 16 * u) * NV_K + k] = vv[u] * f;
+  }
 }
 
 // partial[slice][s][j] = sum_{i in slice} v[s][i] * H[i][j];  one workgroup per K-slice, thread = output column j
@@ -132,10 +149,19 @@ __global__ __launch_bounds__(NV_D) void k_hidden_splitk(const float* __restrict_
   float acc[SMAX];
 #pragma unroll
   for (int s = 0; s < SMAX; ++s) acc[s] = 0.f;
-  for (int i = 0; i < ROWS; ++i) {
-    const float h = H[static_cast<int64_t>(i0 + i) * NV_D + j];
+  // the 67 MB weight matrix is streamed once: 16 rows requested per trip (one wavefront per SIMD has nothing else to hide the
+  // latency with); the additions keep the row order
+  constexpr int HB = 16;
+  static_assert(ROWS % HB == 0, "row batches");
+  const float* hp = H + static_cast<int64_t>(i0) * NV_D + j;
+  for (int i = 0; i < ROWS; i += HB) {
+    float h[HB];
 #pragma unroll
-    for (int s = 0; s < SMAX; ++s) acc[s] = fmaf(s_v[s][i], h, acc[s]);
+    for (int u = 0; u < HB; ++u) h[u] = hp[static_cast<int64_t>(i + u) * NV_D];
+#pragma unroll
+    for (int u = 0; u < HB; ++u)
+#pragma unroll
+      for (int s = 0; s < SMAX; ++s) acc[s] = fmaf(s_v[s][i + u], h[u], acc[s]);
   }
   for (int s = 0; s < ns; ++s) partial[(static_cast<int64_t>(blockIdx.x) * S + s0 + s) * NV_D + j] = acc[s];
 }
@@ -156,12 +182,26 @@ __global__ __launch_bounds__(NV_D) void k_netvlad_tail(const float* __restrict__
   __shared__ float s_red[4];
   const int s = blockIdx.x, j = threadIdx.x;
   float o = 0.f;
-  for (int b = 0; b < NV_SPLIT; ++b) o += partial[(static_cast<int64_t>(b) * S + s) * NV_D + j];
+  constexpr int TB = 16;                          // loads requested per trip (8 workgroups: nothing else hides the latency)
+  static_assert(NV_SPLIT % TB == 0 && NV_D % TB == 0, "load batches");
+  for (int b = 0; b < NV_SPLIT; b += TB) {
+    float p[TB];
+#pragma unroll
+    for (int u = 0; u < TB; ++u) p[u] = partial[(static_cast<int64_t>(b + u) * S + s) * NV_D + j];
+#pragma unroll
+    for (int u = 0; u < TB; ++u) o += p[u];
+  }
   o = (o - bn2.mean[j]) / sqrtf(bn2.var[j] + eps) * bn2.w[j] + bn2.b[j];
   s_o[j] = o;
   __syncthreads();
   float g = 0.f;
-  for (int i = 0; i < NV_D; ++i) g = fmaf(s_o[i], Wg[i * NV_D + j], g);
+  for (int i = 0; i < NV_D; i += TB) {
+    float wv[TB];
+#pragma unroll
+    for (int u = 0; u < TB; ++u) wv[u] = Wg[(i + u) * NV_D + j];
+#pragma unroll
+    for (int u = 0; u < TB; ++u) g = fmaf(s_o[i + u], wv[u], g);
+  }
   g = (g - bng.mean[j]) / sqrtf(bng.var[j] + eps) * bng.w[j] + bng.b[j];
   g = 1.f / (1.f + expf(-g));
   const float a = o * g;
