@@ -200,15 +200,29 @@ __global__ __launch_bounds__(256) void k_gn_stats(const float* __restrict__ x, i
       }
       s = ss = 0.f;
     };
-    for (int64_t n = r0; n < r1; ++n) {
-      while (n >= seg_end && cur + 1 < S) {   // wave-uniform
-        flush(cur);
-        ++cur;
-        seg_end += seg_len[cur];
+    constexpr int RB = 8;                       // rows requested per trip (clamped addresses, masked afterwards: branch-free loads)
+    const int cc = c < C ? c : C - 1;
+    for (int64_t n0 = r0; n0 < r1; n0 += RB) {
+      float vv[RB];
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const int64_t nn = n0 + u < r1 ? n0 + u : r1 - 1;
+        vv[u] = x[nn * C + cc];
       }
-      const float v = c < C ? x[n * C + c] : 0.f;
-      s += v;
-      ss = fmaf(v, v, ss);
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const int64_t n = n0 + u;
+        if (n < r1) {                           // wave-uniform
+          while (n >= seg_end && cur + 1 < S) {
+            flush(cur);
+            ++cur;
+            seg_end += seg_len[cur];
+          }
+          const float v = c < C ? vv[u] : 0.f;
+          s += v;
+          ss = fmaf(v, v, ss);
+        }
+      }
     }
     flush(cur);
   }
