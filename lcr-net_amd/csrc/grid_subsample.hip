@@ -532,6 +532,33 @@ __device__ __forceinline__ void hm_phase(const uint64_t* __restrict__ key, int32
   __syncthreads();
 }
 
+// Emit the barycentres in iteration order: pos[rank] = position of the rank-th inserted voxel.  Two dependent gathers per
+// element (segment of the rank, then its barycentre): four elements per thread are requested together.
+__device__ __forceinline__ void hm_emit(const int32_t* __restrict__ pos, const int32_t* __restrict__ ins_seg, const float* __restrict__ bary,
+                                        float* __restrict__ out_xyz, int64_t o, int n) {
+  constexpr int EU = 4;
+  for (int e0 = threadIdx.x; e0 < n; e0 += EU * HM_T) {
+    int seg[EU], dst[EU];
+#pragma unroll
+    for (int k = 0; k < EU; ++k) {
+      const int e = e0 + k * HM_T < n ? e0 + k * HM_T : n - 1;
+      seg[k] = ins_seg[o + e];
+      dst[k] = pos[e];
+    }
+    float b[EU][3];
+#pragma unroll
+    for (int k = 0; k < EU; ++k)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) b[k][d] = bary[3 * static_cast<int64_t>(seg[k]) + d];
+#pragma unroll
+    for (int k = 0; k < EU; ++k)
+      if (e0 + k * HM_T < n) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) out_xyz[3 * (o + dst[k]) + d] = b[k][d];
+      }
+  }
+}
+
 // The first HM_LDS_PHASES phases (up to 2357 buckets) run on LDS-resident arrays: a phase is eight block-wide passes with a
 // barrier between them, full of scattered accesses and atomics — one CU issues those ~30x faster to LDS than to L2/HBM.
 constexpr int HM_LDS_PHASES = 8;
@@ -582,14 +609,7 @@ __global__ __launch_bounds__(HM_T) void k_gs_hashorder(const GsHeader* __restric
       }
     }
     if (done) {
-      // lt[rank] = position in iteration order
-      for (int e = tid; e < n; e += HM_T) {
-        const int seg = ins_seg[o + e];
-        const int64_t dst = o + lt[e];
-        out_xyz[3 * dst + 0] = bary[3 * seg + 0];
-        out_xyz[3 * dst + 1] = bary[3 * seg + 1];
-        out_xyz[3 * dst + 2] = bary[3 * seg + 2];
-      }
+      hm_emit(lt, ins_seg, bary, out_xyz, o, n);
       return;
     }
     for (int e = tid; e < lo; e += HM_T) hm_t[o + e] = lt[e];
@@ -616,14 +636,7 @@ __global__ __launch_bounds__(HM_T) void k_gs_hashorder(const GsHeader* __restric
     lo = hi;
     if (hi >= n) break;
   }
-  // t[rank] = position in iteration order
-  for (int e = tid; e < n; e += HM_T) {
-    const int seg = ins_seg[o + e];
-    const int64_t dst = o + t[e];
-    out_xyz[3 * dst + 0] = bary[3 * seg + 0];
-    out_xyz[3 * dst + 1] = bary[3 * seg + 1];
-    out_xyz[3 * dst + 2] = bary[3 * seg + 2];
-  }
+  hm_emit(t, ins_seg, bary, out_xyz, o, n);
 }
 
 }  // namespace lcr
