@@ -16,6 +16,7 @@ import sys
 import time
 
 import numpy as np
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL across processes)
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
