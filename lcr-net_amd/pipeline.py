@@ -215,7 +215,7 @@ class PairPipeline:
     model, `workers` pairs in flight: one host thread + one HIP stream per worker, results handed back in input order.
 
     One pair is ~1000 short, dependent launches and four host round trips (NMS sizes, match counts, ...), i.e. bound by the host
-    and by launch latency, not by the GPU; a second pair in flight fills the gaps (81 -> 122 pairs/s on the demo pair).  More than
+    and by launch latency, not by the GPU; a second pair in flight fills the gaps (80 -> 100-120 pairs/s on the demo pair).  More than
     two workers lose to interpreter-lock contention (59 pairs/s with three)."""
 
     def __init__(self, model, voxel_size=0.3, radius=1.275, num_stages=4, neighbor_limits=(74, 68, 70, 67), workers=2):
