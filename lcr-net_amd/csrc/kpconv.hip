@@ -197,9 +197,10 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_cin1(const float* __re
     for (int k = 0; k < KP_K; ++k) wreg[q][k] = o < Cout ? W[k * Cout + o] : 0.f;
   }
   const float inv_sigma = 1.f / sigma;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * KP_WAVES;
-  int64_t t = static_cast<int64_t>(blockIdx.x) * KP_WAVES + w;
-  if (t >= M) return;                                   // wavefront-level synchronisation only below
+  const XcdBand band = xcd_band(M, w, KP_WAVES);         // a contiguous eighth of the (ordered) queries per XCD
+  const int64_t stride = band.stride, M_end = band.end;
+  int64_t t = band.begin;
+  if (t >= M_end) return;                               // wavefront-level synchronisation only below
   struct Row {
     int64_t m, j;
     float   qx, qy, qz;
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_cin1(const float* __re
     float f, x, y, z;
   };
   auto load_row = [&](int64_t tt, Row& r) {
-    const int64_t tc = tt < M ? tt : M - 1;             // beyond the end: a valid row whose values are never used
+    const int64_t tc = tt < M_end ? tt : M_end - 1;     // beyond the end of the band: a valid row whose values are never used
     r.m = order ? order[tc] : tc;
     r.qx = q_pts[3 * r.m];
     r.qy = q_pts[3 * r.m + 1];
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_cin1(const float* __re
   load_row(t, r0);
   gather(r0, n0);
   load_row(t + stride, r1);
-  for (; t < M; t += stride) {
+  for (; t < M_end; t += stride) {
     Row r2;
     gather(r1, n1);
     load_row(t + 2 * stride, r2);
@@ -439,7 +440,7 @@ extern "C" int lcr_kpconv_cin1(const float* s_feats, const float* q_pts, const f
   if (M == 0) return LCR_OK;
   const KPoints kp = load_kp(kernel_points_host);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  dim3 grid(grid_for(M, KP_WAVES)), block(KP_WAVES * 64);
+  dim3 grid(grid_for_xcd(M, KP_WAVES)), block(KP_WAVES * 64);
 #define LCR_CIN1(IDX, MAXO) \
   hipLaunchKernelGGL((k_kpconv_cin1<IDX, MAXO>), grid, block, 0, st, s_feats, q_pts, s_pts, static_cast<const IDX*>(idx), M, Ns, H, kp, sigma, W, bias, Cout, out, order)
   if (idx_is_64) {
