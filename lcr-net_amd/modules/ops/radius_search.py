@@ -98,8 +98,10 @@ class SupportGrid:
                    "lcr_support_grid_order")
         return out
 
-    def query(self, q_points, q_lengths, neighbor_limit, dtype=torch.int32, want_counts=False):
-        """[nq_cap, limit] indices (rows beyond sum(q_lengths) are left unwritten) and optionally the in-radius counts."""
+    def query(self, q_points, q_lengths, neighbor_limit, dtype=torch.int32, want_counts=False, q_order=None):
+        """[nq_cap, limit] indices (rows beyond sum(q_lengths) are left unwritten) and optionally the in-radius counts.
+        q_order (int32 [nq], a permutation of the query rows, e.g. the query set's own `order()`): processing order only —
+        the result is the same, spatially coherent wavefronts re-use their candidate cells from cache."""
         assert q_points.dtype == torch.float32 and q_points.is_contiguous() and q_lengths.numel() == self.B
         dev = q_points.device
         nq = q_points.shape[0]
@@ -107,7 +109,8 @@ class SupportGrid:
         out = torch.empty((nq, limit), dtype=dtype, device=dev) if limit > 0 else None
         cnt = torch.empty((nq,), dtype=torch.int32, device=dev) if (want_counts or limit == 0) else None
         o64, o32 = (out, None) if dtype == torch.int64 else (None, out)
-        _lib.check(_lib.lib().lcr_radius_query(_lib.ptr(q_points), _lib.ptr(q_lengths), self.B, nq, _lib.ptr(self.ws), self.ns_cap,
-                                               self.radius, limit, _lib.ptr(o64), _lib.ptr(o32), _lib.ptr(cnt), _lib.stream_ptr(dev)),
-                   "lcr_radius_query")
+        assert q_order is None or (q_order.dtype == torch.int32 and q_order.is_contiguous() and q_order.numel() >= nq)
+        _lib.check(_lib.lib().lcr_radius_query_ordered(_lib.ptr(q_points), _lib.ptr(q_lengths), self.B, nq, _lib.ptr(self.ws), self.ns_cap,
+                                                       self.radius, limit, _lib.ptr(o64), _lib.ptr(o32), _lib.ptr(cnt), _lib.ptr(q_order),
+                                                       _lib.stream_ptr(dev)), "lcr_radius_query")
         return (out, cnt) if (want_counts or limit == 0) else out

@@ -261,3 +261,25 @@ def test_registration_collate_precomputes_the_pair_stack(ops_golden):
     for key in ("points", "lengths", "neighbors", "subsampling", "upsampling"):
         for got_t, want_t in zip(dd[key], want[key]):
             assert np.array_equal(got_t.cpu().numpy(), want_t), key
+
+
+def test_radius_query_processing_order_does_not_change_the_result():
+    """lcr_radius_query_ordered: any permutation of the queries as processing order (cell order, reversed, random) gives the rows
+    of the unordered call, counts included; ragged clouds with an empty one."""
+    from lcrnet_amd.modules.ops import SupportGrid
+    rng = np.random.default_rng(11)
+    lens = np.array([3000, 0, 1, 2500], dtype=np.int64)
+    s = (rng.random((int(lens.sum()), 3)) * np.array([40, 40, 5])).astype(np.float32)
+    qlens = np.array([700, 0, 3, 900], dtype=np.int64)
+    q = np.concatenate([s[:700] + 0.01, s[3000:3001].repeat(3, 0), s[3001:3901] - 0.02]).astype(np.float32)
+    grid = SupportGrid(dev(s), dev(lens), 2.0)
+    base, base_cnt = grid.query(dev(q), dev(qlens), 40, want_counts=True)
+    want = oracle_ops.radius_search(q, s, qlens, lens, 2.0, 40)
+    assert np.array_equal(base.cpu().numpy(), want)
+    nq = len(q)
+    qgrid = SupportGrid(dev(q), dev(qlens), 2.0)
+    orders = [qgrid.order()[:nq].contiguous(), torch.arange(nq - 1, -1, -1, dtype=torch.int32, device="cuda"),
+              torch.from_numpy(rng.permutation(nq).astype(np.int32)).cuda()]
+    for od in orders:
+        got, cnt = grid.query(dev(q), dev(qlens), 40, want_counts=True, q_order=od)
+        assert torch.equal(got, base) and torch.equal(cnt, base_cnt)
