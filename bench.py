@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--no-upsampling", action="store_true", help="skip the 3 decoder-only upsampling searches")
     ap.add_argument("--no-overlap", action="store_true", help="run pre-processing and encoder on one stream (no pipelining)")
     ap.add_argument("--no-thread", action="store_true", help="two streams but a single host thread")
-    ap.add_argument("--pre-workers", type=int, default=1, help="host threads / streams pre-processing consecutive batches concurrently")
+    ap.add_argument("--pre-workers", type=int, default=2, help="host threads / streams pre-processing consecutive batches concurrently")
     ap.add_argument("--depth", type=int, default=2, help="batches pre-processed ahead of the encoder")
     ap.add_argument("--single-encoder", action="store_true", help="one encoder stream (default: consecutive batches alternate between two)")
     return ap.parse_args()

@@ -16,7 +16,7 @@ from .data import precompute_batch, precompute_batch_arena, voxelize_raw_scans
 
 class DescriptorPipeline:
     def __init__(self, model, voxel_size=0.3, radius=1.275, num_stages=4, neighbor_limits=(64, 65, 74, 80), upsampling=False,
-                 raw_voxel=None, overlap=True, producer_thread=True, depth=2, pre_workers=1):
+                 raw_voxel=None, overlap=True, producer_thread=True, depth=2, pre_workers=2):
         """raw_voxel: voxel size of the raw-scan ingest step (None = inputs are already voxelised like the reference's
         downsampled .npy scans; 0.3 = BASELINE configs[1]).  upsampling: also compute the 3 decoder-only upsampling lists."""
         self.model = model
@@ -25,11 +25,16 @@ class DescriptorPipeline:
         self.upsampling, self.raw_voxel, self.overlap = upsampling, raw_voxel, overlap
         dev = next(model.parameters()).device
         self.device = dev
-        # the pre-processing chain is latency-bound (hundreds of dependent short launches): give it the high-priority queue so
-        # that its launches are not parked behind the encoder's long kernels
-        prio = -1 if os.environ.get("LCR_PRE_PRIORITY", "1") != "0" else 0
+        # The pre-processing chain is latency-bound (~130 dependent short launches per batch).  With ONE chain in flight it needs the
+        # high-priority queue so that its launches are not parked behind the encoder's long kernels (+9..27 %).  Two chains in
+        # flight (consecutive batches on two host threads / streams) hide that latency better — but only at NORMAL priority: two
+        # queues of the same elevated priority run pathologically slowly on this stack (one batch 3.9 ms instead of 1.8, even on an
+        # otherwise idle GPU), which is what made the second worker look like a loss at first.  2 workers at normal priority:
+        # 2.17 -> 2.31 k scans/s; a third (2.27) or a third encoder stream (2.13) loses again.
+        self.producer_thread, self.depth, self.pre_workers = producer_thread, depth, max(1, int(pre_workers))
+        default_prio = "1" if (self.pre_workers == 1 or not producer_thread) else "0"
+        prio = -1 if os.environ.get("LCR_PRE_PRIORITY", default_prio) != "0" else 0
         self.pre_stream = torch.cuda.Stream(dev, priority=prio) if overlap else None
-        self.producer_thread, self.depth, self.pre_workers = producer_thread, depth, pre_workers
         self.stats = {"pre_wait_s": 0.0, "pre_busy_s": 0.0, "enc_wait_s": 0.0, "batches": 0}   # where the two host threads wait
         self._ones_buf = None
         self.enc_streams = None      # set by enable_dual_encoder(): consecutive batches' encoders on alternating streams
