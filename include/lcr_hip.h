@@ -39,6 +39,10 @@ const char* lcr_last_error(void);
  * the logged events and returns the number of records of `kind`. */
 void lcr_ktimer_enable(int on);
 int lcr_ktimer_read(int kind, int max_records, double* seconds, int64_t* meta);
+/* Diagnostic: one wavefront spinning for `microseconds` on `stream`.  The runtime deals streams to 4 hardware queues; two busy
+ * streams on one queue serialise each other.  A short kernel on stream B behind a spin on stream A tells whether A and B share
+ * a queue (lcr-net_amd/pipeline.py picks four streams on four queues this way). */
+int lcr_debug_spin(int microseconds, void* stream);
 int lcr_version(void);
 
 /* ------------------------------------------------------------------------------------------------

@@ -25,6 +25,7 @@ _SIGS = {
     "lcr_precompute_layout": (c_int, [c_i64, c_int, c_int, c_vp, c_int, c_i64, c_vp]),
     "lcr_precompute_batch": (c_int, [c_vp, c_vp, c_vp, c_float, c_float, c_float, c_int, c_vp, c_size_t, c_vp, c_size_t, c_vp, c_vp, c_vp]),
     "lcr_radius_query": (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_i64, c_float, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "lcr_debug_spin": (c_int, [c_int, c_vp]),
     "lcr_radius_query_ordered": (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_i64, c_float, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "lcr_radius_search_ws_bytes": (c_int, [c_i64, c_i64, c_int, c_size_p]),
     "lcr_radius_search": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_float, c_int, c_vp, c_vp, c_vp, c_vp,

@@ -265,6 +265,18 @@ int exclusive_scan_i32_dev(const int32_t* in, int32_t* out, int64_t n, const int
 
 extern "C" const char* lcr_last_error(void) { return lcr::g_err; }
 
+// One wavefront that spins for `microseconds` (constant 100 MHz wall clock).  Used by the host side to find out which streams
+// share a hardware queue: a short kernel on another stream finishes immediately unless it sits behind this one in the same queue.
+__global__ void k_spin(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+extern "C" int lcr_debug_spin(int microseconds, void* stream) {
+  if (microseconds < 0 || microseconds > 100000) return LCR_EARG;
+  hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<long long>(microseconds) * 100);
+  return hipGetLastError() == hipSuccess ? LCR_OK : LCR_EHIP;
+}
+
 extern "C" void lcr_ktimer_enable(int on) {
   std::lock_guard<std::mutex> lk(lcr::g_kt_mu);
   if (on) {

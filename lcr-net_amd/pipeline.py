@@ -14,6 +14,75 @@ import torch
 from .data import precompute_batch, precompute_batch_arena, voxelize_raw_scans
 
 
+def _native_streams(device, n, priority=0):
+    """n HIP streams created back to back, wrapped for torch."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    out = []
+    with torch.cuda.device(device):
+        for _ in range(n):
+            h = ctypes.c_void_p()
+            rc = hip.hipStreamCreateWithPriority(ctypes.byref(h), 1, int(priority))      # hipStreamNonBlocking
+            if rc != 0:
+                raise RuntimeError("hipStreamCreateWithPriority failed: %d" % rc)
+            out.append(torch.cuda.ExternalStream(h.value, device=device))
+    return out
+
+
+def _share_queue(a, b, spin_us=400):
+    """True if streams a and b are served by the same hardware queue: a short kernel on b behind a long spin on a."""
+    import ctypes
+    from . import _lib
+    L = _lib.lib()
+    best = None
+    for _ in range(3):                                                     # the shortest of three trials: a cold launch, a clock
+        a.synchronize()                                                    # ramp or another process's kernel can only ADD time
+        b.synchronize()
+        t0, tb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record(b)                                                       # b's clock starts before a's spin is queued
+        _lib.check(L.lcr_debug_spin(spin_us, ctypes.c_void_p(a.cuda_stream)), "lcr_debug_spin")
+        _lib.check(L.lcr_debug_spin(1, ctypes.c_void_p(b.cuda_stream)), "lcr_debug_spin")
+        tb.record(b)
+        a.synchronize()
+        b.synchronize()
+        us = t0.elapsed_time(tb) * 1e3
+        best = us if best is None else min(best, us)
+        if best < 0.5 * spin_us:
+            return False
+    return True
+
+
+def distinct_queue_streams(device, n, priority=0, pool=10):
+    """n streams on n DIFFERENT hardware queues (as far as the runtime has them; 4 by default).
+
+    The runtime deals streams to its hardware queues by an internal schedule that depends on every stream created in the process
+    before (torch's pool, RCCL, ...), and two BUSY streams on one queue serialise each other: with the pipeline's four streams on
+    four queues 2.3 k scans/s, with both encoder streams on one queue 1.9 k, with each encoder stream behind a pre-processing chain
+    1.8 k (rocprofv3 queue ids; shifting the creation order by one dummy stream was enough to fall from one case into the other).
+    So a small pool is created and probed pairwise (`_share_queue`, ~1 ms per probe) and the first n mutually non-sharing streams
+    are kept; if fewer exist, the pool order fills the rest."""
+    if os.environ.get("LCR_NO_QUEUE_PROBE"):
+        return _native_streams(device, n, priority)
+    cand = _native_streams(device, max(pool, n), priority)
+    import ctypes
+    from . import _lib
+    for c in cand:                                        # first launch on every candidate (code object load, queue creation)
+        _lib.check(_lib.lib().lcr_debug_spin(1, ctypes.c_void_p(c.cuda_stream)), "lcr_debug_spin")
+    torch.cuda.synchronize(device)
+    chosen = []
+    for c in cand:
+        if len(chosen) == n:
+            break
+        if all(not _share_queue(x, c) for x in chosen):
+            chosen.append(c)
+    for c in cand:
+        if len(chosen) == n:
+            break
+        if c not in chosen:
+            chosen.append(c)
+    return chosen
+
+
 class DescriptorPipeline:
     def __init__(self, model, voxel_size=0.3, radius=1.275, num_stages=4, neighbor_limits=(64, 65, 74, 80), upsampling=False,
                  raw_voxel=None, overlap=True, producer_thread=True, depth=2, pre_workers=2):
@@ -34,7 +103,15 @@ class DescriptorPipeline:
         self.producer_thread, self.depth, self.pre_workers = producer_thread, depth, max(1, int(pre_workers))
         default_prio = "1" if (self.pre_workers == 1 or not producer_thread) else "0"
         prio = -1 if os.environ.get("LCR_PRE_PRIORITY", default_prio) != "0" else 0
-        self.pre_stream = torch.cuda.Stream(dev, priority=prio) if overlap else None
+        # all streams of the pipeline are created ONCE, here: W pre-processing + 2 encoder streams on distinct hardware queues
+        if not overlap:
+            self._streams = []
+        elif prio == 0:
+            self._streams = distinct_queue_streams(dev, self.pre_workers + 2, 0)
+        else:                                             # elevated pre-processing streams live in their own queue class
+            self._streams = _native_streams(dev, self.pre_workers, prio) + distinct_queue_streams(dev, 2, 0)
+        self.pre_stream = self._streams[0] if overlap else None
+        self.pre_streams = self._streams[:self.pre_workers] if (overlap and producer_thread) else []
         self.stats = {"pre_wait_s": 0.0, "pre_busy_s": 0.0, "enc_wait_s": 0.0, "batches": 0}   # where the two host threads wait
         self._ones_buf = None
         self.enc_streams = None      # set by enable_dual_encoder(): consecutive batches' encoders on alternating streams
@@ -42,7 +119,8 @@ class DescriptorPipeline:
     def enable_dual_encoder(self, n=2):
         """Run the encoders of consecutive batches on two alternating streams so that the small-grid kernels of one (stage-3/4
         GEMMs, GroupNorm, NetVLAD) fill the gaps of the other.  Results are handed back in order on the caller's stream."""
-        self.enc_streams = [torch.cuda.Stream(self.device) for _ in range(n)]
+        own = self._streams[self.pre_workers:self.pre_workers + n]
+        self.enc_streams = own + [torch.cuda.Stream(self.device) for _ in range(n - len(own))]
         return self
 
     # ---- stages -----------------------------------------------------------------------------------------------------
@@ -79,15 +157,20 @@ class DescriptorPipeline:
             return self.model(dd)["anc_global"]
 
     # ---- driver -----------------------------------------------------------------------------------------------------
-    def run(self, batches):
+    def run(self, batches, sync_to_caller=True):
         """batches: iterable of (points, lengths) device tensors.  Yields one [B,256] descriptor tensor per batch, in order.
-        The yielded tensor is valid on the CURRENT stream (the consumer may use it without further synchronisation)."""
+        sync_to_caller=True: the yielded tensor is valid on the CURRENT stream (the consumer may use it without further
+        synchronisation).  sync_to_caller=False (threaded two-encoder mode): yields (descriptors, done_event, stream) and never
+        enqueues a wait on the caller's stream — a consumer that keeps working on the producing stream (e.g. an all-gather issued
+        under `torch.cuda.stream(stream)`) then leaves the caller's hardware queue free of barrier packets: that queue is shared with
+        one of the pipeline's four streams (5 streams, 4 hardware queues), and a wait-for-the-encoder parked in it stalls whatever
+        else runs there."""
         if not self.overlap:
             for pts, lens in batches:
                 yield self.encode(self.preprocess(pts, lens))
             return
         if self.producer_thread:
-            yield from self._run_threaded(batches)
+            yield from self._run_threaded(batches, sync_to_caller)
             return
         main = torch.cuda.current_stream(self.device)
         pre = self.pre_stream
@@ -117,7 +200,7 @@ class DescriptorPipeline:
             main.wait_event(ready)
             yield self.encode(dd)
 
-    def _run_threaded(self, batches):
+    def _run_threaded(self, batches, sync_to_caller=True):
         """Same overlap, but the pre-processing (whose two length read-backs block the host) runs in its own host thread(s),
         `depth` batches ahead, so the encoder stream never waits for the host to come back from a synchronisation.  ctypes
         releases the GIL during every kernel launch / synchronisation, so the threads do interleave.  With `pre_workers` > 1,
@@ -128,7 +211,7 @@ class DescriptorPipeline:
         main = torch.cuda.current_stream(self.device)
         dev = self.device
         W = max(1, int(self.pre_workers))
-        streams = [self.pre_stream] + [torch.cuda.Stream(dev, priority=self.pre_stream.priority) for _ in range(W - 1)]
+        streams = self.pre_streams[:W]
         for st in streams:
             st.wait_stream(main)
         out = queue.Queue()
@@ -202,11 +285,14 @@ class DescriptorPipeline:
                     desc = self.encode(dd)
                     done = torch.cuda.Event()
                     done.record(es)
-                desc.record_stream(main)
-                if pending is not None:
-                    main.wait_event(pending[1])
-                    yield pending[0]
-                pending = (desc, done)
+                if not sync_to_caller:
+                    yield (desc, done, es)
+                else:
+                    desc.record_stream(main)
+                    if pending is not None:
+                        main.wait_event(pending[1])
+                        yield pending[0]
+                    pending = (desc, done)
             k += 1
         if pending is not None:
             main.wait_event(pending[1])
