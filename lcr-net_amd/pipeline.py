@@ -339,10 +339,14 @@ class PairPipeline:
         out = queue.Queue()
         slots = threading.Semaphore(2 * self.workers)       # finished pairs not yet consumed
 
+        worker_streams = distinct_queue_streams(dev, self.workers)      # two busy streams on one hardware queue serialise each other
+        stream_it = iter(worker_streams)
+
         def worker():
             try:
                 torch.cuda.set_device(dev)
-                st = torch.cuda.Stream(dev)
+                with it_lock:
+                    st = next(stream_it)
                 st.wait_stream(main)
                 with torch.cuda.stream(st):
                     while True:
