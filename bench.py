@@ -4,20 +4,30 @@
 One step = one batch of 8 synthetic 64-beam scans (~120 k points each, already resident in HBM) through the whole path:
 0.3 m voxelisation (a-1) -> 3 grid subsamples + 10 radius searches (a-1/a-2/a-3) -> KPConv encoder (a-4..a-6) ->
 NetVLAD (a-7) -> 8 unit-norm 256-D descriptors.  Weights: seeded random in the reference checkpoint layout (no checkpoint
-in the containers).  N GPUs = N ranks, each with its own batch (scan-parallel, weak scaling), descriptors all-gathered
-over RCCL inside the timed region (the exchange step of the retrieval).
+in the containers).  N GPUs = N ranks (one process per GPU), each with its own batch (scan-parallel, weak scaling),
+descriptors all-gathered over RCCL inside the timed region (the exchange step of the retrieval; the reference's
+multi-process entry is utils/engine/base_tester.py:88).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+
+Launch forms: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the ranks come from the
+environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  A bare `python bench.py --gpus N` with N > 1 starts the N rank
+processes itself (same environment contract, 127.0.0.1 rendezvous) and rank 0 prints the line with `n_gpus: N`.
+`LCR_BENCH_SINGLE_DEVICE=1` puts every rank on GPU 0 (dry run of the N-rank code path on a 1-GPU box; backend from
+`LCR_BENCH_BACKEND`, default gloo there because RCCL refuses two ranks on one device).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 import numpy as np
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL across processes)
-import torch
+_PRE_WORKER = "--cpu-worker" in sys.argv and sys.argv[sys.argv.index("--cpu-worker") + 1] == "pre"
+if not _PRE_WORKER:                                        # a pre-processing-only CPU worker is numpy + ctypes only
+    import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -28,12 +38,13 @@ VOXEL, RADIUS, NUM_STAGES = 0.3, 1.275, 4
 LIMITS = [64, 65, 74, 80]          # reference training/eval default (dataset_loop_detection.py:25,80)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3           # dense fp32 MFMA/vector peak
+PMC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # written by tools/pmc_summary.py from separate rocprofv3 --pmc passes
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-upsampling", action="store_true", help="skip the 3 decoder-only upsampling searches")
@@ -42,60 +53,154 @@ def parse():
     ap.add_argument("--pre-workers", type=int, default=2, help="host threads / streams pre-processing consecutive batches concurrently")
     ap.add_argument("--depth", type=int, default=2, help="batches pre-processed ahead of the encoder")
     ap.add_argument("--single-encoder", action="store_true", help="one encoder stream (default: consecutive batches alternate between two)")
+    ap.add_argument("--cpu-worker", nargs=4, metavar=("MODE", "SCAN", "THREADS", "START"), help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
 def make_batch(rank):
     import lcrnet_amd.synthetic as synthetic
-    scans = [synthetic.synthetic_scan(rank * BATCH + i) for i in range(BATCH)]
-    return scans
+    return [synthetic.synthetic_scan(rank * BATCH + i) for i in range(BATCH)]
 
 
-
-def cpu_baseline(scans, n_scans=2):
-    """The same path on host cores: native ops from the compiled reference when oracle/_ref is present (else the C++
-    restatement), encoder + NetVLAD from the torch fp32 restatement.  Bounded sample, rank 0 only."""
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1 only): the same path on the host cores of this box.  SURVEY §8d: pre-processing only and end to end,
+# at 1 core and at all cores with ONE SCAN PER PROCESS (pre-processing: one single-thread process per core; end to end: one
+# 8-thread process per 8 cores) (the reference's own parallelism: DataLoader worker processes,
+# config_ld.py:42).  Native ops = the reference's C++ compiled from source (oracle/_ref) when present, else the C++ restatement;
+# encoder + NetVLAD = the torch fp32 restatement.  Each worker is a fresh interpreter (no fork of a process that owns a GPU).
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_worker(mode, scan_path, threads, start_at):
+    """One scan, `mode` in {pre, e2e}, on `threads` torch threads, starting at wall-clock `start_at`.  Prints seconds from
+    start_at to completion (a worker that is not ready in time is charged for its lateness)."""
+    threads = int(threads)
+    if mode == "e2e":
+        torch.set_num_threads(threads)
     from oracle import ops as oracle_ops
-    from oracle import torch_ref
-    from lcrnet_amd.model_family import create_model
-    from lcrnet_amd.weights import seeded_state_dict
     impl = "ref" if oracle_ops.have_ref() else "oracle"
-    m = create_model()
-    sd = seeded_state_dict(m.state_dict(), 7351)
-    threads = torch.get_num_threads()
-    t_pre = t_enc = 0.0
-    t0 = time.time()
-    with torch.no_grad():
-        for raw in scans[:n_scans]:
-            t = time.time()
-            p, l = oracle_ops.grid_subsample(raw, np.array([len(raw)]), VOXEL, impl=impl)
-            st = oracle_ops.precompute_data_stack_mode(p, l, NUM_STAGES, VOXEL, RADIUS, LIMITS, impl=impl)
-            t_pre += time.time() - t
-            t = time.time()
+    raw = np.load(scan_path)
+    sd = None
+    if mode == "e2e":
+        from oracle import torch_ref
+        from lcrnet_amd.model_family import create_model
+        from lcrnet_amd.weights import seeded_state_dict
+        sd = seeded_state_dict(create_model().state_dict(), 7351)
+    oracle_ops.grid_subsample(raw[:1000], np.array([1000]), VOXEL, impl=impl)     # library loaded before the clock starts
+    start_at = float(start_at)
+    while time.time() < start_at:
+        time.sleep(0.001)
+    p, l = oracle_ops.grid_subsample(raw, np.array([len(raw)]), VOXEL, impl=impl)
+    st = oracle_ops.precompute_data_stack_mode(p, l, NUM_STAGES, VOXEL, RADIUS, LIMITS, impl=impl)
+    if mode == "e2e":
+        with torch.no_grad():
             dd = {k: [torch.from_numpy(np.ascontiguousarray(x)) for x in v] for k, v in st.items()}
             feats = torch_ref.kp_encoder(sd, torch.ones(len(p), 1), dd)
             torch_ref.global_descriptor(sd, feats[-1])
-            t_enc += time.time() - t
-    dt = time.time() - t0
-    return {"value": round(n_scans / dt, 4), "unit": "scans/s", "cores": threads,
-            "kind": "reference" if impl == "ref" else "port",
-            "sample": "%d of the %d scans of this batch, end to end; native ops: %s (1 thread, %.2f s/scan); encoder+NetVLAD: torch fp32 "
-                      "restatement on %d threads (%.2f s/scan)" % (n_scans, BATCH, "reference C++ compiled from source (oracle/_ref)"
-                                                                    if impl == "ref" else "oracle C++ restatement", t_pre / n_scans,
-                                                                    threads, t_enc / n_scans)}
+    print(json.dumps({"seconds": time.time() - start_at, "impl": impl}))
+
+
+def _run_cpu_workers(mode, scan_paths, procs, threads, lead):
+    start_at = time.time() + lead
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
+    ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", mode, scan_paths[i % len(scan_paths)], str(threads),
+                            repr(start_at)], stdout=subprocess.PIPE, env=env, cwd=ROOT) for i in range(procs)]
+    outs = [json.loads(p.communicate()[0].decode().strip().splitlines()[-1]) for p in ps]
+    wall = max(o["seconds"] for o in outs)
+    return procs / wall, wall, outs[0]["impl"]
+
+
+def cpu_baseline(scans):
+    import tempfile
+    cores = os.cpu_count() or 1
+    try:
+        import psutil
+        avail_gb = psutil.virtual_memory().available / 2**30
+    except Exception:
+        avail_gb = 64.0
+    tmp = tempfile.mkdtemp(prefix="lcr_cpu_")
+    paths = []
+    for i, s in enumerate(scans):
+        paths.append(os.path.join(tmp, "scan%d.npy" % i))
+        np.save(paths[-1], s)
+    lead1 = 6.0                                                       # interpreter + torch import + weights before the clock starts
+    leadN = 8.0 + 0.15 * cores
+    pre1, _, impl = _run_cpu_workers("pre", paths, 1, 1, 2.0)        # numpy + ctypes only: short lead
+    preN, pre_wall, _ = _run_cpu_workers("pre", paths, cores, 1, 3.0 + 0.05 * cores)
+    e1, e1_wall, _ = _run_cpu_workers("e2e", paths, 1, 1, lead1)
+    # end to end on all cores: processes of 8 torch threads each, one scan per process — the reference's own shape (torch intra-op
+    # threads for the model next to its DataLoader workers).  Measured on the 256-core GPU box: 256 single-thread processes reach
+    # only 2.7 scans/s (5.6x one core: the fp32 encoder is memory-bound and 256 private copies of its ~1.5 GB of intermediates
+    # thrash the caches), so that split is not used.
+    thr = min(8, cores)
+    procs = int(max(1, min(cores // thr, avail_gb // 3)))
+    eN, eN_wall, _ = _run_cpu_workers("e2e", paths, procs, thr, leadN)
+    for p in paths:
+        os.remove(p)
+    os.rmdir(tmp)
+    kind = "reference" if impl == "ref" else "port"
+    return {"value": round(eN, 4), "unit": "scans/s", "cores": cores, "kind": kind,
+            "sample": "end to end (voxelise + collate + encoder + NetVLAD), all %d cores: %d processes x %d torch thread(s), one scan each, "
+                      "%.1f s wall.  native ops: %s; encoder+NetVLAD: torch fp32 restatement" %
+                      (cores, procs, thr, eN_wall, "reference C++ compiled from source (oracle/_ref)" if impl == "ref" else "oracle C++ restatement"),
+            "end_to_end": {"one_core_scans_per_s": round(e1, 4), "all_cores_scans_per_s": round(eN, 4), "processes": procs, "threads_per_process": thr,
+                           "one_core_s_per_scan": round(e1_wall, 3)},
+            "preprocessing_only": {"one_core_scans_per_s": round(pre1, 4), "all_cores_scans_per_s": round(preN, 4), "processes": cores,
+                                   "all_cores_wall_s": round(pre_wall, 3),
+                                   "what": "0.3 m voxelisation + 3 subsamples + 10 radius searches of one 120k-pt scan, one scan per process"}}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes (one per GPU) with the torchrun environment
+    contract and wait for them; rank 0's JSON line goes to this process's stdout."""
+    import socket
+    n = args.gpus
+    if not os.environ.get("LCR_BENCH_SINGLE_DEVICE"):
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.exit("bench.py: --gpus %d but %d GPU(s) visible (LCR_BENCH_SINGLE_DEVICE=1 runs every rank on GPU 0 as a dry run)" % (n, have))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    sys.exit(rc)
+
+
+def search_bytes(stage_points, upsampling):
+    """SURVEY §8d a-2, int32 indices: (Nq + Ns) * 12 B + Nq * limit * 4 B for each of the 10 (7) searches of one batch."""
+    n, tot = stage_points, 0
+    for i in range(NUM_STAGES):
+        tot += 2 * n[i] * 12 + n[i] * LIMITS[i] * 4
+        if i + 1 < NUM_STAGES:
+            tot += (n[i + 1] + n[i]) * 12 + n[i + 1] * LIMITS[i] * 4
+            if upsampling:
+                tot += (n[i] + n[i + 1]) * 12 + n[i] * LIMITS[i + 1] * 4
+    return tot
 
 
 def main():
     args = parse()
+    if args.cpu_worker:
+        return cpu_worker(*args.cpu_worker)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("LCR_BENCH_BACKEND", "nccl")         # "nccl" is RCCL on ROCm; "gloo" only for dry runs
-        if os.environ.get("LCR_BENCH_SINGLE_DEVICE"):                  # dry run of the N>1 code path on a 1-GPU box
+        single = bool(os.environ.get("LCR_BENCH_SINGLE_DEVICE"))          # dry run of the N>1 code path on a 1-GPU box
+        backend = os.environ.get("LCR_BENCH_BACKEND", "gloo" if single else "nccl")   # "nccl" is RCCL on ROCm
+        if single:
             local = 0
         torch.cuda.set_device(local)
         if backend == "nccl":
@@ -144,7 +249,7 @@ def main():
     run_steps(args.warmup)
     stage_points = [sum(l) for l in pipe.preprocess(raw_pts, raw_lens)["lengths_host"]]
     # ---- timed region: exactly K steps between barrier + synchronize
-    timer = F.KernelTimer({"kpconv_aggregate", "gemm"})
+    timer = F.KernelTimer({"kpconv_aggregate", "gemm", "radius_query"})
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -163,50 +268,64 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    iso = None
+    iso = iso_rs = None
     summ = timer.summary() if rank == 0 else None     # read the timed region's log before anything else is logged
     if rank == 0:
-        # the same GEMM launches once more with nothing else on the GPU (one stream, outside the timed region): in the timed
-        # region three streams share the CUs, so a launch's event-to-event duration includes time it spent waiting for them
-        iso_timer = F.KernelTimer({"gemm"})
+        # the same launches once more with nothing else on the GPU (one stream, outside the timed region): in the timed
+        # region four streams share the CUs, so a launch's event-to-event duration includes time it spent waiting for them
+        iso_timer = F.KernelTimer({"gemm", "radius_query"})
         dd_iso = pipe.preprocess(raw_pts, raw_lens)
         pipe.encode(dd_iso)
         torch.cuda.synchronize()
         F.set_timer(iso_timer)
         for _ in range(3):
+            dd_iso = pipe.preprocess(raw_pts, raw_lens)
             pipe.encode(dd_iso)
         torch.cuda.synchronize()
         F.set_timer(None)
-        g = iso_timer.summary()["gemm"]
+        s_iso = iso_timer.summary()
+        g = s_iso["gemm"]
         iso = sum(2.0 * m[0] * m[1] * m[2] for _, m in g) / sum(t for t, _ in g) / 1e12
+        iso_rs = sum(t for t, _ in s_iso["radius_query"]) / 3.0
     if rank == 0:
         assert torch.isfinite(desc).all() and abs(float(desc.norm(dim=1).mean()) - 1.0) < 1e-3
         # ---- roofline of the dominant kernel family, measured live with HIP events on the launch stream.
-        # Dominant by time = lcr::k_gemm_f32 (all tile variants; ~30 % of the step, profiles/): compute-bound on the fp32
-        # matrix cores, so "achieved" = algorithmic flops (2*M*N*K per launch) / launch time vs the 157.3 TFLOP/s
-        # dense fp32 MFMA peak.  HBM traffic per launch comes from the committed rocprofv3 PMC passes (profiles/*pmc*.json).
-        gem, agg = summ["gemm"], summ["kpconv_aggregate"]
-        t_gemm, t_agg = sum(t for t, _ in gem), sum(t for t, _ in agg)
+        # Dominant by time = lcr::k_gemm_f32 (all tile variants; profiles/): compute-bound on the fp32 matrix cores, so
+        # "achieved" = algorithmic flops (2*M*N*K per launch) / launch time vs the 157.3 TFLOP/s dense fp32 MFMA peak.
+        gem, agg, rsq = summ["gemm"], summ["kpconv_aggregate"], summ["radius_query"]
+        t_gemm, t_agg, t_rs = sum(t for t, _ in gem), sum(t for t, _ in agg), sum(t for t, _ in rsq)
         flops = sum(2.0 * m[0] * m[1] * m[2] for _, m in gem)
-
-        def agg_bytes(m):   # indices + query/support xyz + support features + pos flags + the (M,15C) output + counts
-            M, Ns, H, C, isz = m
-            return M * H * isz + (M + Ns) * 12 + Ns * C * 4 + Ns + M * 15 * C * 4 + M * 4
-        bytes_agg = sum(agg_bytes(m) for _, m in agg)
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("k_gemm_f32", {}).get("traffic_bytes")
+        # KPConv layer = aggregation + its (15C x Cout) contraction, against SURVEY §8d's a-4 bytes: indices + query/support xyz +
+        # support features + OUTPUT features + weights (the materialised (M,15C) aggregate is NOT algorithmic traffic)
+        contr = [(t, m) for t, m in gem if m[2] % 15 == 0 and m[2] >= 480]
+        bytes_kp = sum(M * H * isz + (M + Ns) * 12 + Ns * C * 4 for _, (M, Ns, H, C, isz) in agg) + \
+            sum(M * N * 4 + K * N * 4 for _, (M, N, K) in contr)
+        t_kp = t_agg + sum(t for t, _ in contr)
+        n_search = 7 if args.no_upsampling else 10
+        bytes_rs = search_bytes(stage_points, not args.no_upsampling)
+        traffic, traffic_src = None, None
+        if os.path.exists(PMC_JSON):
+            traffic = json.load(open(PMC_JSON)).get("k_gemm_f32", {}).get("traffic_bytes")
+            traffic_src = "profiles/pmc_traffic.json: separate rocprofv3 --pmc passes of this command (2*FETCH_SIZE + WRITE_SIZE per launch), not measured in this run"
         roof = {"bound": "mfma", "kernel": "lcr::k_gemm_f32 (fp32 MFMA, %d launches/step)" % (len(gem) // max(args.steps, 1)),
                 "achieved": round(flops / t_gemm / 1e12, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(flops / t_gemm / 1e12 / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
+                "frac": round(flops / t_gemm / 1e12 / FP32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "achieved_alone": round(iso, 2), "frac_alone": round(iso / FP32_PEAK_TFLOPS, 4),
                 "avg_launch_us": round(t_gemm / max(len(gem), 1) * 1e6, 2),
                 "gflop_per_launch": round(flops / max(len(gem), 1) / 1e9, 3),
-                "share_of_step": {"gemm": round(t_gemm / dt, 3), "kpconv_aggregate": round(t_agg / dt, 3)},
-                "secondary": {"kernel": "lcr::k_kpconv_aggregate", "bound": "hbm", "achieved": round(bytes_agg / t_agg / 1e9, 1),
-                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bytes_agg / t_agg / 1e9 / HBM_PEAK_GBS, 4),
-                              "avg_launch_us": round(t_agg / max(len(agg), 1) * 1e6, 2)}}
+                "share_of_step": {"gemm": round(t_gemm / dt, 3), "kpconv_aggregate": round(t_agg / dt, 3), "radius_query": round(t_rs / dt, 3)},
+                "neighbor": {"kernel": "lcr::k_radius_query (%d searches/step)" % n_search, "bound": "hbm",
+                             "algorithmic_mb_per_step": round(bytes_rs / 1e6, 2),
+                             "achieved": round(bytes_rs * args.steps / t_rs / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(bytes_rs * args.steps / t_rs / 1e9 / HBM_PEAK_GBS, 4),
+                             "ms_per_step": round(t_rs / args.steps * 1e3, 4),
+                             "achieved_alone": round(bytes_rs / iso_rs / 1e9, 1), "frac_alone": round(bytes_rs / iso_rs / 1e9 / HBM_PEAK_GBS, 4),
+                             "ms_per_step_alone": round(iso_rs * 1e3, 4)},
+                "secondary": {"kernel": "KPConv layers: lcr::k_kpconv_aggregate + its (15C x Cout) contraction", "bound": "hbm",
+                              "achieved": round(bytes_kp / t_kp / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(bytes_kp / t_kp / 1e9 / HBM_PEAK_GBS, 4),
+                              "algorithmic_mb_per_step": round(bytes_kp / args.steps / 1e6, 1),
+                              "ms_per_step": round(t_kp / args.steps * 1e3, 3)}}
         line = {
             "metric": "scans/s (120k-pt KITTI-shape scan -> 256-D descriptor)",
             "value": round(world * BATCH * args.steps / dt, 3), "unit": "scans/s", "n_gpus": world, "steps": args.steps,
@@ -214,17 +333,18 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: batch of 8 synthetic 64-beam scans (~120k pts, 0.3 m voxel -> ~16k pts), "
                                    "voxelise + 3 subsamples + %d radius searches + KPConv encoder + NetVLAD, seeded random weights"
-                                   % (7 if args.no_upsampling else 10),
+                                   % n_search,
                        "scans_per_step_per_gpu": BATCH, "raw_points_per_scan": int(raw_pts.shape[0] // BATCH),
                        "stage_points_per_batch": stage_points, "neighbor_limits": LIMITS,
                        "streams": "1" if args.no_overlap else ("pre-processing stream (own host thread, 2 batches ahead) + %d encoder stream(s)"
                                                                % (1 if (args.single_encoder or args.no_thread) else 2)),
-                       "parallelism": "scan-parallel x%d, all-gather of descriptors" % world},
+                       "parallelism": "scan-parallel x%d, all-gather of descriptors%s" % (world, (" (%s)" % backend) if backend else "")},
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(scans)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
+    pipe.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -75,17 +75,25 @@ static GridLayout grid_layout(void* ws, int64_t ns_cap, int B) {
 __global__ void k_grid_init(GridHeader* h, const int64_t* __restrict__ slen, int B, int64_t ns_cap, int64_t cell_cap,
                             uint32_t* status) {
   if (threadIdx.x == 0) {
+    // offsets clamped to the capacity (like k_gs_init): on an overrun — the expected raw-mode path when the capacity guess was too
+    // small — the clouds beyond the cap become empty, every per-cloud cell budget stays inside cell_cap, and the host retries
+    // after reading the status word
     int64_t o = 0;
+    bool bad = false;
     for (int b = 0; b < B; ++b) {
-      h->s_off[b] = o;
-      o += slen[b];
+      h->s_off[b] = o < ns_cap ? o : ns_cap;
+      const int64_t l = slen[b];
+      bad |= l < 0;
+      o += l > 0 ? l : 0;
     }
-    h->s_off[B] = o;
-    h->ns_total = o;
+    bad |= o > ns_cap;
+    const int64_t tot = o < ns_cap ? o : ns_cap;
+    h->s_off[B] = tot;
+    h->ns_total = tot;
     h->B = B;
     h->ns_cap = ns_cap;
     h->cell_cap = cell_cap;
-    if (o > ns_cap && status) atomicOr(status, LCR_STATUS_LEN_MISMATCH);
+    if (bad && status) atomicOr(status, LCR_STATUS_LEN_MISMATCH);
   }
   for (int b = threadIdx.x; b < B; b += blockDim.x)
     for (int d = 0; d < 3; ++d) {
@@ -135,9 +143,15 @@ __global__ void k_grid_params(GridHeader* h, float radius) {
       if (tot <= budget) break;
       cell *= fmax(cbrt(tot / budget), 1.0) * 1.02;
     }
+    const int64_t cells = static_cast<int64_t>(dim[0]) * dim[1] * dim[2];
+    if (base + cells > h->cell_cap) {          // cannot happen with clamped offsets (sum of budgets == cell_cap); never write past the arrays
+      c.dim[0] = c.dim[1] = c.dim[2] = 0;
+      c.inv_cell = 0.0;
+      continue;
+    }
     for (int d = 0; d < 3; ++d) c.dim[d] = dim[d];
     c.inv_cell = 1.0 / cell;
-    base += dim[0] * dim[1] * dim[2];
+    base += static_cast<int>(cells);
   }
   h->n_cells = base;
 }
@@ -446,6 +460,7 @@ extern "C" int lcr_radius_query_ordered(const float* q, const int64_t* qlen, int
   // workgroup per 4-16 queries
   const int nblk = (min(div_up(nq_cap, RS_WAVES), getenv("LCR_RS_NBLK") ? atoi(getenv("LCR_RS_NBLK")) : 256 * 8 * 4) + 7) / 8 * 8;
   const dim3 grid(nblk), block(RS_WAVES * 64);
+  KernelTimerScope timed(KT_RADIUS, st, nq_cap, ns_cap, limit, out_idx64 ? 8 : 4, B);
   if (out_idx64 && out_idx32)
     hipLaunchKernelGGL((k_radius_query<true, true>), grid, block, 0, st, q, qlen, B, nq_cap, L.hdr, L.cell_start, L.sorted, r2, limit,
                        out_idx64, out_idx32, out_cnt, q_order);

@@ -63,10 +63,10 @@ class Vote_Encoder(nn.Module):
         keep, length = F.greedy_nms(shifted, lens_c, self.NMS_radius)
         nms_pts = shifted[keep.bool()].contiguous()                       # compaction (host sync: output size is data dependent)
         pad = shifted.shape[0]
-        knn = radius_search(nms_pts, shifted, length, lens_c, 2.4, limits[-1])                    # backbone4.py:149-156 (literal 2.4)
+        knn = radius_search(nms_pts, shifted, length, lens_c, 2.4, limits[-1], check=False)                    # backbone4.py:149-156 (literal 2.4)
         centers = F.neighbor_mean(shifted, knn, pad)
-        sub = radius_search(centers, points_c, length, lens_c, self.init_radius * 8, limits[-2])
-        nb = radius_search(centers, centers, length, length, self.init_radius * 16, limits[-1])
+        sub = radius_search(centers, points_c, length, lens_c, self.init_radius * 8, limits[-2], check=False)
+        nb = radius_search(centers, centers, length, length, self.init_radius * 16, limits[-1], check=False)
         f = self.encoder6_1(feats, centers, points_c, sub)
         f = self.encoder6_2(f, centers, centers, nb)
         f = self.encoder6_3(f, centers, centers, nb)

@@ -53,22 +53,34 @@ def radius_count(q_points, s_points, q_lengths, s_lengths, radius):
     return _call(q_points, s_points, q_lengths, s_lengths, radius, 0, False, False, True)[2]
 
 
-def radius_search(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, dtype=torch.int64):
+def radius_search(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, dtype=torch.int64, check=True):
     r"""Neighbours of ``q_points`` in ``s_points`` within ``radius`` (stack mode), on the GPU.
 
-    Returns LongTensor (N, k): k = neighbor_limit if > 0, else the maximum in-radius count (reference width).
-    Rows are ascending in (d², index) and padded with M = s_points.shape[0].
+    check=True (the drop-in behaviour): blocking like the reference op; the device status word is read back and a lengths / rows
+    mismatch raises RuntimeError instead of returning truncated lists, and the result has the reference's shape
+    (N, min(neighbor_limit, max in-radius count)) — radius_search.py:25-26 slices ``[:, :limit]`` off a matrix that is only as wide
+    as the densest neighbourhood.  check=False (stream-ordered callers inside the model): no host synchronisation, always
+    ``neighbor_limit`` columns (the extra ones are pure padding).
+    Rows are ascending in (d², index) and padded with M = s_points.shape[0]; the result is contiguous.
     """
     _check(q_points, s_points, q_lengths, s_lengths)
     limit = int(neighbor_limit)
+    want64 = dtype == torch.int64
     if limit <= 0:
         cnt = radius_count(q_points, s_points, q_lengths, s_lengths, radius)
         limit = int(cnt.max().item()) if cnt.numel() else 0   # host sync: output width is data dependent
         if limit == 0:
             return torch.empty((q_points.shape[0], 0), dtype=dtype, device=q_points.device)
-    want64 = dtype == torch.int64
-    out64, out32, _, _ = _call(q_points, s_points, q_lengths, s_lengths, radius, limit, want64, not want64, False)
-    return out64 if want64 else out32
+    out64, out32, cnt, status = _call(q_points, s_points, q_lengths, s_lengths, radius, limit, want64, not want64, check)
+    out = out64 if want64 else out32
+    if check:
+        mx = cnt.max().to(torch.int32).reshape(1) if cnt.numel() else torch.zeros(1, dtype=torch.int32, device=out.device)
+        st, width = torch.cat([status, mx]).tolist()             # one read-back: status word + widest neighbourhood
+        if st != 0:
+            raise RuntimeError("radius_search: lengths do not match the point tensors (status %d)" % st)
+        if width < limit:
+            out = out[:, :width].contiguous()
+    return out
 
 
 class SupportGrid:

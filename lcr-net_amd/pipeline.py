@@ -14,10 +14,32 @@ import torch
 from .data import precompute_batch, precompute_batch_arena, voxelize_raw_scans
 
 
-def _native_streams(device, n, priority=0):
-    """n HIP streams created back to back, wrapped for torch."""
+_HIP = None
+
+
+def _hip():
+    global _HIP
+    if _HIP is None:
+        import ctypes
+        _HIP = ctypes.CDLL("libamdhip64.so")
+    return _HIP
+
+
+def destroy_streams(streams):
+    """hipStreamDestroy for streams made by `_native_streams` (torch's ExternalStream wrapper does not own its handle)."""
     import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
+    for st in streams:
+        h = getattr(st, "_lcr_handle", None)
+        if h:
+            st.synchronize()
+            _hip().hipStreamDestroy(ctypes.c_void_p(h))
+            st._lcr_handle = None
+
+
+def _native_streams(device, n, priority=0):
+    """n HIP streams created back to back, wrapped for torch (handle kept in `_lcr_handle` for `destroy_streams`)."""
+    import ctypes
+    hip = _hip()
     out = []
     with torch.cuda.device(device):
         for _ in range(n):
@@ -25,7 +47,9 @@ def _native_streams(device, n, priority=0):
             rc = hip.hipStreamCreateWithPriority(ctypes.byref(h), 1, int(priority))      # hipStreamNonBlocking
             if rc != 0:
                 raise RuntimeError("hipStreamCreateWithPriority failed: %d" % rc)
-            out.append(torch.cuda.ExternalStream(h.value, device=device))
+            st = torch.cuda.ExternalStream(h.value, device=device)
+            st._lcr_handle = h.value
+            out.append(st)
     return out
 
 
@@ -80,6 +104,7 @@ def distinct_queue_streams(device, n, priority=0, pool=10):
             break
         if c not in chosen:
             chosen.append(c)
+    destroy_streams([c for c in cand if c not in chosen])     # the candidates that lost the probe are not kept alive
     return chosen
 
 
@@ -115,6 +140,17 @@ class DescriptorPipeline:
         self.stats = {"pre_wait_s": 0.0, "pre_busy_s": 0.0, "enc_wait_s": 0.0, "batches": 0}   # where the two host threads wait
         self._ones_buf = None
         self.enc_streams = None      # set by enable_dual_encoder(): consecutive batches' encoders on alternating streams
+
+    def close(self):
+        """Destroy the pipeline's native streams (idempotent).  The pipeline cannot run afterwards."""
+        destroy_streams(self._streams)
+        self._streams, self.pre_streams, self.pre_stream, self.enc_streams = [], [], None, None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def enable_dual_encoder(self, n=2):
         """Run the encoders of consecutive batches on two alternating streams so that the small-grid kernels of one (stage-3/4
@@ -218,6 +254,7 @@ class DescriptorPipeline:
         slots = threading.Semaphore(self.depth + W - 1)      # batches pre-processed but not yet consumed
         it = enumerate(iter(batches))
         it_lock = threading.Lock()
+        stop = threading.Event()                             # set when the consumer leaves (exhaustion, break, exception)
 
         def producer(st):
             try:
@@ -227,6 +264,8 @@ class DescriptorPipeline:
                         t0 = time.perf_counter()
                         slots.acquire()
                         t1 = time.perf_counter()
+                        if stop.is_set():
+                            break
                         with it_lock:
                             nxt = next(it, None)
                         if nxt is None:
@@ -247,10 +286,22 @@ class DescriptorPipeline:
         threads = [threading.Thread(target=producer, args=(st,), daemon=True) for st in streams]
         for th in threads:
             th.start()
-        k = 0
         ready = {}           # out-of-order arrivals (several workers)
-        finished = 0
-        pending = None       # (descriptors, done event) of the previous batch when two encoder streams are used
+        try:
+            yield from self._consume(out, slots, ready, W, main, sync_to_caller)
+        finally:
+            # consumer gone (normally or not): wake every producer blocked in slots.acquire(), let them see the flag, and join.
+            # Arenas still queued are dropped after their producing streams have drained.
+            stop.set()
+            for _ in range(W + self.depth + 1):
+                slots.release()
+            for th in threads:
+                th.join()
+            for st in streams:
+                st.synchronize()
+
+    def _consume(self, out, slots, ready, W, main, sync_to_caller):
+        k, finished, pending = 0, 0, None
         while True:
             while k not in ready and finished < W:
                 t0 = time.perf_counter()
@@ -297,8 +348,6 @@ class DescriptorPipeline:
         if pending is not None:
             main.wait_event(pending[1])
             yield pending[0]
-        for th in threads:
-            th.join()
 
 
 class PairPipeline:
@@ -313,6 +362,19 @@ class PairPipeline:
         self.model, self.workers = model, max(1, int(workers))
         self.voxel_size, self.radius, self.num_stages, self.limits = voxel_size, radius, num_stages, list(neighbor_limits)
         self.device = next(model.parameters()).device
+        # worker streams: created and probed ONCE per pipeline (two busy streams on one hardware queue serialise each other)
+        self._streams = distinct_queue_streams(self.device, self.workers) if self.workers > 1 else []
+
+    def close(self):
+        """Destroy the worker streams (idempotent)."""
+        destroy_streams(self._streams)
+        self._streams = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def one(self, points, lengths):
         """points f32[N,3] = the two clouds of a pair stacked (already voxelised), lengths i64[2] -> the model's output dict."""
@@ -339,8 +401,11 @@ class PairPipeline:
         out = queue.Queue()
         slots = threading.Semaphore(2 * self.workers)       # finished pairs not yet consumed
 
-        worker_streams = distinct_queue_streams(dev, self.workers)      # two busy streams on one hardware queue serialise each other
+        if len(self._streams) < self.workers:
+            raise RuntimeError("PairPipeline is closed")
+        worker_streams = self._streams[:self.workers]
         stream_it = iter(worker_streams)
+        stop = threading.Event()
 
         def worker():
             try:
@@ -351,6 +416,8 @@ class PairPipeline:
                 with torch.cuda.stream(st):
                     while True:
                         slots.acquire()
+                        if stop.is_set():
+                            break
                         with it_lock:
                             nxt = next(it, None)
                         if nxt is None:
@@ -368,25 +435,32 @@ class PairPipeline:
         threads = [threading.Thread(target=worker, daemon=True) for _ in range(self.workers)]
         for th in threads:
             th.start()
-        ready, finished, k = {}, 0, 0
-        while True:
-            while k not in ready and finished < self.workers:
-                item = out.get()
-                if item is None:
-                    finished += 1
-                elif isinstance(item, BaseException):
-                    raise item
-                else:
-                    ready[item[0]] = item[1:]
-            if k not in ready:
-                break
-            res, ev = ready.pop(k)
-            slots.release()
-            main.wait_event(ev)
-            for v in res.values():
-                if torch.is_tensor(v) and v.is_cuda:
-                    v.record_stream(main)
-            yield res
-            k += 1
-        for th in threads:
-            th.join()
+        try:
+            ready, finished, k = {}, 0, 0
+            while True:
+                while k not in ready and finished < self.workers:
+                    item = out.get()
+                    if item is None:
+                        finished += 1
+                    elif isinstance(item, BaseException):
+                        raise item
+                    else:
+                        ready[item[0]] = item[1:]
+                if k not in ready:
+                    break
+                res, ev = ready.pop(k)
+                slots.release()
+                main.wait_event(ev)
+                for v in res.values():
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(main)
+                yield res
+                k += 1
+        finally:
+            stop.set()                                   # consumer gone: wake the workers, let them see the flag, join
+            for _ in range(3 * self.workers + 1):
+                slots.release()
+            for th in threads:
+                th.join()
+            for st in worker_streams:
+                st.synchronize()

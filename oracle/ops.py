@@ -109,8 +109,10 @@ def radius_count(q_points, s_points, q_lengths, s_lengths, radius):
     return counts, int(mx)
 
 
-def radius_search(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, impl="oracle", return_counts=False):
-    """int64 [Nq, k]: k = neighbor_limit if > 0 else the max in-radius count (reference semantics)."""
+def radius_search(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, impl="oracle", return_counts=False, ref_width=False):
+    """int64 [Nq, k]: k = neighbor_limit if > 0 else the max in-radius count.  ref_width=True: the reference's shape for
+    neighbor_limit > 0 too, k = min(neighbor_limit, max count) (radius_search.py:25-26 slices a matrix only as wide as the densest
+    ball); the default keeps neighbor_limit columns (the extra ones are pure padding) like the native fixed-width lists."""
     q, qp = _f32(q_points)
     s, sp = _f32(s_points)
     ql, qlp = _i64(q_lengths)
@@ -134,6 +136,8 @@ def radius_search(q_points, s_points, q_lengths, s_lengths, radius, neighbor_lim
     out = np.empty((nq, width), dtype=np.int64)
     lib().oracle_radius_search(qp, sp, qlp, slp, len(ql), ctypes.c_float(radius), width,
                                out.ctypes.data_as(_i64p), counts.ctypes.data_as(_i32p))
+    if ref_width and nq and int(counts.max()) < width:
+        out = np.ascontiguousarray(out[:, :int(counts.max())])
     return (out, counts) if return_counts else out
 
 

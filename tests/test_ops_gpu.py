@@ -80,7 +80,7 @@ def test_ragged_and_empty_clouds():
     got_p, got_l = grid_subsample(dev(xyz), dev(lens), 0.8)
     assert np.array_equal(got_l.cpu().numpy(), want_l)
     assert np.array_equal(got_p.cpu().numpy().view(np.uint32), want_p.view(np.uint32))
-    want = oracle_ops.radius_search(want_p, xyz, want_l, lens, 2.0, 30)
+    want = oracle_ops.radius_search(want_p, xyz, want_l, lens, 2.0, 30, ref_width=True)
     got = radius_search(got_p.contiguous(), dev(xyz), got_l, dev(lens), 2.0, 30)
     assert np.array_equal(got.cpu().numpy(), want)
 
@@ -92,7 +92,7 @@ def test_dense_ball_exceeds_lds_capacity():
     s = (rng.standard_normal((3000, 3)) * 0.4).astype(np.float32)
     q = s[:200].copy()
     ql, sl = np.array([200]), np.array([3000])
-    want, cnt = oracle_ops.radius_search(q, s, ql, sl, 1.0, 100, return_counts=True)
+    want, cnt = oracle_ops.radius_search(q, s, ql, sl, 1.0, 100, return_counts=True, ref_width=True)
     assert cnt.max() > 512
     got = radius_search(dev(q), dev(s), dev(ql), dev(sl), 1.0, 100)
     assert np.array_equal(got.cpu().numpy(), want)
@@ -105,7 +105,7 @@ def test_exact_ties_order_by_index():
     rng = np.random.default_rng(2)
     g = g[rng.permutation(len(g))]
     n = np.array([len(g)])
-    want = oracle_ops.radius_search(g, g, n, n, 2.5, 40)
+    want = oracle_ops.radius_search(g, g, n, n, 2.5, 40, ref_width=True)
     got = radius_search(dev(g), dev(g), dev(n), dev(n), 2.5, 40)
     assert np.array_equal(got.cpu().numpy(), want)
 
@@ -159,7 +159,7 @@ def test_negative_coordinates_and_queries_outside_the_support_box():
     s = (rng.random((3000, 3)) * 20 - 30).astype(np.float32)              # all-negative support box
     q = np.concatenate([s[:50] + 0.01, (rng.random((50, 3)) * 400 - 200).astype(np.float32)])   # half of the queries far outside
     ql, sl = np.array([60, 40]), np.array([1800, 1200])
-    want, cnt = oracle_ops.radius_search(q, s, ql, sl, 2.5, 40, return_counts=True)
+    want, cnt = oracle_ops.radius_search(q, s, ql, sl, 2.5, 40, return_counts=True, ref_width=True)
     got = radius_search(dev(q), dev(s), dev(ql), dev(sl), 2.5, 40)
     assert np.array_equal(got.cpu().numpy(), want) and (cnt == 0).any() and (cnt > 0).any()
 
@@ -174,7 +174,7 @@ def test_sixty_four_clouds_and_the_limit_beyond():
     want_p, want_l = oracle_ops.grid_subsample(xyz, lens, 1.0)
     got_p, got_l = grid_subsample(dev(xyz), dev(lens), 1.0)
     assert np.array_equal(got_l.cpu().numpy(), want_l) and np.array_equal(got_p.cpu().numpy().view(np.uint32), want_p.view(np.uint32))
-    want = oracle_ops.radius_search(xyz, xyz, lens, lens, 1.5, 16)
+    want = oracle_ops.radius_search(xyz, xyz, lens, lens, 1.5, 16, ref_width=True)
     got = radius_search(dev(xyz), dev(xyz), dev(lens), dev(lens), 1.5, 16)
     assert np.array_equal(got.cpu().numpy(), want)
     with pytest.raises(RuntimeError):
@@ -238,10 +238,10 @@ def test_random_clouds_subsample_and_search(seed):
     assert np.array_equal(got_l.cpu().numpy(), want_l)
     assert np.array_equal(got_p.cpu().numpy().view(np.uint32), want_p.view(np.uint32))
     radius, limit = voxel * 4.25, int(rng.integers(8, 70))
-    want = oracle_ops.radius_search(want_p, xyz, want_l, lens, radius, limit)               # coarse queries, fine supports
+    want = oracle_ops.radius_search(want_p, xyz, want_l, lens, radius, limit, ref_width=True)               # coarse queries, fine supports
     got = radius_search(got_p.contiguous(), dev(xyz), got_l, dev(lens), radius, limit)
     assert np.array_equal(got.cpu().numpy(), want)
-    want = oracle_ops.radius_search(want_p, want_p, want_l, want_l, radius, limit)          # self search
+    want = oracle_ops.radius_search(want_p, want_p, want_l, want_l, radius, limit, ref_width=True)          # self search
     got = radius_search(got_p.contiguous(), got_p.contiguous(), got_l, got_l, radius, limit)
     assert np.array_equal(got.cpu().numpy(), want)
 
