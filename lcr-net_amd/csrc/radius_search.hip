@@ -8,19 +8,19 @@
 //
 // MI355X design (not a kd-tree): per call a uniform grid over every support cloud (cell >= radius, so the 27-cell
 // neighbourhood covers the ball), built with atomics + a device-wide scan into a cell-sorted float4 array (x,y,z,idx)
-// so that candidate loads are coalesced 16-B reads.  One 64-lane wavefront owns one query: the nine x-runs of the
-// neighbourhood are concatenated, lanes stride over the candidates, survivors are compacted into LDS with a
-// ballot/popcount wavefront scan, and the row is ordered by an all-pairs rank over the LDS keys
-// (key = d2 bits << 32 | index; n ~ 50 so n^2/64 work per lane beats a padded bitonic network).  Rows whose
-// in-radius count exceeds the LDS capacity fall back to a storage-free rank by re-enumeration (exact, slow, rare).
-// HBM-bound by its output rows (limit * 4 or 8 bytes per query); everything else stays in L2.
+// so that candidate loads are coalesced 16-B reads.  One 64-lane wavefront owns one query at a time: the nine x-runs of the
+// neighbourhood (sphere-culled) are concatenated, lanes stride over the candidates, survivors are compacted into LDS with a
+// ballot/popcount wavefront scan, and the row is ordered by a counting sort on 64 monotone bins of d² (key = d2 bits << 32 |
+// index).  Rows whose in-radius count exceeds the LDS capacity fall back to a storage-free rank by re-enumeration (exact,
+// slow, rare).  Nominally HBM-bound by its output rows (limit * 4 or 8 bytes per query); measured, it is bound by instruction
+// issue on three units at once — per query ≈350 VALU, ≈180 SALU and ≈25 LDS wavefront instructions, the LDS unit being shared
+// by the four SIMDs of a CU (DESIGN.md §4.1 has the ablation numbers).
 #include <cstdlib>
 
 #include "common.h"
 
 namespace lcr {
 
-constexpr int RS_CAP = 512;      // LDS keys per wavefront (8 B each)
 constexpr int RS_WAVES = 4;      // wavefronts (= queries in flight) per workgroup
 constexpr int RS_UNROLL = 4;     // candidate chunks (of 64) in flight per wavefront
 constexpr int GRID_MAX_B = 64;   // clouds per call
@@ -201,186 +201,290 @@ __global__ __launch_bounds__(256) void k_grid_scatter(GridHeader* h, const float
   }
 }
 
-// ---- query ---------------------------------------------------------------------------------------------------------
+// ---- query ---------------------------------------------------------------------------------------------------------------------
+// One wavefront per query (round 1's kernel: ≈900 wavefront instructions for a stage-0 query — ≈180 of per-query setup, ≈250 per trip
+// of 256 candidate SLOTS whether or not the query has that many, ≈200 for an all-pairs rank — 695 us for the ten searches of a bench
+// batch).  This form, same contract and bit-identical rows, 455 us:
+//  * a wavefront takes RQ_BLOCK CONSECUTIVE queries of the processing order (neighbours in the query set's own cell order), so the
+//    owning cloud is the previous query's (one compare instead of a prefix walk);
+//  * runs whose cell row lies farther than r from the query, and the outer x cells of a run when the query is farther than r from
+//    them, are dropped before anything is loaded (sphere culling in cell units, conservative by 1e-5: ≈ -25 % candidates);
+//  * the nine (start, prefix) pairs live in scalar registers (v_readlane) — no LDS round trip — and the slot of candidate t is a
+//    compare/select chain on them;
+//  * candidate chunks of 64 are issued 1..4 at a time as the query needs (a sparse far-field query costs one chunk, not four);
+//  * the row is ordered by a counting sort on 64 monotone bins of d² (LDS atomics give the position inside a bin, one wavefront
+//    scan gives the bin offsets, keys move to bin order, and every key only counts the smaller keys of ITS bin — a handful —
+//    instead of all n): ≈ 85 instructions instead of ≈ 200 for n ≈ 50.
+constexpr int RQ_CAP = 512;       // LDS keys per wavefront (denser balls take the exact storage-free path)
+constexpr int RQ_BLOCK = 4;       // consecutive queries per wavefront turn (one per 16-lane DPP row)
+constexpr int RQ_BINS = 64;
+
+__device__ __forceinline__ int rq_bin(uint64_t key, float scale) {
+  const float d2 = __uint_as_float(static_cast<uint32_t>(key >> 32));
+  const int b = static_cast<int>(fmul(d2, scale));          // monotone non-decreasing in d2 (round-to-nearest product, truncation)
+  return b < RQ_BINS - 1 ? b : RQ_BINS - 1;
+}
+
+// wave-uniform run table of one query: prefix p_k of the run lengths and c_k = first slot of run k - p_k.  Plain named scalars on
+// purpose: with arrays the compiler turned the select chain into a select of ADDRESSES and fetched c_k from scratch memory per
+// candidate (a dependent memory round trip in front of every candidate load: 13 us per wavefront turn).
+struct RqRuns {
+  int p1, p2, p3, p4, p5, p6, p7, p8;
+  int c0, c1, c2, c3, c4, c5, c6, c7, c8;
+};
+__device__ __forceinline__ int rq_slot(const RqRuns R, int t) {
+  int off = R.c0;
+  off = t >= R.p1 ? R.c1 : off;
+  off = t >= R.p2 ? R.c2 : off;
+  off = t >= R.p3 ? R.c3 : off;
+  off = t >= R.p4 ? R.c4 : off;
+  off = t >= R.p5 ? R.c5 : off;
+  off = t >= R.p6 ? R.c6 : off;
+  off = t >= R.p7 ? R.c7 : off;
+  off = t >= R.p8 ? R.c8 : off;
+  return t + off;
+}
+
+template <int U>
+__device__ __forceinline__ void rq_chunks(const RqRuns R, const float4* __restrict__ sorted, int t0, int total, float qx, float qy, float qz,
+                                          float r2, float bin_scale, uint64_t* keys, int* cnt, int& n) {
+  const int lane = threadIdx.x & 63;
+  float4 P[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    P[u] = sorted[rq_slot(R, min(t0 + 64 * u + lane, total - 1))];     // all loads of the trip in flight together
+    asm volatile("" : "+v"(P[u].x), "+v"(P[u].y), "+v"(P[u].z), "+v"(P[u].w));   // one 16-B load: keep .w out of the conditional store block
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const float dx = fsub(qx, P[u].x), dy = fsub(qy, P[u].y), dz = fsub(qz, P[u].z);
+    const float d2 = fadd(fadd(fmul(dx, dx), fmul(dy, dy)), fmul(dz, dz));
+    const bool pass = (t0 + 64 * u + lane < total) && d2 < r2;
+    const uint64_t m = __ballot(pass);
+    const int off = n + __popcll(m & lanemask_lt());
+    if (pass && off < RQ_CAP) {
+      const uint64_t key = (static_cast<uint64_t>(__float_as_uint(d2)) << 32) | __float_as_uint(P[u].w);
+      keys[off] = key;
+      atomicAdd(&cnt[rq_bin(key, bin_scale)], 1);             // the counting pass of the sort, for free in this LDS round trip
+    }
+    n += __popcll(m);
+  }
+}
+
 template <bool HAS64, bool HAS32>
 __global__ __launch_bounds__(RS_WAVES * 64) void k_radius_query(const float* __restrict__ q, const int64_t* __restrict__ qlen, int B,
-                                                                 int64_t nq_cap, const GridHeader* __restrict__ h,
-                                                                 const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
-                                                                 float r2, int limit, int64_t* __restrict__ out64,
-                                                                 int32_t* __restrict__ out32, int32_t* __restrict__ out_cnt,
-                                                                 const int32_t* __restrict__ q_order) {
-  __shared__ __attribute__((aligned(16))) uint64_t s_keys[RS_WAVES][RS_CAP + 16];   // + sentinel padding of the rank loop
-  __shared__ int s_run_a[RS_WAVES][12];     // first sorted slot of each x-run
-  __shared__ int s_run_p[RS_WAVES][12];     // exclusive prefix of run lengths
+                                                                  int64_t nq_cap, const GridHeader* __restrict__ h,
+                                                                  const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
+                                                                  float r2, int limit, int64_t* __restrict__ out64,
+                                                                  int32_t* __restrict__ out32, int32_t* __restrict__ out_cnt,
+                                                                  const int32_t* __restrict__ q_order, int qb_dbg) {
+  const int qb = qb_dbg & 0xff, dbg = qb_dbg >> 8;   // dbg: timing ablations (tools/radius_bench.py), 0 in production
+  __shared__ __attribute__((aligned(16))) uint64_t s_keys[RS_WAVES][RQ_CAP];
+  __shared__ uint16_t s_perm[RS_WAVES][RQ_CAP];             // bin-ordered position -> slot in s_keys
+  __shared__ int s_cnt[RS_WAVES][RQ_BINS];
+  __shared__ int s_fill[RS_WAVES][RQ_BINS];
+  __shared__ int s_base[RS_WAVES][RQ_BINS + 1];
   __shared__ int64_t s_qoff[GRID_MAX_B + 1];
 
-  if (threadIdx.x < 64) {                                   // prefix of the query lengths: one load + a wavefront scan
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (threadIdx.x < 64) {
     const int64_t len_b = threadIdx.x < B ? qlen[threadIdx.x] : 0;
     const int64_t inc = wave_incl_scan(len_b);
     if (threadIdx.x < B) s_qoff[threadIdx.x] = inc - len_b;
     if (threadIdx.x == B - 1) s_qoff[B] = inc;
   }
+  s_cnt[w][lane] = 0;
   __syncthreads();
   const int64_t nq = min(s_qoff[B], nq_cap);
   const int64_t ns_total = h->ns_total;
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index as a scalar: per-query values stay in SGPRs
   uint64_t* keys = s_keys[w];
+  uint16_t* perm = s_perm[w];
+  int* cnt = s_cnt[w];
+  int* fill = s_fill[w];
+  int* base = s_base[w];
+  const float bin_scale = fdiv(static_cast<float>(RQ_BINS), r2);
 
-  // With a processing order (the query set's own cell order) consecutive wavefronts search neighbouring cells, and every XCD
-  // walks a contiguous eighth of that order: the candidate cells are re-used from L1 / the XCD's own L2 (-6 % on the ten searches
-  // of a batch; the kernel is bound by its issue rate).  Rows are written at the query's own index either way.
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;            // the grid is a multiple of 8
+  // every XCD walks a contiguous eighth of the processing order; inside it a wavefront takes `qb` (1, 2 or 4) CONSECUTIVE queries per
+  // turn and sets all of them up AT ONCE: query j of the turn lives in DPP row j (lanes 16j .. 16j+8 own its nine runs), so the
+  // header / cell-table loads, the fp64 cell arithmetic and the culling of up to four queries cost the instructions and the load
+  // round trips of one.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
   const int64_t per_xcd = (nq + 7) / 8;
-  const int64_t t_end = min(nq, (xcd + 1) * per_xcd), t_step = static_cast<int64_t>(nslots) * RS_WAVES;
-  int64_t t_cur = xcd * per_xcd + static_cast<int64_t>(slot) * RS_WAVES + w;
-  int64_t qi_next = t_cur < t_end ? (q_order ? static_cast<int64_t>(q_order[t_cur]) : t_cur) : 0;
-  for (; t_cur < t_end; t_cur += t_step) {
-    const int64_t qi = qi_next;
-    {
-      const int64_t tn = t_cur + t_step < t_end ? t_cur + t_step : t_cur;                      // the next query's index: one trip ahead
-      qi_next = q_order ? static_cast<int64_t>(q_order[tn]) : tn;
+  const int64_t x_lo = xcd * per_xcd, x_hi = min(nq, (xcd + 1) * per_xcd);
+  const int64_t turn_step = static_cast<int64_t>(nslots) * RS_WAVES * qb;
+  const int row = lane >> 4, sub = lane & 15;
+  int b = 0;                                     // cloud of this lane's previous query
+  int off_b = 0, off_b1 = 0;                     // its [first, last) rows (nq < 2^31): empty until the first lookup
+  for (int64_t t_blk = x_lo + (static_cast<int64_t>(slot) * RS_WAVES + w) * qb; t_blk < x_hi; t_blk += turn_step) {
+    const int nj = static_cast<int>(min(static_cast<int64_t>(qb), x_hi - t_blk));             // wave-uniform
+    // ---- setup of the turn's queries, one per DPP row
+    const bool mine = row < nj;
+    const int64_t t_me = t_blk + (mine ? row : 0);
+    const int64_t qi_me = q_order ? static_cast<int64_t>(q_order[t_me]) : t_me;
+    if (qi_me < off_b || qi_me >= off_b1) {      // rare in cell order (a turn seldom straddles two clouds)
+      b = cloud_of(s_qoff, B, qi_me);
+      off_b = static_cast<int>(s_qoff[b]);
+      off_b1 = static_cast<int>(s_qoff[b + 1]);
     }
-    const int b = cloud_of(s_qoff, B, qi);
     const GridCloud& c = h->cloud[b];
-    const float qx = q[3 * qi + 0], qy = q[3 * qi + 1], qz = q[3 * qi + 2];
-
-    // nine x-runs (dy, dz in {-1,0,1}); lanes 0..8 own one run each
+    const float mx = q[3 * qi_me + 0], my = q[3 * qi_me + 1], mz = q[3 * qi_me + 2];
     int len = 0, a = 0;
-    if (lane < 9 && c.dim[0] > 0) {
-      const int cx = cell_coord(qx, c.org[0], c.inv_cell, c.dim[0]);
-      const int cy = cell_coord(qy, c.org[1], c.inv_cell, c.dim[1]) + (lane % 3) - 1;
-      const int cz = cell_coord(qz, c.org[2], c.inv_cell, c.dim[2]) + (lane / 3) - 1;
-      const int x0 = max(cx - 1, 0), x1 = min(cx + 1, c.dim[0] - 1);
-      if (x0 <= x1 && cy >= 0 && cy < c.dim[1] && cz >= 0 && cz < c.dim[2]) {
-        const int row = c.cell_base + (cz * c.dim[1] + cy) * c.dim[0];
-        a = cell_start[row + x0];
-        len = cell_start[row + x1 + 1] - a;
+    if (mine && sub < 9 && c.dim[0] > 0) {
+      const double inv = c.inv_cell;
+      const double ux = (static_cast<double>(mx) - c.org[0]) * inv, uy = (static_cast<double>(my) - c.org[1]) * inv,
+                   uz = (static_cast<double>(mz) - c.org[2]) * inv;
+      const double fx = floor(ux), fy = floor(uy), fz = floor(uz);
+      const int dyl = (sub % 3) - 1, dzl = (sub / 3) - 1;
+      const int cx = static_cast<int>(fmin(fmax(fx, -2.0), static_cast<double>(c.dim[0]) + 1.0));      // == cell_coord()
+      const int cy = static_cast<int>(fmin(fmax(fy, -2.0), static_cast<double>(c.dim[1]) + 1.0)) + dyl;
+      const int cz = static_cast<int>(fmin(fmax(fz, -2.0), static_cast<double>(c.dim[2]) + 1.0)) + dzl;
+      // sphere culling in cell units.  A support filed in cell row cy+1 lies at least (1 - frac_y) cells away in y (its cell index
+      // is the same fp64 floor; supports on the box's max face are clamped INTO the last cell, i.e. lie farther still), so a run
+      // whose (y, z) gap alone exceeds r cannot hold a neighbour, and an outer x cell is out of reach when its x gap adds up
+      // beyond r.  Margin 1e-5 relative on r² (fp32 d² of a true neighbour is below r² by construction; the fp64 gaps carry
+      // ~1e-15).  An axis on which the query lies outside the box (clamped cell) is not culled.
+      const double rc2 = static_cast<double>(r2) * inv * inv * 1.00001;
+      const bool iny = fy >= 0.0 && fy < static_cast<double>(c.dim[1]), inz = fz >= 0.0 && fz < static_cast<double>(c.dim[2]),
+                 inx = fx >= 0.0 && fx < static_cast<double>(c.dim[0]);
+      const double ry = uy - fy, rz = uz - fz, rx = ux - fx;
+      const double gy = (!iny || dyl == 0) ? 0.0 : (dyl < 0 ? ry : 1.0 - ry);
+      const double gz = (!inz || dzl == 0) ? 0.0 : (dzl < 0 ? rz : 1.0 - rz);
+      const double g2 = gy * gy + gz * gz;
+      int x0 = cx - 1, x1 = cx + 1;
+      if (inx) {
+        if (rx * rx + g2 >= rc2) x0 = cx;
+        if ((1.0 - rx) * (1.0 - rx) + g2 >= rc2) x1 = cx;
+      }
+      x0 = max(x0, 0);
+      x1 = min(x1, c.dim[0] - 1);
+      if (g2 < rc2 && x0 <= x1 && cy >= 0 && cy < c.dim[1] && cz >= 0 && cz < c.dim[2]) {
+        const int crow = c.cell_base + (cz * c.dim[1] + cy) * c.dim[0];
+        a = cell_start[crow + x0];
+        len = cell_start[crow + x1 + 1] - a;
       }
     }
-    const int incl = wave_incl_scan(len);
-    const int total = __shfl(incl, 8);
-    if (lane < 9) {
-      s_run_a[w][lane] = a;
-      s_run_p[w][lane] = incl - len;
-    }
-    // wave-private LDS: same-wave program order is enough, but keep the compiler honest
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int incl = len;                                            // inclusive scan inside every 16-lane row (lanes 9..15 hold zeros)
+    incl += dpp0<DPP_ROW_SHR1>(incl);
+    incl += dpp0<DPP_ROW_SHR2>(incl);
+    incl += dpp0<DPP_ROW_SHR4>(incl);
+    incl += dpp0<DPP_ROW_SHR8>(incl);
+    const int pk_all = incl - len, ck_all = a - pk_all;
+    const int qi_lo = static_cast<int>(qi_me);                 // nq < 2^31 (checked on the host)
 
-    int p1 = s_run_p[w][1], p2 = s_run_p[w][2], p3 = s_run_p[w][3], p4 = s_run_p[w][4], p5 = s_run_p[w][5],
-        p6 = s_run_p[w][6], p7 = s_run_p[w][7], p8 = s_run_p[w][8];
+    for (int j = 0; j < nj; ++j) {
+      const int l0 = 16 * j;                                   // wave-uniform lane base of query j
+      const int64_t qi = static_cast<int64_t>(__builtin_amdgcn_readlane(qi_lo, l0));
+      const float qx = rdlane(mx, l0), qy = rdlane(my, l0), qz = rdlane(mz, l0);
+      const int total = (dbg & 2) ? 0 : rdlane(incl, l0 + 8);
+      RqRuns R;
+      R.c0 = rdlane(ck_all, l0);
+      R.p1 = rdlane(pk_all, l0 + 1), R.c1 = rdlane(ck_all, l0 + 1);
+      R.p2 = rdlane(pk_all, l0 + 2), R.c2 = rdlane(ck_all, l0 + 2);
+      R.p3 = rdlane(pk_all, l0 + 3), R.c3 = rdlane(ck_all, l0 + 3);
+      R.p4 = rdlane(pk_all, l0 + 4), R.c4 = rdlane(ck_all, l0 + 4);
+      R.p5 = rdlane(pk_all, l0 + 5), R.c5 = rdlane(ck_all, l0 + 5);
+      R.p6 = rdlane(pk_all, l0 + 6), R.c6 = rdlane(ck_all, l0 + 6);
+      R.p7 = rdlane(pk_all, l0 + 7), R.c7 = rdlane(ck_all, l0 + 7);
+      R.p8 = rdlane(pk_all, l0 + 8), R.c8 = rdlane(ck_all, l0 + 8);
 
-    auto candidate = [&](int t, float& d2, uint32_t& idx) {
-      const int r = (t >= p1) + (t >= p2) + (t >= p3) + (t >= p4) + (t >= p5) + (t >= p6) + (t >= p7) + (t >= p8);
-      const int slot = s_run_a[w][r] + (t - s_run_p[w][r]);
-      const float4 P = sorted[slot];
-      const float dx = fsub(qx, P.x), dy = fsub(qy, P.y), dz = fsub(qz, P.z);
-      d2 = fadd(fadd(fmul(dx, dx), fmul(dy, dy)), fmul(dz, dz));
-      idx = __float_as_uint(P.w);
-    };
-
-    // RS_UNROLL chunks of 64 candidates per trip: their loads are issued back to back, so a query pays the L2 round trip
-    // once per 256 candidates instead of once per 64
-    int n = 0;
-    for (int t0 = 0; t0 < total; t0 += 64 * RS_UNROLL) {
-      float d2[RS_UNROLL];
-      uint32_t idx[RS_UNROLL];
-      bool pass[RS_UNROLL];
-      // unconditional loads with the candidate index clamped (lanes beyond `total` re-read the last candidate and are masked
-      // out afterwards): a load inside a lane-conditional block made the compiler wait for it at the end of the block, so the
-      // RS_UNROLL loads were never in flight together
-      float4 P[RS_UNROLL];
-#pragma unroll
-      for (int u = 0; u < RS_UNROLL; ++u) {
-        const int t = min(t0 + 64 * u + lane, total - 1);
-        const int r = (t >= p1) + (t >= p2) + (t >= p3) + (t >= p4) + (t >= p5) + (t >= p6) + (t >= p7) + (t >= p8);
-        P[u] = sorted[s_run_a[w][r] + (t - s_run_p[w][r])];
+      int n = 0;
+      for (int t0 = 0; t0 < total; t0 += 64 * RS_UNROLL) {
+        const int rem = total - t0;                            // wave-uniform: issue as many chunks as the query still has
+        if (rem > 192) rq_chunks<4>(R, sorted, t0, total, qx, qy, qz, r2, bin_scale, keys, cnt, n);
+        else if (rem > 128) rq_chunks<3>(R, sorted, t0, total, qx, qy, qz, r2, bin_scale, keys, cnt, n);
+        else if (rem > 64) rq_chunks<2>(R, sorted, t0, total, qx, qy, qz, r2, bin_scale, keys, cnt, n);
+        else rq_chunks<1>(R, sorted, t0, total, qx, qy, qz, r2, bin_scale, keys, cnt, n);
       }
-#pragma unroll
-      for (int u = 0; u < RS_UNROLL; ++u) {
-        const float dx = fsub(qx, P[u].x), dy = fsub(qy, P[u].y), dz = fsub(qz, P[u].z);
-        d2[u] = fadd(fadd(fmul(dx, dx), fmul(dy, dy)), fmul(dz, dz));
-        idx[u] = __float_as_uint(P[u].w);
-        pass[u] = (t0 + 64 * u + lane < total) && d2[u] < r2;
+      if (out_cnt) {
+        if (lane == 0) out_cnt[qi] = n;
       }
-#pragma unroll
-      for (int u = 0; u < RS_UNROLL; ++u) {
-        const uint64_t m = __ballot(pass[u]);
-        const int off = n + __popcll(m & lanemask_lt());
-        if (pass[u] && off < RS_CAP) keys[off] = (static_cast<uint64_t>(__float_as_uint(d2[u])) << 32) | idx[u];
-        n += __popcll(m);
+      if (limit <= 0 || (dbg & 1)) {
+        if (n > 0) cnt[lane] = 0;
+        continue;
       }
-    }
-    if (out_cnt) {
-      if (lane == 0) out_cnt[qi] = n;
-    }
-    if (limit <= 0) continue;
 
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    int64_t* row64 = HAS64 ? out64 + qi * static_cast<int64_t>(limit) : nullptr;
-    int32_t* row32 = HAS32 ? out32 + qi * static_cast<int64_t>(limit) : nullptr;
-
-    if (n <= RS_CAP) {
-      // all-pairs rank over the LDS keys (keys are unique: the index is part of the key).  The list is padded to a multiple of
-      // 16 with all-ones sentinels (never smaller than a key) so that the comparison loop runs in groups of 16 broadcast reads:
-      // with 4 per group the loop was bound by LDS latency and took half of the kernel.
-      if (lane < 16 && n + lane < ((n + 15) & ~15)) keys[n + lane] = ~0ull;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const int n16 = (n + 15) & ~15;
-      for (int e = lane; e < n; e += 64) {
-        const uint64_t k = keys[e];
-        int rank = 0;
-        for (int j = 0; j < n16; j += 16) {
-          ulonglong2 kj[8];                       // 8 x ds_read_b128 (two keys each), all lanes the same address
-#pragma unroll
-          for (int u = 0; u < 8; ++u) kj[u] = *reinterpret_cast<const ulonglong2*>(&keys[j + 2 * u]);
-#pragma unroll
-          for (int u = 0; u < 8; ++u) rank += (kj[u].x < k) + (kj[u].y < k);
+
+      int64_t* row64 = HAS64 ? out64 + qi * static_cast<int64_t>(limit) : nullptr;
+      int32_t* row32 = HAS32 ? out32 + qi * static_cast<int64_t>(limit) : nullptr;
+
+      if (n == 0) {
+        // nothing in range: the row is all padding
+      } else if (n <= RQ_CAP) {
+        // counting sort on RQ_BINS monotone bins of d²: bin counts (taken while the keys were compacted) -> wavefront scan -> key
+        // SLOTS dealt into bin order (an atomic per key hands out the positions of a bin; order inside a bin is arbitrary; 16-bit
+        // slots, the keys stay put: a second key buffer costs two of the six resident workgroups per CU, measured 130 -> 154 us) -> every key counts the smaller keys of its own bin (1.8 keys on average for n = 50).
+        {
+          const int cb = cnt[lane];
+          const int inc = wave_incl_scan(cb);
+          base[lane + 1] = inc;
+          if (lane == 0) base[0] = 0;
+          fill[lane] = inc - cb;
+          cnt[lane] = 0;                                       // clean for the next query
         }
-        if (rank < limit) {
-          const int64_t v = static_cast<int64_t>(static_cast<uint32_t>(k));
-          if (HAS64) row64[rank] = v;
-          if (HAS32) row32[rank] = static_cast<int32_t>(v);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int e = lane; e < n; e += 64) perm[atomicAdd(&fill[rq_bin(keys[e], bin_scale)], 1)] = static_cast<uint16_t>(e);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int e = lane; e < n; e += 64) {
+          const uint64_t k = keys[e];
+          const int bb = rq_bin(k, bin_scale);
+          const int lo = base[bb], hi = base[bb + 1];
+          int rank = lo;
+          for (int j0 = lo; j0 < hi; j0 += 4) {                // four bin mates per trip: two LDS round trips for bins of up to four
+            const int s0 = perm[j0], s1 = perm[min(j0 + 1, hi - 1)], s2 = perm[min(j0 + 2, hi - 1)], s3 = perm[min(j0 + 3, hi - 1)];
+            const uint64_t a0 = keys[s0], a1 = keys[s1], a2 = keys[s2], a3 = keys[s3];
+            rank += (a0 < k) + (j0 + 1 < hi && a1 < k) + (j0 + 2 < hi && a2 < k) + (j0 + 3 < hi && a3 < k);   // keys are unique
+          }
+          if ((dbg & 4) ? rank == -12345 : rank < limit) {
+            const int64_t v = static_cast<int64_t>(static_cast<uint32_t>(k));
+            if (HAS64) row64[rank] = v;
+            if (HAS32) row32[rank] = static_cast<int32_t>(v);
+          }
+        }
+      } else {
+        // exact fallback without storage: rank every in-radius candidate by re-enumerating the runs
+        cnt[lane] = 0;                                         // bin counts of the compacted part: not used on this path
+        for (int t0 = 0; t0 < total; t0 += 64) {
+          const int t = t0 + lane;
+          float d2 = 0.f;
+          uint32_t idx = 0;
+          bool pass = false;
+          if (t < total) {
+            const float4 P = sorted[rq_slot(R, t)];
+            const float dx = fsub(qx, P.x), dy = fsub(qy, P.y), dz = fsub(qz, P.z);
+            d2 = fadd(fadd(fmul(dx, dx), fmul(dy, dy)), fmul(dz, dz));
+            idx = __float_as_uint(P.w);
+            pass = d2 < r2;
+          }
+          const uint64_t k = (static_cast<uint64_t>(__float_as_uint(d2)) << 32) | idx;
+          int rank = 0;
+          for (int u = 0; u < total; ++u) {   // u is wave-uniform: one broadcast load per step
+            const float4 E = sorted[rq_slot(R, u)];
+            const float ex = fsub(qx, E.x), ey = fsub(qy, E.y), ez = fsub(qz, E.z);
+            const float e2 = fadd(fadd(fmul(ex, ex), fmul(ey, ey)), fmul(ez, ez));
+            const uint64_t ek = (static_cast<uint64_t>(__float_as_uint(e2)) << 32) | __float_as_uint(E.w);
+            rank += (e2 < r2) && (ek < k);
+          }
+          if (pass && rank < limit) {
+            if (HAS64) row64[rank] = static_cast<int64_t>(idx);
+            if (HAS32) row32[rank] = static_cast<int32_t>(idx);
+          }
         }
       }
-    } else {
-      // exact fallback without storage: rank every in-radius candidate by re-enumerating the runs
-      for (int t0 = 0; t0 < total; t0 += 64) {
-        const int t = t0 + lane;
-        float d2 = 0.f;
-        uint32_t idx = 0;
-        bool pass = false;
-        if (t < total) {
-          candidate(t, d2, idx);
-          pass = d2 < r2;
+      if (!(dbg & 8))
+        for (int col = n + lane; col < limit; col += 64) {
+          if (HAS64) row64[col] = ns_total;
+          if (HAS32) row32[col] = static_cast<int32_t>(ns_total);
         }
-        const uint64_t k = (static_cast<uint64_t>(__float_as_uint(d2)) << 32) | idx;
-        int rank = 0;
-        for (int u = 0; u < total; ++u) {   // u is wave-uniform: one broadcast load per step
-          float e2;
-          uint32_t eidx;
-          candidate(u, e2, eidx);
-          const uint64_t ek = (static_cast<uint64_t>(__float_as_uint(e2)) << 32) | eidx;
-          rank += (e2 < r2) && (ek < k);
-        }
-        if (pass && rank < limit) {
-          if (HAS64) row64[rank] = static_cast<int64_t>(idx);
-          if (HAS32) row32[rank] = static_cast<int32_t>(idx);
-        }
-      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    for (int col = n + lane; col < limit; col += 64) {
-      if (HAS64) row64[col] = ns_total;
-      if (HAS32) row32[col] = static_cast<int32_t>(ns_total);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -450,27 +554,56 @@ extern "C" int lcr_radius_query_ordered(const float* q, const int64_t* qlen, int
     set_error("lcr_radius_query: limit > 0 needs an index output");
     return LCR_EARG;
   }
+  if (nq_cap > (int64_t(1) << 31) - 1) {
+    set_error("lcr_radius_query: more than 2^31-1 query points");
+    return LCR_EARG;
+  }
   if (nq_cap == 0) return LCR_OK;
   static const bool no_order = getenv("LCR_RS_NO_ORDER") != nullptr;      // A/B switch
   if (no_order) q_order = nullptr;
   GridLayout L = grid_layout(const_cast<void*>(grid_ws), ns_cap, B);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float r2 = radius * radius;   // fp32 product, as radius_neighbors_cpu.cpp:12
-  // few, long-lived workgroups: the per-workgroup prologue (query offsets) and launch ramp were ~40 % of the kernel with one
-  // workgroup per 4-16 queries
-  const int nblk = (min(div_up(nq_cap, RS_WAVES), getenv("LCR_RS_NBLK") ? atoi(getenv("LCR_RS_NBLK")) : 256 * 8 * 4) + 7) / 8 * 8;
-  const dim3 grid(nblk), block(RS_WAVES * 64);
+  const dim3 block(RS_WAVES * 64);
   KernelTimerScope timed(KT_RADIUS, st, nq_cap, ns_cap, limit, out_idx64 ? 8 : 4, B);
-  if (out_idx64 && out_idx32)
-    hipLaunchKernelGGL((k_radius_query<true, true>), grid, block, 0, st, q, qlen, B, nq_cap, L.hdr, L.cell_start, L.sorted, r2, limit,
-                       out_idx64, out_idx32, out_cnt, q_order);
-  else if (out_idx64)
-    hipLaunchKernelGGL((k_radius_query<true, false>), grid, block, 0, st, q, qlen, B, nq_cap, L.hdr, L.cell_start, L.sorted, r2, limit,
-                       out_idx64, out_idx32, out_cnt, q_order);
-  else
-    hipLaunchKernelGGL((k_radius_query<false, true>), grid, block, 0, st, q, qlen, B, nq_cap, L.hdr, L.cell_start, L.sorted, r2, limit,
-                       out_idx64, out_idx32, out_cnt, q_order);
-  return check_launch("lcr_radius_query");
+  {
+    // queries per wavefront turn: four (one per DPP row) when the search is large enough to fill the chip anyway, fewer for the
+    // small coarse-stage searches, which are latency-bound and want as many wavefronts as they have queries
+    static const int qb_env = getenv("LCR_RS_QB") ? atoi(getenv("LCR_RS_QB")) : 0;
+    static const int dbg_env = getenv("LCR_RS_DBG") ? atoi(getenv("LCR_RS_DBG")) : 0;
+    const int qb = (qb_env ? qb_env : (nq_cap >= 65536 ? 4 : (nq_cap >= 16384 ? 2 : 1))) | (dbg_env << 8);
+    // One resident generation of workgroups, each with an equal share of the queries: with more workgroups than fit, the last
+    // generation runs on a part-empty chip (2048 workgroups on 6-per-CU residency: 2 of 8 ran alone, measured 3.3 wavefronts per
+    // SIMD on average instead of 6).  Residency from the kernel's register count (the occupancy API is one workgroup per CU high
+    // for kernels with 97-112 SGPRs on this stack, MI355X_MICROARCH.md).
+    static const int wg_per_cu = []() {
+      if (getenv("LCR_RS_WG_PER_CU")) return atoi(getenv("LCR_RS_WG_PER_CU"));
+      hipFuncAttributes fa;
+      int api = 0;
+      if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_radius_query<false, true>)) != hipSuccess) return 4;
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, reinterpret_cast<const void*>(&k_radius_query<false, true>), RS_WAVES * 64, 0);
+      const int by_vgpr = 512 / ((fa.numRegs + 7) / 8 * 8);
+      return max(1, min(min(api > 0 ? api : 8, by_vgpr), 6));
+    }();
+    static const int n_cu = []() {
+      int dev = 0, n = 256;
+      hipGetDevice(&dev);
+      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+      return n;
+    }();
+    const int nblk2 = (min(div_up(nq_cap, RS_WAVES * (qb & 0xff)), getenv("LCR_RS_NBLK") ? atoi(getenv("LCR_RS_NBLK")) : n_cu * wg_per_cu) + 7) / 8 * 8;
+    const dim3 grid2(nblk2);
+    if (out_idx64 && out_idx32)
+      hipLaunchKernelGGL((k_radius_query<true, true>), grid2, block, 0, st, q, qlen, B, nq_cap, L.hdr, L.cell_start, L.sorted, r2, limit,
+                         out_idx64, out_idx32, out_cnt, q_order, qb);
+    else if (out_idx64)
+      hipLaunchKernelGGL((k_radius_query<true, false>), grid2, block, 0, st, q, qlen, B, nq_cap, L.hdr, L.cell_start, L.sorted, r2, limit,
+                         out_idx64, out_idx32, out_cnt, q_order, qb);
+    else
+      hipLaunchKernelGGL((k_radius_query<false, true>), grid2, block, 0, st, q, qlen, B, nq_cap, L.hdr, L.cell_start, L.sorted, r2, limit,
+                         out_idx64, out_idx32, out_cnt, q_order, qb);
+    return check_launch("lcr_radius_query");
+  }
 }
 
 // order[i] = stacked row index of the i-th support in cell-sorted order: a spatially coherent processing order for any kernel

@@ -61,14 +61,81 @@ def compute_PR_overlap(rows, ground_truth, thre_range=(0, 1), interval=0.01, sta
     return precisions, recalls
 
 
+def compute_AP(precisions, recalls):
+    """:13-17 — sum of (recall step) x precision."""
+    ap = 0.
+    for i in range(1, len(precisions)):
+        ap += (recalls[i] - recalls[i - 1]) * precisions[i]
+    return ap
+
+
 def compute_F1(precisions, recalls):
-    p, r = np.asarray(precisions, dtype=np.float64), np.asarray(recalls, dtype=np.float64)
-    f1 = 2 * p * r / (p + r + 1e-12)
-    return float(f1.max()), int(f1.argmax())
+    """:19-27 — max over the sweep of 2pr/(p+r), and its position.  Like the reference there is no epsilon: a sweep point with
+    p + r == 0 yields NaN and NaN wins max/argmax (numpy semantics), exactly as there."""
+    p, r = np.asarray(precisions), np.asarray(recalls)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        f1 = 2 * p * r / (p + r)
+    return f1.max(), f1.argmax()
 
 
 def auc(precisions, recalls):
+    """plotPRC :124-145: points sorted by recall descending, sklearn.metrics.auc (trapezoid; sign follows the direction) x 100."""
     order = sorted(zip(recalls, precisions), reverse=True)
     r = np.array([o[0] for o in order], dtype=np.float64)
     p = np.array([o[1] for o in order], dtype=np.float64)
-    return float(abs(np.trapz(p, r)) * 100)
+    trapezoid = getattr(np, "trapezoid", None) or np.trapz
+    return float(abs(trapezoid(p, r)) * 100)
+
+
+# ---- registration metrics (BASELINE config 5; utils/utils/registration.py:13-113, experiments/registration/eval.py:222-236) ----------
+def relative_rotation_error(gt_rotation, est_rotation):
+    """Isotropic RRE in degrees: acos((trace(R_est^T R_gt) - 1) / 2), argument clipped to [-1, 1] (registration.py:13-28)."""
+    c = 0.5 * (np.trace(np.asarray(est_rotation).T @ np.asarray(gt_rotation)) - 1.0)
+    return 180.0 * np.arccos(np.clip(c, -1.0, 1.0)) / np.pi
+
+
+def euler_angles_deg(R):
+    """Roll / pitch / yaw in degrees with the reference's conventions (registration.py:30-47): the gimbal-lock branch
+    (sqrt(R00^2 + R10^2) < 1e-6) sets yaw = 0, and degrees use the literal 3.141592653589793."""
+    import math
+    sy = math.sqrt(R[0, 0] * R[0, 0] + R[1, 0] * R[1, 0])
+    if sy >= 1e-6:
+        ang = (math.atan2(R[2, 1], R[2, 2]), math.atan2(-R[2, 0], sy), math.atan2(R[1, 0], R[0, 0]))
+    else:
+        ang = (math.atan2(-R[1, 2], R[1, 1]), math.atan2(-R[2, 0], sy), 0)
+    return tuple(a * 180.0 / 3.141592653589793 for a in ang)
+
+
+def relative_rotation_error_rpy(gt_rotation, est_rotation):
+    """Per-axis |difference| of the Euler angles, folded into [0, 180] (registration.py:50-80)."""
+    d = [abs(g - e) for g, e in zip(euler_angles_deg(gt_rotation), euler_angles_deg(est_rotation))]
+    return tuple(360 - x if x > 180 else x for x in d)
+
+
+def relative_translation_error(gt_translation, est_translation):
+    """RTE = |t_gt - t_est|_2 (registration.py:82-93)."""
+    return np.linalg.norm(np.asarray(gt_translation) - np.asarray(est_translation))
+
+
+def compute_registration_error(gt_transform, est_transform):
+    """(4,4), (4,4) -> (rre deg, rte m, rx, ry, rz) like registration.py:97-113."""
+    gt, est = np.asarray(gt_transform), np.asarray(est_transform)
+    rre = relative_rotation_error(gt[:3, :3], est[:3, :3])
+    rx, ry, rz = relative_rotation_error_rpy(gt[:3, :3], est[:3, :3])
+    return rre, relative_translation_error(gt[:3, 3], est[:3, 3]), rx, ry, rz
+
+
+def registration_summary(gt_transforms, est_transforms, rre_threshold=5.0, rte_threshold=2.0):
+    """The registration block of experiments/registration/eval.py:222-236,269-277: a pair is accepted when RRE < 5 deg and
+    RTE < 2 m (config_reg.py:66-67); RR = mean acceptance over all pairs, RRE / RTE / Rx / Ry / Rz = means over the ACCEPTED pairs
+    (NaN when none is accepted: the reference's meter is np.mean of an empty list, utils/utils/average_meter.py:28-29)."""
+    acc, kept = [], []
+    for gt, est in zip(gt_transforms, est_transforms):
+        e = compute_registration_error(gt, est)
+        ok = bool(e[0] < rre_threshold and e[1] < rte_threshold)
+        acc.append(float(ok))
+        if ok:
+            kept.append(e)
+    m = np.mean(np.asarray(kept, dtype=np.float64), axis=0) if kept else np.full(5, np.nan)
+    return {"RR": float(np.mean(acc)) if acc else 0.0, "RRE": float(m[0]), "RTE": float(m[1]), "Rx": float(m[2]), "Ry": float(m[3]),
+            "Rz": float(m[4]), "pairs": len(acc), "accepted": len(kept)}

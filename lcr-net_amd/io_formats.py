@@ -2,7 +2,7 @@
 consume this package's outputs unchanged.
 
   * per-frame descriptor  `{seq_id}_{idx}.npz`, key `anc_global` (1,256) f32   — test_loop_detection.py:60-69
-  * retrieval rows        `predicted_des_L2_dis.npz`, `arr_0` float64 [R,3] = (query i, match j, squared L2), 50 rows per
+  * retrieval rows        `predicted_des_L2_dis.npz`, `arr_0` float64 [R,1,3] = (query i, match j, squared L2), 50 rows per
     query frame 101..C-2 in ascending distance; queries whose database holds fewer than k frames are filled the way faiss
     fills them (j = -1, d = FLT_MAX)                                            — eval_loop_detection_overlap_dataset.py:183-219
   * demo text line        `pos anc L2 r11 … t3`                                 — demo/demo.py:80-81
@@ -37,10 +37,49 @@ def pair_dist_rows(query_ids, idx, d2):
 
 
 def save_pair_dist(features_root, rows):
-    np.savez_compressed(os.path.join(features_root, "predicted_des_L2_dis"), np.asarray(rows, dtype=np.float64))
+    """`predicted_des_L2_dis.npz`, `arr_0` float64 [R,1,3]: the reference stacks (1,3) rows (eval_..._dataset.py:203-217), and both
+    of its readers reshape to (R,3) (:32-33, :226-227)."""
+    np.savez_compressed(os.path.join(features_root, "predicted_des_L2_dis"), np.asarray(rows, dtype=np.float64).reshape(-1, 1, 3))
 
 
 def lcr_output_line(pos_idx, anc_idx, pos_global, anc_global, estimated_transform):
     feat_dis = float(np.sqrt(np.sum((np.asarray(pos_global) - np.asarray(anc_global)) ** 2)))
     m = np.asarray(estimated_transform, dtype=np.float64).reshape(-1)[:12]
     return f"{pos_idx} {anc_idx} {feat_dis:.2f} " + " ".join(f"{v:.6f}" for v in m) + " \n"
+
+
+# keys of the per-pair registration file, in the reference's order (demo/demo.py:84-105; experiments/registration/test_registration.py
+# writes the same file and experiments/registration/eval.py reads it back)
+REGISTRATION_KEYS = ("pos_points_f", "anc_points_f", "pos_points_c", "anc_points_c", "pos_node_corr_indices", "anc_node_corr_indices",
+                     "pos_corr_points", "anc_corr_points", "corr_scores", "gt_node_corr_indices", "gt_node_corr_overlaps",
+                     "estimated_transform")
+
+
+def _to_numpy(v):
+    if hasattr(v, "detach"):
+        v = v.detach().cpu().numpy()
+    return np.asarray(v)
+
+
+def save_registration(output_dir, seq_id, anchor_idx, positive_idx, output_dict, transform):
+    """`{seq_id}_{anchor_idx}_{positive_idx}.npz` with the 15 arrays of demo/demo.py:86-105 (the model's output dict + the
+    ground-truth `transform` of the data dict + both global descriptors).  Returns the path."""
+    # gt_node_corr_indices / gt_node_corr_overlaps are written by demo.py:97-98 but are NOT produced by the shipped
+    # LCRNet.forward (LCRNet.py:161-321 never sets them; only the training-time loss path reads them, loss_reg.py:175,256): when the
+    # output dict has none they are stored empty, (0,2) int64 / (0,) f32, so that experiments/registration/eval.py:97-98 can open the file
+    empty = {"gt_node_corr_indices": np.zeros((0, 2), dtype=np.int64), "gt_node_corr_overlaps": np.zeros((0,), dtype=np.float32)}
+    arrays = {k: (_to_numpy(output_dict[k]) if k in output_dict else empty[k]) for k in REGISTRATION_KEYS}
+    arrays["transform"] = _to_numpy(transform)
+    arrays["pos_feature_global"] = _to_numpy(output_dict["pos_feature_global"])
+    arrays["anc_feature_global"] = _to_numpy(output_dict["anc_feature_global"])
+    path = os.path.join(output_dir, f"{seq_id}_{anchor_idx}_{positive_idx}.npz")
+    np.savez_compressed(path, **arrays)
+    return path
+
+
+def load_registration(path):
+    """-> dict of arrays; `estimated_transform` falls back to `estimated_transform_lgr` like eval.py:171-175."""
+    d = dict(np.load(path))
+    if "estimated_transform" not in d and "estimated_transform_lgr" in d:
+        d["estimated_transform"] = d["estimated_transform_lgr"]
+    return d

@@ -38,13 +38,13 @@ GT_COPY = os.path.join(HERE, "loop_gt_seq00_0.3overlap_inactive.npz")
 
 def synthetic_descriptors(ground_truth, seed=0, dim=256):
     """[C, dim] unit-norm f32.  Frames without a loop: random directions.  Frames with ground-truth loops: their first loop
-    partner's descriptor plus noise whose size cycles through 5 levels (0.05 .. 0.9 of unit norm), renormalised — the nearest
+    partner's descriptor plus noise whose size cycles through 5 levels (0.3 .. 6 x unit norm), renormalised — the nearest
     neighbour is a true loop for the quiet ones and a random frame for the loud ones."""
     rng = np.random.default_rng(seed)
     C = len(ground_truth)
     d = rng.standard_normal((C, dim)).astype(np.float32)
     d /= np.linalg.norm(d, axis=1, keepdims=True)
-    levels = np.array([0.05, 0.2, 0.45, 0.7, 0.9], dtype=np.float32)
+    levels = np.array([0.3, 1.0, 2.5, 4.0, 6.0], dtype=np.float32)
     for i in range(C):
         gt = np.asarray(ground_truth[i])
         if gt.any():
@@ -153,6 +153,8 @@ def main():
     rows, P, R, ap, f1, f1_idx, tops, auc = run_reference(desc, GT_COPY, [1, 45, 5])
     print("kitti00: rows", rows.shape, "top1 %.4f top45 %.4f top5 %.4f  F1 %.4f@%d  AP %.4f  AUC %.3f  PR points %d" % (tops[0], tops[1], tops[2], f1, f1_idx, ap, auc, len(P)))
     k = 50
+    assert rows.shape[1:] == (1, 3)                                # the reference stacks (1,3) rows: predicted_des_L2_dis.npz holds [R,1,3]
+    rows = rows.reshape(-1, 3)
     q = rows[:, 0].reshape(-1, k)
     assert (q == q[:, :1]).all() and q[0, 0] == 101 and q[-1, 0] == len(gt) - 2
     store["k00_query_first_last"] = np.array([q[0, 0], q[-1, 0]], dtype=np.int64)
@@ -168,7 +170,7 @@ def main():
     rows, P, R, ap, f1, f1_idx, tops, auc = run_reference(d2, gtf, [1, 3])
     shutil.rmtree(tmp)
     print("small: rows", rows.shape, "top1 %.4f top3 %.4f  F1 %.4f@%d  AP %.4f  AUC %.3f" % (tops[0], tops[1], f1, f1_idx, ap, auc))
-    store["small_rows"] = rows.astype(np.float64)          # full [R,3] rows incl. the -1 / FLT_MAX fill (298 queries x 50)
+    store["small_rows"] = rows.reshape(-1, 3).astype(np.float64)   # full [R,3] rows incl. the -1 / FLT_MAX fill (298 queries x 50)
     store["small_precisions"], store["small_recalls"] = P, R
     store["small_scalars"] = np.array([tops[0], tops[1], f1, f1_idx, ap, auc], dtype=np.float64)
     np.savez_compressed(os.path.join(HERE, "retrieval_golden.npz"), **store)

@@ -29,7 +29,8 @@ def test_pair_dist_rows_and_metrics(tmp_path):
     assert rows[0, 0] == 101 and rows[0, 1] == 0                      # frame 101 has a 1-frame database
     assert rows[1, 1] == -1 and rows[1, 2] == float(io.FAISS_EMPTY_DISTANCE)
     io.save_pair_dist(str(tmp_path), rows)
-    assert np.array_equal(np.load(tmp_path / "predicted_des_L2_dis.npz")["arr_0"], rows)
+    back = np.load(tmp_path / "predicted_des_L2_dis.npz")["arr_0"]
+    assert back.shape == (len(rows), 1, 3) and np.array_equal(back.reshape(-1, 3), rows)       # the reference's [R,1,3] layout
     gt = np.empty(400, dtype=object)
     for i in range(400):
         gt[i] = np.array([i - 200]) if i >= 200 else np.array([])

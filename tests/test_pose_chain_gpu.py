@@ -1,0 +1,120 @@
+"""GPU: the pose tail (a-10) stage by stage on the REFERENCE'S OWN intermediates (tests/golden/pose_chain_golden.npz, produced by
+forward hooks on the imported reference modules — make_golden_pose_chain.py), at north_star's tolerance: poses within 1e-4,
+integer results (NMS counts, correspondences, inlier counts, winning hypothesis) exact.  Unlike the whole-pair comparison in
+test_pose_gpu.py these do not depend on a random-weight consensus: every stage sees exactly the tensors the reference stage saw.
+
+Reference: backbone4.py:121-220 (Vote_Encoder), vote/vote.py:13-70 (greedy NMS), geotransformer/local_global_registration.py:52-246,
+registration/procrustes.py:6-73."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, LIMITS, NUM_STAGES, RADIUS, VOXEL, load_scan
+from oracle import ops as oracle_ops
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, GOLDEN)
+TOL = 1e-4                                   # BASELINE.json north_star: "descriptors/poses within 1e-4 fp32"
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLDEN, "pose_chain_golden.npz"))
+
+
+@pytest.fixture(scope="module")
+def model():
+    from lcrnet_amd.config import make_cfg
+    from lcrnet_amd.model_family import LCRNet
+    from lcrnet_amd.weights import seeded_state_dict
+    seed = json.load(open(os.path.join(GOLDEN, "model_manifest.json")))["seed"]
+    cfg = make_cfg()
+    cfg["neighbor_limits"] = LIMITS
+    m = LCRNet(cfg).eval()
+    m.load_state_dict(seeded_state_dict(m.state_dict(), seed), strict=True)
+    return m.cuda()
+
+
+def cu(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def test_vote_nms_node_centres_on_reference_features(gold, model):
+    """A: reference `enhanced_feats_c` -> vote offsets (clamped) -> exact greedy NMS -> node centres -> node features."""
+    a, b = load_scan("003854"), load_scan("000958")
+    st = oracle_ops.precompute_data_stack_mode(np.concatenate([a, b]), np.array([len(a), len(b)]), NUM_STAGES, VOXEL, RADIUS, LIMITS)
+    dd = {k: [cu(t) for t in v] for k, v in st.items()}
+    with torch.no_grad():
+        vd = model.vote_encoder(cu(gold["A_enhanced_feats_c"]), dd)
+    n0 = gold["A_shifted_pos_points_c"].shape[0]
+    shifted = vd["shifted_points_c"].cpu().numpy()
+    e_shift = max(np.abs(shifted[:n0] - gold["A_shifted_pos_points_c"]).max(), np.abs(shifted[n0:] - gold["A_shifted_anc_points_c"]).max())
+    assert vd["length"].cpu().tolist() == gold["A_length"].tolist()                       # greedy NMS: same nodes kept ...
+    m0 = int(gold["A_length"][0])
+    centres = vd["points_c"].cpu().numpy()
+    e_ctr = max(np.abs(centres[:m0] - gold["A_pos_points_c"]).max(), np.abs(centres[m0:] - gold["A_anc_points_c"]).max())
+    feats = vd["feats_c"].cpu().numpy()
+    want = np.concatenate([gold["A_pos_feats_c"], gold["A_anc_feats_c"]])
+    e_feat = np.abs(feats - want).max()
+    scale = np.abs(want).max()
+    print("vote chain on reference features: shifted %.2e  centres %.2e  node feats %.2e (|feat|max %.2f)" % (e_shift, e_ctr, e_feat, scale))
+    assert e_shift < TOL and e_ctr < TOL                                                   # ... at the same places (1e-4 m)
+    assert e_feat < TOL * max(1.0, scale)
+
+
+def _run_lgr(model, ref, src, rm, sm, logs):
+    from lcrnet_amd import functional as F
+    with torch.no_grad():
+        rp, sp, sc, T = model._local_global_registration(cu(ref), cu(src), cu(rm), cu(sm), cu(logs))
+        # the intermediates, through the same kernels the model method uses
+        bij, sc2 = F.top1_matching(cu(logs), cu(rm), cu(sm))
+        P, K = rm.shape
+        b = bij[:, 0].long()
+        start = torch.zeros(P + 1, dtype=torch.int32, device="cuda")
+        start[1:] = torch.cumsum(torch.bincount(b, minlength=P), 0).int()
+        hyp = F.procrustes(sp, rp, sc, start)
+        counts, best = F.inlier_count(hyp, sp, rp, model.acceptance_radius, start, model.correspondence_threshold)
+    return rp.cpu().numpy(), sp.cpu().numpy(), sc.cpu().numpy(), T.cpu().numpy(), bij.cpu().numpy(), hyp.cpu().numpy(), counts.cpu().numpy(), int(best.item())
+
+
+def _check_lgr(tag, got, g, prefix):
+    rp, sp, sc, T, bij, hyp, counts, best = got
+    assert np.array_equal(bij.astype(np.int32), g[prefix + "corr_bij"]), "dense correspondences differ"      # exact: (patch, i, j) rows, row-major
+    assert np.array_equal(rp, g[prefix + "ref_corr_points"]) and np.array_equal(sp, g[prefix + "src_corr_points"])
+    e_sc = np.abs(sc - g[prefix + "corr_scores"]).max()
+    chunks = g[prefix + "chunks"]
+    sizes = np.bincount(bij[:, 0], minlength=int(bij[:, 0].max()) + 1)
+    valid = np.nonzero(sizes >= 3)[0]                                   # hypotheses exist for patches with >= 3 correspondences
+    assert len(valid) == len(chunks)
+    cnt = counts[valid]
+    assert np.array_equal(cnt, g[prefix + "inlier_counts"]), "per-hypothesis inlier counts differ"            # integers: exact
+    assert int(np.nonzero(valid == best)[0][0]) == int(g[prefix + "best"]), "another hypothesis won"
+    e_hyp = np.abs(hyp[valid] - g[prefix + "hypotheses"]).max()
+    e_T = np.abs(T - g[prefix + "transform"]).max()
+    print("%s: %d correspondences, %d hypotheses, best %d (%d inliers): scores %.2e  hypotheses %.2e  T %.2e" %
+          (tag, len(sc), len(valid), int(g[prefix + "best"]), int(cnt.max()), e_sc, e_hyp, e_T))
+    assert e_sc < 1e-6
+    assert e_T < TOL, (T, g[prefix + "transform"])
+    return e_hyp
+
+
+def test_local_global_registration_on_reference_intermediates(gold, model):
+    """B: 40 of the reference's 639 patch correspondences (its knn points, masks and log matching scores) -> the transform the
+    reference's own LocalGlobalRegistration returns for them, within 1e-4; integer stages exact."""
+    got = _run_lgr(model, gold["B_ref_knn_points"], gold["B_src_knn_points"], gold["B_ref_knn_masks"], gold["B_src_knn_masks"], gold["B_log_scores"])
+    _check_lgr("reference subset", got, gold, "B_")
+
+
+def test_local_global_registration_well_conditioned(gold, model):
+    """C: seeded synthetic patches with a known motion, outlier patches and confident wrong matches: every hypothesis, the winner and
+    the refined pose equal the reference module's to 1e-4, and the pose is the true one to 1e-3."""
+    from make_golden_pose_chain import synthetic_lgr_case
+    ref, src, rm, sm, logs, T_true = synthetic_lgr_case()
+    got = _run_lgr(model, ref, src, rm, sm, logs)
+    e_hyp = _check_lgr("synthetic", got, gold, "C_")
+    assert e_hyp < TOL
+    assert np.abs(got[3] - T_true).max() < 1e-3

@@ -12,6 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+REPS = int(os.environ.get("LCR_RB_REPS", "20"))
+
+
 def main():
     import bench
     from lcrnet_amd.data import voxelize_raw_scans
@@ -43,11 +46,11 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
-        for _ in range(20):
+        for _ in range(REPS):
             out = fn()
         e1.record()
         torch.cuda.synchronize()
-        t = e0.elapsed_time(e1) / 20 * 1e3
+        t = e0.elapsed_time(e1) / REPS * 1e3
         total += t
         nq, H = out.shape
         print("%-16s nq=%7d limit=%3d  %8.1f us  %6.1f GB/s out   sum %d" % (tag, nq, H, t, nq * H * 4 / t / 1e3, int(out.long().sum())))
@@ -58,6 +61,8 @@ def main():
             timed("subsampling[%d]" % i, lambda: grids[i].query(P[i + 1], L[i + 1], bench.LIMITS[i]))
             timed("upsampling[%d]" % i, lambda: grids[i + 1].query(P[i], L[i], bench.LIMITS[i + 1]))
     print("total %.1f us" % total)
+    if os.environ.get("LCR_RB_NO_CELL_ORDER"):
+        return
     # the same searches with the QUERIES permuted into their own grid's cell order (spatially coherent wavefronts)
     total = 0.0
     Pc = [P[i][grids[i].order().long()].contiguous() for i in range(bench.NUM_STAGES)]
