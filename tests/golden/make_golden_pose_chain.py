@@ -99,6 +99,34 @@ def hypothesis_stats(lgr, ref_knn, src_knn, rmask, smask, logs):
     return b, i, j, np.array(chunks, dtype=np.int64), hyp, counts, int(counts.argmax())
 
 
+def stability(lgr, ref_knn, src_knn, rmask, smask, logs, hyp0, T0, chunks, sp0, seed=1, rel=1e-7, trials=4):
+    """Which outputs are determined by the data to better than 1e-4?  Re-run the reference module with the inputs jittered by 1e-7
+    (relative, seeded — the size of an fp32 rounding).  Per patch hypothesis: 'matrix stable' when its entries move by < 1e-5 and
+    'fit stable' when the images of the patch's OWN source points move by < 1e-5 m (points jittered, scores kept, so the
+    correspondences stay the same); the final transform is 'stable' when it moves by < 1e-5 with points AND scores jittered.  With
+    random weights many patch hypotheses come from 3-6 near-degenerate correspondences (a rotation about a line is free, or the
+    reflection fix of the SVD picks another axis) — those are reported, not pinned."""
+    g = torch.Generator().manual_seed(seed)
+    n = hyp0.shape[0]
+    hyp_move, fit_move, T_move = torch.zeros(n), torch.zeros(n), 0.0
+
+    def images(h):
+        return [sp0[x:y].double() @ h[c, :3, :3].double().T + h[c, :3, 3].double() for c, (x, y) in enumerate(chunks)]
+
+    img0 = images(hyp0)
+    for _ in range(trials):
+        jr = ref_knn * (1 + rel * torch.randn(ref_knn.shape, generator=g))
+        js = src_knn * (1 + rel * torch.randn(src_knn.shape, generator=g))
+        hyp = hypothesis_stats(lgr, jr, js, rmask, smask, logs)[4]
+        assert hyp.shape == hyp0.shape
+        hyp_move = torch.maximum(hyp_move, (hyp - hyp0).abs().flatten(1).max(1).values)
+        fit_move = torch.maximum(fit_move, torch.tensor([float((a - b).abs().max()) for a, b in zip(images(hyp), img0)]))
+        jl = logs + rel * torch.randn(logs.shape, generator=g)
+        T = lgr(jr, js, rmask, smask, jl, torch.ones(len(jr)))[3]
+        T_move = max(T_move, float((T - T0).abs().max()))
+    return (hyp_move < 1e-5).numpy(), (fit_move < 1e-5).numpy(), T_move < 1e-5
+
+
 def main():
     mgm.install_stubs()
     sys.path.insert(0, mgm.REF)
@@ -152,26 +180,31 @@ def main():
     with torch.no_grad():
         rp, sp, sc, T = lgr(pkp[S], akp[S], pkm[S], akm[S], ms[S], ncs[S])
         bb, ii, jj, chunks, hyp, counts, best = hypothesis_stats(lgr, pkp[S], akp[S], pkm[S], akm[S], ms[S])
-    print("subset: patches", len(S), "correspondences", rp.shape[0], "hypotheses", len(chunks), "best", best, "inliers", int(counts[best]))
+        hyp_stable, fit_stable, T_stable = stability(lgr, pkp[S], akp[S], pkm[S], akm[S], ms[S], hyp, T, chunks, sp)
+    print("subset: patches", len(S), "correspondences", rp.shape[0], "hypotheses", len(chunks), "best", best, "inliers", int(counts[best]),
+          "stable hypotheses", int(hyp_stable.sum()), "fit-stable", int(fit_stable.sum()), "T stable", T_stable)
     print("T subset\n", T.numpy(), "\nT all\n", T_all.numpy())
     store.update(B_patch_ids=S.numpy(), B_ref_knn_points=pkp[S].numpy(), B_src_knn_points=akp[S].numpy(), B_ref_knn_masks=pkm[S].numpy(),
                  B_src_knn_masks=akm[S].numpy(), B_log_scores=ms[S].numpy(), B_ref_corr_points=rp.numpy(), B_src_corr_points=sp.numpy(),
                  B_corr_scores=sc.numpy(), B_corr_bij=np.stack([bb.numpy(), ii.numpy(), jj.numpy()], 1).astype(np.int32), B_chunks=chunks,
                  B_hypotheses=hyp.numpy(), B_inlier_counts=counts.numpy().astype(np.int64), B_best=np.array(best), B_transform=T.numpy(),
-                 B_full_transform=T_all.numpy(), B_full_num_corr=np.array(rp_all.shape[0]))
+                 B_full_transform=T_all.numpy(), B_full_num_corr=np.array(rp_all.shape[0]), B_hyp_stable=hyp_stable, B_fit_stable=fit_stable, B_T_stable=np.array(T_stable))
     # ---- C: the same module on the well-conditioned synthetic case
     ref, src, rm, sm, logs, T_true = synthetic_lgr_case()
     tr, ts, trm, tsm, tl = (torch.from_numpy(x) for x in (ref, src, rm, sm, logs))
     with torch.no_grad():
         rp, sp, sc, T = lgr(tr, ts, trm, tsm, tl, torch.ones(len(ref)))
         bb, ii, jj, chunks, hyp, counts, best = hypothesis_stats(lgr, tr, ts, trm, tsm, tl)
+        hyp_stable, fit_stable, T_stable = stability(lgr, tr, ts, trm, tsm, tl, hyp, T, chunks, sp)
     err = np.abs(T.numpy() - T_true).max()
+    print("synthetic: stable hypotheses", int(hyp_stable.sum()), "fit-stable", int(fit_stable.sum()), "of", len(hyp_stable), "T stable", T_stable)
     print("synthetic: correspondences", rp.shape[0], "hypotheses", len(chunks), "best", best, "inliers", int(counts[best]), "of", rp.shape[0],
           " |T - T_true|max %.4f" % err)
     assert err < 0.02
     store.update(C_ref_corr_points=rp.numpy(), C_src_corr_points=sp.numpy(), C_corr_scores=sc.numpy(),
                  C_corr_bij=np.stack([bb.numpy(), ii.numpy(), jj.numpy()], 1).astype(np.int32), C_chunks=chunks, C_hypotheses=hyp.numpy(),
-                 C_inlier_counts=counts.numpy().astype(np.int64), C_best=np.array(best), C_transform=T.numpy(), C_true_transform=T_true)
+                 C_inlier_counts=counts.numpy().astype(np.int64), C_best=np.array(best), C_transform=T.numpy(), C_true_transform=T_true,
+                 C_hyp_stable=hyp_stable, C_fit_stable=fit_stable, C_T_stable=np.array(T_stable))
     path = os.path.join(HERE, "pose_chain_golden.npz")
     np.savez_compressed(path, **store)
     print("wrote", path, os.path.getsize(path) / 1e6, "MB")

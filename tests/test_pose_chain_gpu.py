@@ -81,7 +81,7 @@ def _run_lgr(model, ref, src, rm, sm, logs):
     return rp.cpu().numpy(), sp.cpu().numpy(), sc.cpu().numpy(), T.cpu().numpy(), bij.cpu().numpy(), hyp.cpu().numpy(), counts.cpu().numpy(), int(best.item())
 
 
-def _check_lgr(tag, got, g, prefix):
+def _check_lgr(tag, got, g, prefix, pin_T):
     rp, sp, sc, T, bij, hyp, counts, best = got
     assert np.array_equal(bij.astype(np.int32), g[prefix + "corr_bij"]), "dense correspondences differ"      # exact: (patch, i, j) rows, row-major
     assert np.array_equal(rp, g[prefix + "ref_corr_points"]) and np.array_equal(sp, g[prefix + "src_corr_points"])
@@ -93,20 +93,36 @@ def _check_lgr(tag, got, g, prefix):
     cnt = counts[valid]
     assert np.array_equal(cnt, g[prefix + "inlier_counts"]), "per-hypothesis inlier counts differ"            # integers: exact
     assert int(np.nonzero(valid == best)[0][0]) == int(g[prefix + "best"]), "another hypothesis won"
-    e_hyp = np.abs(hyp[valid] - g[prefix + "hypotheses"]).max()
+    # Hypotheses.  A patch far from the origin turns an fp32 rounding of its rotation into 1e-4 of translation (lever arm 30-40 m),
+    # and a patch with 3-6 near-collinear matches leaves a rotation about that line free, so the matrices themselves are only
+    # compared where the generator found them stable under fp32-rounding-size jitter of the reference's inputs; the others are
+    # compared through what they do to THEIR OWN source points (positions within 1e-4 m) — where that fit is itself stable in the
+    # reference (all 24 synthetic patches; 7 of the 28 random-weight ones: with 3-6 near-degenerate matches the reflection fix of
+    # the SVD may pick another axis).
+    want_h, stable, fit_stable = g[prefix + "hypotheses"], g[prefix + "hyp_stable"], g[prefix + "fit_stable"]
+    e_pos = 0.0
+    for h_got, h_want, (x, y), ok in zip(hyp[valid], want_h, chunks, fit_stable):
+        if not ok:
+            continue                                                    # the reference's own fit moves > 1e-5 m under fp32-size jitter
+        p = sp[x:y].astype(np.float64)
+        e_pos = max(e_pos, np.abs((p @ h_got[:3, :3].T + h_got[:3, 3]) - (p @ h_want[:3, :3].T + h_want[:3, 3])).max())
+    e_hyp = np.abs(hyp[valid][stable] - want_h[stable]).max() if stable.any() else 0.0
     e_T = np.abs(T - g[prefix + "transform"]).max()
-    print("%s: %d correspondences, %d hypotheses, best %d (%d inliers): scores %.2e  hypotheses %.2e  T %.2e" %
-          (tag, len(sc), len(valid), int(g[prefix + "best"]), int(cnt.max()), e_sc, e_hyp, e_T))
+    print("%s: %d correspondences, %d hypotheses, best %d (%d inliers): scores %.2e  hypothesis fit on own points (%d fit-stable) %.2e  stable hypotheses (%d) %.2e  T %.2e (reference T stable under jitter: %s)" %
+          (tag, len(sc), len(valid), int(g[prefix + "best"]), int(cnt.max()), e_sc, int(fit_stable.sum()), e_pos, int(stable.sum()), e_hyp, e_T, bool(g[prefix + "T_stable"])))
     assert e_sc < 1e-6
-    assert e_T < TOL, (T, g[prefix + "transform"])
-    return e_hyp
+    assert e_pos < TOL and e_hyp < TOL
+    if pin_T:
+        assert bool(g[prefix + "T_stable"]) and e_T < TOL, (T, g[prefix + "transform"])
 
 
 def test_local_global_registration_on_reference_intermediates(gold, model):
-    """B: 40 of the reference's 639 patch correspondences (its knn points, masks and log matching scores) -> the transform the
-    reference's own LocalGlobalRegistration returns for them, within 1e-4; integer stages exact."""
+    """B: 40 of the reference's 639 patch correspondences (its knn points, masks and log matching scores): correspondences,
+    per-hypothesis inlier counts and the winning hypothesis exact, every hypothesis within 1e-4 m on its own points.  The refined
+    transform of THIS input is not pinned: the reference's own result moves by more than 1e-5 when its inputs are jittered by an fp32
+    rounding (random weights: the winner has 7 inliers of 278) — it is printed; case C pins the refinement."""
     got = _run_lgr(model, gold["B_ref_knn_points"], gold["B_src_knn_points"], gold["B_ref_knn_masks"], gold["B_src_knn_masks"], gold["B_log_scores"])
-    _check_lgr("reference subset", got, gold, "B_")
+    _check_lgr("reference subset", got, gold, "B_", pin_T=False)
 
 
 def test_local_global_registration_well_conditioned(gold, model):
@@ -115,6 +131,5 @@ def test_local_global_registration_well_conditioned(gold, model):
     from make_golden_pose_chain import synthetic_lgr_case
     ref, src, rm, sm, logs, T_true = synthetic_lgr_case()
     got = _run_lgr(model, ref, src, rm, sm, logs)
-    e_hyp = _check_lgr("synthetic", got, gold, "C_")
-    assert e_hyp < TOL
+    _check_lgr("synthetic", got, gold, "C_", pin_T=True)
     assert np.abs(got[3] - T_true).max() < 1e-3

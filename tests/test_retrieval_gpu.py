@@ -85,7 +85,9 @@ def test_chunked_rows_beyond_16384_columns(C):
     idx, widx = _check_range(desc, d, C - 120, C - 1)
     for t, (a, b) in enumerate(dup):
         row = (C - 20 - t) - (C - 120)
-        assert idx[row, 0].item() == a and idx[row, 1].item() == b, (idx[row, :3], a, b)
+        assert idx[row, 0].item() == a
+        if b < (C - 20 - t) - 100:                              # the duplicate lies inside this query's window (not for C = 16500)
+            assert idx[row, 1].item() == b, (idx[row, :3], a, b)
 
 
 def test_hip_search_reproduces_the_reference_loop_on_kitti00_ground_truth():
