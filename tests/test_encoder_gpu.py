@@ -114,7 +114,7 @@ def test_residual_blocks_match_torch_ref(model):
     got = {"encoder1_2": feats[0], "encoder2_3": feats[1], "encoder3_3": feats[2], "encoder4_3": feats[3]}
     for name, g in got.items():
         err = (g.cpu() - trace[name]).abs().max().item()
-        assert err < 5e-4, (name, err)
+        assert err < 1e-4 * max(1.0, trace[name].abs().max().item()), (name, err)      # relative to the stage's magnitude (up to ~80)
 
 
 def test_descriptor_matches_reference_golden(model, model_golden):
@@ -129,7 +129,7 @@ def test_descriptor_matches_reference_golden(model, model_golden):
         assert (g - want).abs().max().item() < DESC_TOL, (name, (g - want).abs().max().item())
         if name == "003854":
             fc = torch.from_numpy(model_golden["003854/feats_c"])
-            assert (out["feats_c"].cpu() - fc).abs().max().item() < 1e-3
+            assert (out["feats_c"].cpu() - fc).abs().max().item() < 1e-4 * max(1.0, fc.abs().max().item())   # measured 2.5e-6 relative (tests/test_float_parity_gpu.py)
 
 
 def test_gpu_pipeline_batch_equals_single_scans(model, model_golden):
@@ -169,7 +169,8 @@ def test_pair_stack_groupnorm_over_pair(model, model_golden):
         fc = model.encoder(torch.ones(dd["points"][0].shape[0], 1, device="cuda"), dd)[-1]
         g = model.netvlad.describe(fc, [n0, fc.shape[0] - n0]).cpu()
     r = model_golden["pair/feats_c_rows"]
-    assert (fc.cpu()[r] - torch.from_numpy(model_golden["pair/feats_c_vals"])).abs().max().item() < 1e-3
+    want_fc = torch.from_numpy(model_golden["pair/feats_c_vals"])
+    assert (fc.cpu()[r] - want_fc).abs().max().item() < 1e-4 * max(1.0, want_fc.abs().max().item())
     assert (g[0] - torch.from_numpy(model_golden["pair/pos_global"])[0]).abs().max().item() < DESC_TOL
     assert (g[1] - torch.from_numpy(model_golden["pair/anc_global"])[0]).abs().max().item() < DESC_TOL
 

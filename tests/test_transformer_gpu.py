@@ -63,5 +63,5 @@ def test_pair_model_transformer_and_descriptors():
         rows = golden[f"pair/{tag}_tf_rows"]
         want = torch.from_numpy(golden[f"pair/{tag}_tf_vals"])
         err = (e.cpu()[rows] - want).abs().max().item()
-        assert err < 5e-4, (tag, err)
+        assert err < 1e-4, (tag, err)                                    # measured 5.0e-5 / 1.3e-5 on features of magnitude 4
         assert abs(e.abs().mean().item() - golden[f"pair/{tag}_tf_stats"][1]) < 1e-4
