@@ -248,6 +248,11 @@ int lcr_rotary_embed(float* x, const float* theta, int64_t N, int heads, void* s
 /* out[Nq, heads*32] = softmax(q k^T / sqrt(32)) v per head, fused (no score matrix in memory); head_dim must be 32. */
 int lcr_attention_f32(const float* q, const float* k, const float* v, int64_t Nq, int64_t Nk, int heads, int head_dim,
                       float* out, void* stream);
+/* P (<= 64) independent attention problems in one launch over stacked q / k / v: problem p attends its q_len[p] query rows to its
+ * k_len[p] key rows (HOST arrays; rows are stacked in problem order).  The batch form of RPEMultiHeadAttention /
+ * MultiHeadAttention for P registration pairs per call (reference loop: model_family/LCRNet.py:274-321, one pair per forward). */
+int lcr_attention_seg_f32(const float* q, const float* k, const float* v, const int64_t* q_len_host, const int64_t* k_len_host, int P,
+                          int heads, int head_dim, float* out, void* stream);
 /* y = LayerNorm(a + b) (b may be NULL), rows of D <= 1024 features. */
 int lcr_add_layernorm(const float* a, const float* b, const float* gamma, const float* beta, int64_t N, int D, float eps,
                       float* y, void* stream);

@@ -83,13 +83,11 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ src, int64_t
   }
 }
 
-// q [Nq, H*32], k/v [Nk, H*32] -> out [Nq, H*32];  grid (ceil(Nq/32), H), 64 threads
-__global__ __launch_bounds__(64) void k_attention(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-                                                  int64_t Nq, int64_t Nk, int heads, float scale, float* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) float s_q[32 * AT_LD], s_k[32 * AT_LD], s_v[32 * AT_LD];
+// one (head, 32-query tile) of one attention problem: q [Nq, H*32], k/v [Nk, H*32] -> out [Nq, H*32]; 64 threads
+__device__ __forceinline__ void attention_tile(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                               int64_t Nq, int64_t Nk, int heads, float scale, float* __restrict__ out, int64_t q0, int head,
+                                               float* s_q, float* s_k, float* s_v) {
   const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
-  const int head = blockIdx.y;
-  const int64_t q0 = static_cast<int64_t>(blockIdx.x) * 32;
   const int ld = heads * AT_D;
   load_tile(q, Nq, q0, ld, head * AT_D, s_q);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -179,6 +177,32 @@ __global__ __launch_bounds__(64) void k_attention(const float* __restrict__ q, c
   }
 }
 
+// grid (ceil(Nq/32), H)
+__global__ __launch_bounds__(64) void k_attention(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                  int64_t Nq, int64_t Nk, int heads, float scale, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float s_q[32 * AT_LD], s_k[32 * AT_LD], s_v[32 * AT_LD];
+  attention_tile(q, k, v, Nq, Nk, heads, scale, out, static_cast<int64_t>(blockIdx.x) * 32, blockIdx.y, s_q, s_k, s_v);
+}
+
+// Several independent attention problems in ONE launch (registration pairs batched per call: the self layers of 2P clouds, the
+// cross layers of P pairs): problem p attends queries [q_off[p], q_off[p+1]) to keys [k_off[p], k_off[p+1]) of the stacked
+// tensors.  One pair alone is 27 query tiles x 4 heads = 108 wavefronts on 256 CUs; P pairs fill the chip.
+constexpr int AT_MAX_P = 64;
+struct AttnSeg {
+  int P;
+  int q_off[AT_MAX_P + 1], k_off[AT_MAX_P + 1], tile_off[AT_MAX_P + 1];   // row offsets; first query tile of every problem
+};
+__global__ __launch_bounds__(64) void k_attention_seg(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                      AttnSeg seg, int heads, float scale, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float s_q[32 * AT_LD], s_k[32 * AT_LD], s_v[32 * AT_LD];
+  int p = 0;
+  while (p + 1 < seg.P && static_cast<int>(blockIdx.x) >= seg.tile_off[p + 1]) ++p;      // block-uniform, scalar
+  const int ld = heads * AT_D;
+  const int64_t qo = seg.q_off[p], ko = seg.k_off[p];
+  attention_tile(q + qo * ld, k + ko * ld, v + ko * ld, seg.q_off[p + 1] - qo, seg.k_off[p + 1] - ko, heads, scale, out + qo * ld,
+                 static_cast<int64_t>(static_cast<int>(blockIdx.x) - seg.tile_off[p]) * 32, blockIdx.y, s_q, s_k, s_v);
+}
+
 // y = LayerNorm(a + b) * gamma + beta, rows of D (<= 1024) features; one wavefront per row
 __global__ __launch_bounds__(256) void k_add_layernorm(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int64_t N, int D, float eps, float* __restrict__ y) {
@@ -235,9 +259,48 @@ extern "C" int lcr_attention_f32(const float* q, const float* k, const float* v,
   }
   if (Nq == 0) return LCR_OK;
   const float scale = 1.f / sqrtf(static_cast<float>(head_dim));
+  KernelTimerScope timed(KT_ATTENTION, static_cast<hipStream_t>(stream), Nq * Nk, 1, heads, head_dim);
   hipLaunchKernelGGL(k_attention, dim3(static_cast<int>((Nq + 31) / 32), heads), dim3(64), 0, static_cast<hipStream_t>(stream), q, k, v, Nq, Nk,
                      heads, scale, out);
   return check_launch("lcr_attention_f32");
+}
+
+extern "C" int lcr_attention_seg_f32(const float* q, const float* k, const float* v, const int64_t* q_len_host, const int64_t* k_len_host,
+                                     int P, int heads, int head_dim, float* out, void* stream) {
+  if (!q || !k || !v || !out || !q_len_host || !k_len_host || P < 1 || P > AT_MAX_P || heads < 1 || head_dim != AT_D) {
+    set_error("lcr_attention_seg_f32: bad argument (head_dim must be %d, 1 <= P <= %d)", AT_D, AT_MAX_P);
+    return LCR_EARG;
+  }
+  AttnSeg seg;
+  seg.P = P;
+  int64_t qo = 0, ko = 0, to = 0;
+  for (int p = 0; p < P; ++p) {
+    if (q_len_host[p] < 0 || k_len_host[p] < 1) {
+      set_error("lcr_attention_seg_f32: problem %d has %lld queries / %lld keys (keys >= 1)", p, static_cast<long long>(q_len_host[p]),
+                static_cast<long long>(k_len_host[p]));
+      return LCR_EARG;
+    }
+    seg.q_off[p] = static_cast<int>(qo);
+    seg.k_off[p] = static_cast<int>(ko);
+    seg.tile_off[p] = static_cast<int>(to);
+    qo += q_len_host[p];
+    ko += k_len_host[p];
+    to += (q_len_host[p] + 31) / 32;
+    if (qo > 2147483647 || ko > 2147483647) {
+      set_error("lcr_attention_seg_f32: more than 2^31-1 stacked rows");
+      return LCR_EARG;
+    }
+  }
+  seg.q_off[P] = static_cast<int>(qo);
+  seg.k_off[P] = static_cast<int>(ko);
+  seg.tile_off[P] = static_cast<int>(to);
+  if (to == 0) return LCR_OK;
+  const float scale = 1.f / sqrtf(static_cast<float>(head_dim));
+  int64_t qk = 0;
+  for (int p = 0; p < P; ++p) qk += q_len_host[p] * k_len_host[p];
+  KernelTimerScope timed(KT_ATTENTION, static_cast<hipStream_t>(stream), qk, P, heads, head_dim);
+  hipLaunchKernelGGL(k_attention_seg, dim3(static_cast<int>(to), heads), dim3(64), 0, static_cast<hipStream_t>(stream), q, k, v, seg, heads, scale, out);
+  return check_launch("lcr_attention_seg_f32");
 }
 
 extern "C" int lcr_add_layernorm(const float* a, const float* b, const float* gamma, const float* beta, int64_t N, int D, float eps, float* y,

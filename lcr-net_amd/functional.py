@@ -16,7 +16,7 @@ class KernelTimer:
     """Opt-in per-launch timing of lcr_gemm_f32 ("gemm", meta (M,N,K)) and lcr_kpconv_aggregate ("kpconv_aggregate", meta
     (M,Ns,H,C,index bytes)) with HIP events on the launch stream, recorded inside the library (so launches issued by the native
     encoder driver are seen too).  set_timer(t) starts a fresh log, set_timer(None) stops logging, t.summary() synchronises."""
-    KINDS = {"gemm": 0, "kpconv_aggregate": 1, "radius_query": 2}
+    KINDS = {"gemm": 0, "kpconv_aggregate": 1, "radius_query": 2, "attention": 3}
 
     def __init__(self, names):
         self.names = set(names)
@@ -32,7 +32,7 @@ class KernelTimer:
                 sec = (ctypes.c_double * max(n, 1))()
                 meta = (ctypes.c_int64 * (5 * max(n, 1)))()
                 L.lcr_ktimer_read(kind, n, ctypes.cast(sec, ctypes.c_void_p), ctypes.cast(meta, ctypes.c_void_p))
-                width = 3 if name == "gemm" else 5            # radius_query: (nq_cap, ns_cap, limit, index bytes, B)
+                width = 3 if name == "gemm" else 5            # radius_query: (nq_cap, ns_cap, limit, index bytes, B); attention: (sum Nq*Nk, P, heads, head_dim, 0)
                 out[name] = [(sec[i], tuple(int(meta[5 * i + k]) for k in range(width))) for i in range(n)]
             self._cache = out
         return self._cache
@@ -232,10 +232,19 @@ def rotary_embed_(x, theta, heads):
     return x
 
 
-def attention(q, k, v, heads):
-    """Fused softmax(q k^T / sqrt(d)) v per head; q [Nq, heads*32], k/v [Nk, heads*32]."""
+def attention(q, k, v, heads, q_lens=None, k_lens=None):
+    """Fused softmax(q k^T / sqrt(d)) v per head; q [Nq, heads*32], k/v [Nk, heads*32].  With q_lens / k_lens (host sequences of
+    equal length P <= 64, summing to Nq / Nk): P independent problems over the stacked rows in one launch."""
     assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
     out = torch.empty_like(q)
+    if q_lens is not None:
+        P = len(q_lens)
+        assert len(k_lens) == P and sum(q_lens) == q.shape[0] and sum(k_lens) == k.shape[0]
+        ql, kl = (ctypes.c_int64 * P)(*[int(x) for x in q_lens]), (ctypes.c_int64 * P)(*[int(x) for x in k_lens])
+        _lib.check(_lib.lib().lcr_attention_seg_f32(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), ctypes.cast(ql, ctypes.c_void_p),
+                                                    ctypes.cast(kl, ctypes.c_void_p), P, heads, q.shape[1] // heads, _lib.ptr(out),
+                                                    _lib.stream_ptr(q.device)), "lcr_attention_seg_f32")
+        return out
     _lib.check(_lib.lib().lcr_attention_f32(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), q.shape[0], k.shape[0], heads, q.shape[1] // heads,
                                             _lib.ptr(out), _lib.stream_ptr(q.device)), "lcr_attention_f32")
     return out

@@ -13,6 +13,7 @@ import torch.nn as nn
 from ..backbone4 import KPEncoder
 from ..config import make_cfg
 from ..modules.kpconv import LastUnaryBlock, ResidualBlock, UnaryBlock
+from ..modules.kpconv.modules import StageContext
 from .. import functional as F
 from ..modules.netvlad import NetVLADLoupe2
 from ..modules.ops import radius_search
@@ -55,7 +56,9 @@ class Vote_Encoder(nn.Module):
         self.init_radius = init_radius
         self.neighbor_limits = list(neighbor_limits)
 
-    def forward(self, feats, data_dict, neighbor_limit=None):
+    def forward(self, feats, data_dict, neighbor_limit=None, pairs=1):
+        """pairs > 1: the stack holds `pairs` registration pairs; GroupNorm statistics are taken per pair (the reference's
+        statistics over its one-pair stack), everything else is per cloud anyway."""
         limits = list(neighbor_limit) if neighbor_limit is not None else self.neighbor_limits
         lens_c = data_dict["lengths"][-1]
         points_c = data_dict["points"][-1].contiguous()
@@ -67,9 +70,13 @@ class Vote_Encoder(nn.Module):
         centers = F.neighbor_mean(shifted, knn, pad)
         sub = radius_search(centers, points_c, length, lens_c, self.init_radius * 8, limits[-2], check=False)
         nb = radius_search(centers, centers, length, length, self.init_radius * 16, limits[-1], check=False)
-        f = self.encoder6_1(feats, centers, points_c, sub)
-        f = self.encoder6_2(f, centers, centers, nb)
-        f = self.encoder6_3(f, centers, centers, nb)
+        if pairs > 1:
+            q_ctx, s_ctx = StageContext(length.view(pairs, 2).sum(1)), StageContext(lens_c.view(pairs, 2).sum(1))
+        else:
+            q_ctx = s_ctx = StageContext(None)
+        f = self.encoder6_1(feats, centers, points_c, sub, q_ctx, s_ctx)
+        f = self.encoder6_2(f, centers, centers, nb, q_ctx, q_ctx)
+        f = self.encoder6_3(f, centers, centers, nb, q_ctx, q_ctx)
         return {"shifted_points_c": shifted, "nms_mask": keep, "length": length, "points_c": centers, "feats_c": f}
 
 
@@ -82,11 +89,14 @@ class KPDecoder(nn.Module):
         self.decoder2 = UnaryBlock(init_dim * 12, init_dim * 4, group_norm)
         self.decoder1 = LastUnaryBlock(init_dim * 6, init_dim * 2)
 
-    def forward(self, feats, data_dict):
+    def forward(self, feats, data_dict, pairs=1):
         f1, f2, f3, f4 = feats
         U = data_dict["upsampling"]
-        l3 = self.decoder3(F.upsample_concat(f4, U[2], f3))
-        l2 = self.decoder2(F.upsample_concat(l3, U[1], f2))
+        L = data_dict["lengths"]
+        c3 = StageContext(L[2].view(pairs, 2).sum(1) if pairs > 1 else None)      # GroupNorm over a pair's two clouds
+        c2 = StageContext(L[1].view(pairs, 2).sum(1) if pairs > 1 else None)
+        l3 = self.decoder3(F.upsample_concat(f4, U[2], f3), c3)
+        l2 = self.decoder2(F.upsample_concat(l3, U[1], f2), c2)
         l1 = self.decoder1(F.upsample_concat(l2, U[0], f1))
         return [l1, l2, l3]
 
@@ -145,36 +155,91 @@ class LCRNet(nn.Module):
         """Pair stack [pos(ref), anc(src)] (data.py:110-113) -> the reference's output_dict (LCRNet.py:274-321).  GroupNorm
         statistics span the pair unless data_dict['segment_lengths'] says otherwise.  pose=False stops after the transformer
         and the global descriptors."""
+        return self.forward_pairs(data_dict, pose)[0]
+
+    def forward_pairs(self, data_dict, pose=True):
+        """P registration pairs per call: the stack is [pos_0, anc_0, pos_1, anc_1, ...] (2P clouds, P <= 32) -> a list of P
+        output dicts, each what `forward` returns for that pair alone (GroupNorm statistics are taken per pair, the reference's
+        one-pair stack; attention, matching and registration are per pair by construction).  The reference runs one pair per
+        forward (LCRNet.py:274-321, batch_size 1); batching turns its ~1000 small launches per pair into shared ones: encoder,
+        3D-RoFormer (segmented attention launch), NetVLAD, vote encoder and decoder run ONCE over the stack, and only the
+        matching / registration tail, whose tensor shapes depend on each pair's data, runs pair by pair."""
         if self.training:
             raise RuntimeError("lcr-net_amd implements inference only; call .eval()")
         feats = data_dict["features"].detach()
+        lens_dev = data_dict["lengths"]
+        B = lens_dev[-1].numel()
+        if B % 2 or B < 2:
+            raise RuntimeError("the pair model needs an even number of clouds [pos_0, anc_0, pos_1, anc_1, ...]; got %d" % B)
+        P = B // 2
         lens_c = data_dict.get("lengths_c_host")
         if lens_c is None:
-            lens_c = data_dict["lengths"][-1].tolist()              # host sync, as the reference's .item() calls (LCRNet.py:127-128)
-        n0, n1 = int(lens_c[0]), int(lens_c[1])
+            lens_c = lens_dev[-1].tolist()                           # host sync, as the reference's .item() calls (LCRNet.py:127-128)
+        lens_c = [int(x) for x in lens_c]
         points_c = data_dict["points"][-1]
-        feats_list = self.encoder(feats, data_dict)
+        dd = data_dict
+        if P > 1 and "segment_lengths" not in data_dict:             # GroupNorm per pair at every stage
+            dd = dict(data_dict)
+            dd["segment_lengths"] = [l.view(P, 2).sum(1) for l in lens_dev]
+        feats_list = self.encoder(feats, dd)
         feats_c = feats_list[-1]
-        pos_c, anc_c = feats_c[:n0].contiguous(), feats_c[n0:n0 + n1].contiguous()
-        e0, e1 = self.transformer(points_c[:n0].contiguous(), points_c[n0:n0 + n1].contiguous(), pos_c, anc_c)
-        g = self.netvlad.describe(feats_c[:n0 + n1], [n0, n1])       # pre-transformer features (LCRNet.py:296-297)
-        out = {"pos_feature_global": g[0:1], "anc_feature_global": g[1:2], "ori_pos_points_c": points_c[:n0],
-               "ori_anc_points_c": points_c[n0:n0 + n1], "pos_feats_c_enhanced": e0, "anc_feats_c_enhanced": e1}
+        off_c = [0]
+        for n in lens_c:
+            off_c.append(off_c[-1] + n)
+        n_c = off_c[-1]
+        pos_lens, anc_lens = lens_c[0::2], lens_c[1::2]
+        if P == 1:
+            n0, n1 = lens_c
+            pos_c, anc_c = feats_c[:n0].contiguous(), feats_c[n0:n0 + n1].contiguous()
+            e0, e1 = self.transformer(points_c[:n0].contiguous(), points_c[n0:n0 + n1].contiguous(), pos_c, anc_c)
+            enhanced = torch.cat([e0, e1], 0)
+        else:
+            # rows of all first clouds / all second clouds, stacked: every Linear and LayerNorm of the transformer runs once
+            idx0 = torch.cat([torch.arange(off_c[2 * p], off_c[2 * p + 1]) for p in range(P)]).to(feats_c.device, non_blocking=True)
+            idx1 = torch.cat([torch.arange(off_c[2 * p + 1], off_c[2 * p + 2]) for p in range(P)]).to(feats_c.device, non_blocking=True)
+            e0, e1 = self.transformer(points_c[idx0], points_c[idx1], feats_c[idx0], feats_c[idx1], pos_lens, anc_lens)
+            enhanced = torch.empty((n_c, e0.shape[1]), dtype=e0.dtype, device=e0.device)
+            enhanced[idx0] = e0
+            enhanced[idx1] = e1
+        g = self.netvlad.describe(feats_c[:n_c], lens_c)            # pre-transformer features (LCRNet.py:296-297)
+        outs = []
+        for p in range(P):
+            a0, a1, a2 = off_c[2 * p], off_c[2 * p + 1], off_c[2 * p + 2]
+            outs.append({"pos_feature_global": g[2 * p:2 * p + 1], "anc_feature_global": g[2 * p + 1:2 * p + 2],
+                         "ori_pos_points_c": points_c[a0:a1], "ori_anc_points_c": points_c[a1:a2],
+                         "pos_feats_c_enhanced": enhanced[a0:a1], "anc_feats_c_enhanced": enhanced[a1:a2]})
         if not pose:
-            out["feats_list"] = feats_list
-            return out
+            outs[0]["feats_list"] = feats_list
+            return outs
 
-        # ---- KeypointDetection tail (LCRNet.py:152-159) and DenseMatchingHEAD (:161-272)
-        enhanced = torch.cat([e0, e1], 0)
-        vd = self.vote_encoder(enhanced, data_dict)
-        m = vd["length"].tolist()                                     # host sync (the reference does length[0] indexing too)
-        m0 = int(m[0])
-        L0 = data_dict["lengths"][0].tolist()
-        nf0, nf1 = int(L0[0]), int(L0[1])
+        # ---- KeypointDetection tail (LCRNet.py:152-159): once over the stack
+        vd = self.vote_encoder(enhanced, data_dict, pairs=P)
+        m = [int(x) for x in vd["length"].tolist()]                   # host sync (the reference does length[0] indexing too)
+        off_m = [0]
+        for x in m:
+            off_m.append(off_m[-1] + x)
+        L0 = data_dict.get("lengths_host")
+        L0 = [int(x) for x in (L0[0] if L0 is not None else lens_dev[0].tolist())]
+        off_f = [0]
+        for x in L0:
+            off_f.append(off_f[-1] + x)
         pts_f = data_dict["points"][0]
-        pos_f, anc_f = pts_f[:nf0].contiguous(), pts_f[nf0:nf0 + nf1].contiguous()
-        pos_nodes, anc_nodes = vd["points_c"][:m0].contiguous(), vd["points_c"][m0:].contiguous()
-        pos_fc, anc_fc = vd["feats_c"][:m0].contiguous(), vd["feats_c"][m0:].contiguous()
+        fl = list(feats_list)
+        fl[-1] = enhanced                                              # LCRNet.py:154-155
+        feats_f = self.kpdecoder(fl, data_dict, pairs=P)[0]
+        # ---- DenseMatchingHEAD (:161-272): pair by pair (shapes depend on each pair's nodes / matches)
+        for p in range(P):
+            c = 2 * p
+            sl = lambda off, i: slice(off[i], off[i + 1])
+            self._dense_matching(outs[p], pts_f[sl(off_f, c)].contiguous(), pts_f[sl(off_f, c + 1)].contiguous(),
+                                 feats_f[sl(off_f, c)].contiguous(), feats_f[sl(off_f, c + 1)].contiguous(),
+                                 vd["points_c"][sl(off_m, c)].contiguous(), vd["points_c"][sl(off_m, c + 1)].contiguous(),
+                                 vd["feats_c"][sl(off_m, c)].contiguous(), vd["feats_c"][sl(off_m, c + 1)].contiguous())
+            outs[p].update({"shifted_pos_points_c": vd["shifted_points_c"][sl(off_c, c)], "shifted_anc_points_c": vd["shifted_points_c"][sl(off_c, c + 1)],
+                            "length": vd["length"][c:c + 2], "feats_c": vd["feats_c"][off_m[c]:off_m[c + 2]]})
+        return outs
+
+    def _dense_matching(self, out, pos_f, anc_f, pos_ff, anc_ff, pos_nodes, anc_nodes, pos_fc, anc_fc):
         K = self.num_points_in_patch
         _, pos_nm, pos_knn, pos_km = F.point_to_node_partition(pos_f, pos_nodes, K)
         _, anc_nm, anc_knn, anc_km = F.point_to_node_partition(anc_f, anc_nodes, K)
@@ -183,27 +248,21 @@ class LCRNet(nn.Module):
                                      scale=1.0 / pos_fc.shape[1] ** 0.5, iters=self.node_optimal_transport.num_iterations)
         nbij, node_corr_scores = F.top1_matching(ns)                   # masks are not applied at this level (superpoint_matching.py:130-162)
         pi, ai = nbij[:, 1].long(), nbij[:, 2].long()
-        fl = list(feats_list)
-        fl[-1] = enhanced                                              # LCRNet.py:154-155
-        feats_f = self.kpdecoder(fl, data_dict)[0]
-        pos_ff, anc_ff = feats_f[:nf0].contiguous(), feats_f[nf0:].contiguous()
         pk, ak = pos_knn[pi].contiguous(), anc_knn[ai].contiguous()    # (P, K) point indices of the matched patches
         pkm, akm = pos_km[pi].contiguous(), anc_km[ai].contiguous()
         pkp, akp = F.gather_rows(pos_f, pk), F.gather_rows(anc_f, ak)
         pkf, akf = F.gather_rows(pos_ff, pk), F.gather_rows(anc_ff, ak)
         ms = F.log_optimal_transport(F.bmm_nt(pkf, akf), pkm, akm, self.optimal_transport.alpha,
-                                     scale=1.0 / feats_f.shape[1] ** 0.5, iters=self.optimal_transport.num_iterations)
+                                     scale=1.0 / pos_ff.shape[1] ** 0.5, iters=self.optimal_transport.num_iterations)
         rp, sp, sc, T = self._local_global_registration(pkp, akp, pkm, akm, ms)
         out.update({
-            "shifted_pos_points_c": vd["shifted_points_c"][:n0], "shifted_anc_points_c": vd["shifted_points_c"][n0:n0 + n1],
-            "length": vd["length"], "pos_points_c": pos_nodes, "anc_points_c": anc_nodes, "feats_c": vd["feats_c"],
-            "pos_feats_c": pos_fc, "anc_feats_c": anc_fc, "pos_points_f": pos_f, "anc_points_f": anc_f,
+            "pos_points_c": pos_nodes, "anc_points_c": anc_nodes, "pos_feats_c": pos_fc, "anc_feats_c": anc_fc,
+            "pos_points_f": pos_f, "anc_points_f": anc_f,
             "pos_node_knn_indices": pos_knn, "pos_node_knn_masks": pos_km, "anc_node_knn_indices": anc_knn, "anc_node_knn_masks": anc_km,
             "pos_node_corr_indices": pi, "anc_node_corr_indices": ai, "node_corr_scores": node_corr_scores,
             "pos_feats_f": pos_ff, "anc_feats_f": anc_ff, "pos_node_corr_knn_points": pkp, "anc_node_corr_knn_points": akp,
             "pos_node_corr_knn_masks": pkm, "anc_node_corr_knn_masks": akm, "matching_scores": ms,
             "pos_corr_points": rp, "anc_corr_points": sp, "corr_scores": sc, "estimated_transform": T})
-        return out
 
 
 def create_model(cfg=None):

@@ -1,7 +1,10 @@
 """ThDRoFormer (3D-RoFormer) — module tree / parameter names of experiments/lcrnet/modules/thdroformer
 (thdroformer_linear.py:12-97, rpetransformer.py:57-220, vanilla_transformer.py:13-144, Rotary3DPosEmb.py:27-38) so the
 `transformer.*` checkpoint keys load unchanged; forward on the HIP kernels (lcr_gemm_f32 for every Linear,
-lcr_rotary_embed, the fused MFMA attention lcr_attention_f32, lcr_add_layernorm).  Batch 1 pair, like the reference."""
+lcr_rotary_embed, the fused MFMA attention lcr_attention_f32, lcr_add_layernorm).  One pair per call like the reference, or P
+pairs per call (`lens0` / `lens1`): the rows of all first clouds are stacked in one tensor, those of all second clouds in another,
+every Linear / LayerNorm runs once over the stack and the attention kernel takes the P problems in one launch
+(lcr_attention_seg_f32) — per-pair results are those of P separate calls."""
 import torch.nn as nn
 
 from ... import functional as F
@@ -29,14 +32,14 @@ class _MultiHeadAttention(nn.Module):
         self.proj_k = nn.Linear(d_model, d_model)
         self.proj_v = nn.Linear(d_model, d_model)
 
-    def forward(self, input_q, input_k, input_v, theta_q=None):
+    def forward(self, input_q, input_k, input_v, theta_q=None, q_lens=None, k_lens=None):
         q = F.linear(input_q, self.proj_q.weight, self.proj_q.bias)
         k = F.linear(input_k, self.proj_k.weight, self.proj_k.bias)
         v = F.linear(input_v, self.proj_v.weight, self.proj_v.bias)
         if theta_q is not None:                                   # self layers: the SAME theta rotates q and k
             F.rotary_embed_(q, theta_q, self.num_heads)
             F.rotary_embed_(k, theta_q, self.num_heads)
-        return F.attention(q, k, v, self.num_heads)
+        return F.attention(q, k, v, self.num_heads, q_lens, k_lens)
 
 
 class _AttentionLayer(nn.Module):
@@ -46,8 +49,8 @@ class _AttentionLayer(nn.Module):
         self.linear = nn.Linear(d_model, d_model)
         self.norm = nn.LayerNorm(d_model)
 
-    def forward(self, x, memory, theta=None):
-        h = self.attention(x, memory, memory, theta)
+    def forward(self, x, memory, theta=None, x_lens=None, m_lens=None):
+        h = self.attention(x, memory, memory, theta, x_lens, m_lens)
         h = F.linear(h, self.linear.weight, self.linear.bias)
         return F.add_layernorm(h, x, self.norm.weight, self.norm.bias, self.norm.eps)
 
@@ -71,8 +74,8 @@ class _TransformerLayer(nn.Module):
         self.attention = _AttentionLayer(d_model, num_heads)
         self.output = _AttentionOutput(d_model)
 
-    def forward(self, x, memory, theta=None):
-        return self.output(self.attention(x, memory, theta))
+    def forward(self, x, memory, theta=None, x_lens=None, m_lens=None):
+        return self.output(self.attention(x, memory, theta, x_lens, m_lens))
 
 
 class RPEConditionalTransformer(nn.Module):
@@ -81,16 +84,16 @@ class RPEConditionalTransformer(nn.Module):
         self.blocks, self.parallel = list(blocks), parallel
         self.layers = nn.ModuleList([_TransformerLayer(d_model, num_heads) for _ in self.blocks])
 
-    def forward(self, feats0, feats1, theta0, theta1):
+    def forward(self, feats0, feats1, theta0, theta1, lens0=None, lens1=None):
         for i, block in enumerate(self.blocks):
             if block == "self":                                   # one shared module for both clouds (rpetransformer.py:203-206)
-                feats0 = self.layers[i](feats0, feats0, theta0)
-                feats1 = self.layers[i](feats1, feats1, theta1)
+                feats0 = self.layers[i](feats0, feats0, theta0, lens0, lens0)
+                feats1 = self.layers[i](feats1, feats1, theta1, lens1, lens1)
             elif self.parallel:
-                feats0, feats1 = self.layers[i](feats0, feats1), self.layers[i](feats1, feats0)
+                feats0, feats1 = self.layers[i](feats0, feats1, None, lens0, lens1), self.layers[i](feats1, feats0, None, lens1, lens0)
             else:                                                 # sequential: cloud 1 attends to the UPDATED cloud 0 (:213-214)
-                feats0 = self.layers[i](feats0, feats1)
-                feats1 = self.layers[i](feats1, feats0)
+                feats0 = self.layers[i](feats0, feats1, None, lens0, lens1)
+                feats1 = self.layers[i](feats1, feats0, None, lens1, lens0)
         return feats0, feats1
 
 
@@ -103,15 +106,16 @@ class ThDRoFormer(nn.Module):
         self.transformer = RPEConditionalTransformer(["self", "cross"] * num_layers, hidden_dim, num_heads)
         self.out_proj = nn.Linear(hidden_dim, output_dim)
 
-    def forward(self, ref_points, src_points, ref_feats, src_feats):
-        """(N,3), (M,3), (N,C), (M,C)  [a leading batch dim of 1 as in the reference is accepted] -> (N,out), (M,out)."""
+    def forward(self, ref_points, src_points, ref_feats, src_feats, ref_lens=None, src_lens=None):
+        """(N,3), (M,3), (N,C), (M,C)  [a leading batch dim of 1 as in the reference is accepted] -> (N,out), (M,out).
+        ref_lens / src_lens (host sequences, one entry per pair): the inputs are the stacks of P pairs' first / second clouds."""
         squeeze = ref_points.dim() == 3
         if squeeze:
             ref_points, src_points, ref_feats, src_feats = ref_points[0], src_points[0], ref_feats[0], src_feats[0]
         t0, t1 = self.embedding(ref_points.contiguous()), self.embedding(src_points.contiguous())
         f0 = F.linear(ref_feats, self.in_proj.weight, self.in_proj.bias)
         f1 = F.linear(src_feats, self.in_proj.weight, self.in_proj.bias)
-        f0, f1 = self.transformer(f0, f1, t0, t1)
+        f0, f1 = self.transformer(f0, f1, t0, t1, ref_lens, src_lens)
         f0 = F.linear(f0, self.out_proj.weight, self.out_proj.bias)
         f1 = F.linear(f1, self.out_proj.weight, self.out_proj.bias)
         return (f0[None], f1[None]) if squeeze else (f0, f1)

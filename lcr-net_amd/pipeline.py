@@ -358,8 +358,11 @@ class PairPipeline:
     and by launch latency, not by the GPU; a second pair in flight fills the gaps (80 -> 100-120 pairs/s on the demo pair).  More than
     two workers lose to interpreter-lock contention (59 pairs/s with three)."""
 
-    def __init__(self, model, voxel_size=0.3, radius=1.275, num_stages=4, neighbor_limits=(74, 68, 70, 67), workers=2):
+    def __init__(self, model, voxel_size=0.3, radius=1.275, num_stages=4, neighbor_limits=(74, 68, 70, 67), workers=2, pairs_per_call=1):
+        """pairs_per_call > 1: consecutive pairs are stacked and go through `LCRNet.forward_pairs` together (one collate, one encoder /
+        transformer / vote-encoder / decoder pass for all of them; only the matching + registration tail runs pair by pair)."""
         self.model, self.workers = model, max(1, int(workers))
+        self.pairs_per_call = max(1, min(32, int(pairs_per_call)))
         self.voxel_size, self.radius, self.num_stages, self.limits = voxel_size, radius, num_stages, list(neighbor_limits)
         self.device = next(model.parameters()).device
         # worker streams: created and probed ONCE per pipeline (two busy streams on one hardware queue serialise each other)
@@ -385,21 +388,46 @@ class PairPipeline:
         with torch.no_grad():
             return self.model(dd)
 
+    def many(self, pairs):
+        """pairs: list of (points, lengths[2]) -> list of output dicts (one stacked call; `one` for a single pair)."""
+        if len(pairs) == 1:
+            return [self.one(*pairs[0])]
+        points = torch.cat([p for p, _ in pairs]).contiguous()
+        lengths = torch.cat([l for _, l in pairs])
+        dd = precompute_batch(points, lengths, self.num_stages, self.voxel_size, self.radius, self.limits, upsampling=True)
+        del dd["segment_lengths"]            # forward_pairs takes GroupNorm statistics per PAIR (both clouds), not per cloud
+        dd["features"] = torch.ones(points.shape[0], 1, device=points.device)
+        dd["lengths_c_host"] = dd["lengths_host"][-1]
+        with torch.no_grad():
+            return self.model.forward_pairs(dd)
+
+    def _grouped(self, pairs):
+        group = []
+        for item in pairs:
+            group.append(item)
+            if len(group) == self.pairs_per_call:
+                yield group
+                group = []
+        if group:
+            yield group
+
     def run(self, pairs):
         """pairs: iterable of (points, lengths) device tensors.  Yields one output dict per pair, in order, valid on the caller's
         current stream."""
         import queue
         import threading
+        groups = self._grouped(pairs)        # the work items: groups of `pairs_per_call` pairs; a result is a list of dicts
         if self.workers == 1:
-            for pts, lens in pairs:
-                yield self.one(pts, lens)
+            for g in groups:
+                yield from self.many(g)
             return
+
         dev = self.device
         main = torch.cuda.current_stream(dev)
-        it = enumerate(iter(pairs))
+        it = enumerate(groups)
         it_lock = threading.Lock()
         out = queue.Queue()
-        slots = threading.Semaphore(2 * self.workers)       # finished pairs not yet consumed
+        slots = threading.Semaphore(2 * self.workers)       # finished groups not yet consumed
 
         if len(self._streams) < self.workers:
             raise RuntimeError("PairPipeline is closed")
@@ -423,8 +451,8 @@ class PairPipeline:
                         if nxt is None:
                             slots.release()
                             break
-                        k, (pts, lens) = nxt
-                        res = self.one(pts, lens)
+                        k, group = nxt
+                        res = self.many(group)
                         ev = torch.cuda.Event()
                         ev.record(st)
                         out.put((k, res, ev))
@@ -451,10 +479,11 @@ class PairPipeline:
                 res, ev = ready.pop(k)
                 slots.release()
                 main.wait_event(ev)
-                for v in res.values():
-                    if torch.is_tensor(v) and v.is_cuda:
-                        v.record_stream(main)
-                yield res
+                for d in res:
+                    for v in d.values():
+                        if torch.is_tensor(v) and v.is_cuda:
+                            v.record_stream(main)
+                yield from res
                 k += 1
         finally:
             stop.set()                                   # consumer gone: wake the workers, let them see the flag, join

@@ -1,0 +1,74 @@
+"""GPU: P registration pairs per call (`LCRNet.forward_pairs`, BASELINE configs[4]) give each pair what a call of its own gives.
+
+The reference runs one pair per forward (model_family/LCRNet.py:274-321); batching shares the encoder / 3D-RoFormer (segmented
+attention launch) / vote encoder / decoder launches between the pairs.  GroupNorm statistics are per pair in both forms, so the only
+differences are fp32 re-association (other GEMM tile shapes for other row counts, atomics order): descriptors and dense features
+within 1e-4 (relative to the tensor's magnitude), node counts equal.  The registration tail works on near-uniform random-weight
+scores, so correspondences and the pose are only compared loosely here (they are pinned in tests/test_pose_chain_gpu.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import LIMITS, NUM_STAGES, RADIUS, VOXEL, load_scan
+
+pytestmark = pytest.mark.gpu
+PAIRS = [("003854", "000958"), ("000026", "000560"), ("003528", "004481")]
+
+
+def test_segmented_attention_equals_separate_launches():
+    from lcrnet_amd import functional as F
+    g = torch.Generator().manual_seed(0)
+    q_lens, k_lens = [844, 5, 33, 823], [823, 700, 1, 844]
+    q = torch.randn(sum(q_lens), 128, generator=g).cuda()
+    k = torch.randn(sum(k_lens), 128, generator=g).cuda()
+    v = torch.randn(sum(k_lens), 128, generator=g).cuda()
+    got = F.attention(q, k, v, 4, q_lens, k_lens)
+    qo = ko = 0
+    for nq, nk in zip(q_lens, k_lens):
+        want = F.attention(q[qo:qo + nq].contiguous(), k[ko:ko + nk].contiguous(), v[ko:ko + nk].contiguous(), 4)
+        assert torch.equal(got[qo:qo + nq], want)                  # same tiles, same arithmetic: bit-identical
+        qo += nq
+        ko += nk
+
+
+def test_forward_pairs_equals_one_call_per_pair():
+    from lcrnet_amd.config import make_cfg
+    from lcrnet_amd.model_family import LCRNet
+    from lcrnet_amd.pipeline import PairPipeline
+    from lcrnet_amd.weights import seeded_state_dict
+    cfg = make_cfg()
+    cfg["neighbor_limits"] = LIMITS
+    m = LCRNet(cfg).eval()
+    m.load_state_dict(seeded_state_dict(m.state_dict(), 7351), strict=True)
+    m = m.cuda()
+    work = []
+    for a, b in PAIRS:
+        pa, pb = torch.from_numpy(load_scan(a)).cuda(), torch.from_numpy(load_scan(b)).cuda()
+        work.append((torch.cat([pa, pb]), torch.tensor([len(pa), len(pb)], dtype=torch.int64, device="cuda")))
+    with PairPipeline(m, VOXEL, RADIUS, NUM_STAGES, LIMITS, workers=1, pairs_per_call=1) as single, \
+            PairPipeline(m, VOXEL, RADIUS, NUM_STAGES, LIMITS, workers=1, pairs_per_call=3) as batched:
+        one = [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in o.items()} for o in single.run(work)]
+        many = [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in o.items()} for o in batched.run(work)]
+    assert len(one) == len(many) == 3
+
+    def rel(a, b):
+        return float((a - b).abs().max() / max(1.0, float(b.abs().max())))
+
+    for i, (o, b) in enumerate(zip(one, many)):
+        assert rel(b["pos_feature_global"], o["pos_feature_global"]) < 1e-5 and rel(b["anc_feature_global"], o["anc_feature_global"]) < 1e-5
+        assert rel(b["pos_feats_c_enhanced"], o["pos_feats_c_enhanced"]) < 1e-4 and rel(b["anc_feats_c_enhanced"], o["anc_feats_c_enhanced"]) < 1e-4
+        assert torch.allclose(b["shifted_pos_points_c"], o["shifted_pos_points_c"], atol=1e-4)
+        assert b["length"].tolist() == o["length"].tolist(), i                         # same NMS result
+        assert torch.allclose(b["pos_points_c"], o["pos_points_c"], atol=1e-4) and torch.allclose(b["anc_points_c"], o["anc_points_c"], atol=1e-4)
+        assert rel(b["pos_feats_c"], o["pos_feats_c"]) < 1e-4 and rel(b["pos_feats_f"], o["pos_feats_f"]) < 1e-4 and rel(b["anc_feats_f"], o["anc_feats_f"]) < 1e-4
+        assert (b["pos_node_knn_indices"] == o["pos_node_knn_indices"]).float().mean().item() > 0.995   # node centres differ by ~1e-6: rare nearest-node flips
+        sb = set(zip(b["pos_node_corr_indices"].tolist(), b["anc_node_corr_indices"].tolist()))
+        so = set(zip(o["pos_node_corr_indices"].tolist(), o["anc_node_corr_indices"].tolist()))
+        assert len(sb & so) >= 0.97 * len(so)
+        n = o["corr_scores"].shape[0]
+        assert abs(b["corr_scores"].shape[0] - n) <= 0.05 * n
+        T = b["estimated_transform"].numpy()
+        assert abs(np.linalg.det(T[:3, :3]) - 1) < 1e-4
+        print("pair %d: descriptor diff %.1e, enhanced %.1e, fine feats %.1e, node corr %d/%d, point corr %d vs %d" % (
+            i, rel(b["pos_feature_global"], o["pos_feature_global"]), rel(b["pos_feats_c_enhanced"], o["pos_feats_c_enhanced"]),
+            rel(b["pos_feats_f"], o["pos_feats_f"]), len(sb & so), len(so), b["corr_scores"].shape[0], n))
