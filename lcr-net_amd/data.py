@@ -265,6 +265,84 @@ def test_loop_detection_collate_fn_stack_mode_online(data_dicts, num_stages, vox
 test_loop_detection_collate_fn_stack_mode_online.__test__ = False     # a collate of the reference's name, not a pytest case
 
 
+# ---- training-time collates (experiments/lcrnet/data.py:130-348), mirrored by name ------------------------------------------------
+# Host logic only (stacking order, which keys are popped / unwrapped); the collate proper is the same device-side
+# precompute_data_stack_mode.  They exist so that the reference's trainval_* scripts can keep their DataLoader code when the
+# pre-processing moves to the GPU; the training loop itself (losses, optimiser) is out of scope.
+def _precompute_or_keep(merged, feats, points, lengths, batch_size, num_stages, voxel_size, search_radius, neighbor_limits, precompute_data,
+                        device):
+    merged["features"] = feats
+    if precompute_data:
+        dev = torch.device(device)
+        merged["features"] = feats.to(dev)
+        merged.update(precompute_data_stack_mode(points.to(dev, torch.float32).contiguous(), lengths.to(dev), num_stages, voxel_size,
+                                                 search_radius, neighbor_limits))
+    else:
+        merged["points"], merged["lengths"] = points, lengths
+    merged["batch_size"] = batch_size
+    return merged
+
+
+def train_loop_detection_collate_fn_stack_mode(data_dicts, num_stages, voxel_size, search_radius, neighbor_limits, precompute_data=True):
+    """data.py:130-170 (pre-extracted features): `features` = [pos.., anc.., neg..] feats, `lengths` likewise; nothing is
+    precomputed whatever `precompute_data` says (the reference ignores it here), every other key stays a per-sample list."""
+    merged = _merge_samples(data_dicts)
+    feats = torch.cat(merged.pop("pos_feats") + merged.pop("anc_feats") + merged.pop("neg_feats"), dim=0)
+    lengths = torch.cat(merged.pop("pos_lengths") + merged.pop("anc_lengths") + merged.pop("neg_lengths"), dim=0)
+    merged["features"], merged["lengths"], merged["batch_size"] = feats, lengths, len(data_dicts)
+    return merged
+
+
+def train_loop_detection_collate_fn_stack_mode_online(data_dicts, num_stages, voxel_size, search_radius, neighbor_limits,
+                                                      precompute_data=True, device="cuda"):
+    """data.py:173-235 (online triplets): clouds stacked [pos_1..pos_B, anc_1..anc_B, neg_1..neg_B]; when the first negative is
+    empty (`lengths[2B] == 0`) the negatives' LENGTHS are dropped (their zero points add nothing to the stack); `transform` is
+    unwrapped for B = 1."""
+    B = len(data_dicts)
+    merged = _merge_samples(data_dicts)
+    lengths = torch.cat(merged.pop("pos_lengths") + merged.pop("anc_lengths") + merged.pop("neg_lengths"), dim=0)
+    if lengths[2 * B] == 0:
+        lengths = lengths[:2 * B]
+    feats = torch.cat(merged.pop("pos_feats") + merged.pop("anc_feats") + merged.pop("neg_feats"), dim=0)
+    points = torch.cat(merged.pop("pos_points") + merged.pop("anc_points") + merged.pop("neg_points"), dim=0)
+    if B == 1 and "transform" in merged:
+        merged["transform"] = merged["transform"][0]
+    return _precompute_or_keep(merged, feats, points, lengths, B, num_stages, voxel_size, search_radius, neighbor_limits, precompute_data, device)
+
+
+def train_loop_detection_collate_fn_stack_mode_halfonline(data_dicts, num_stages, voxel_size, search_radius, neighbor_limits,
+                                                          precompute_data=True, device="cuda"):
+    """data.py:238-288 (anchors online, positives / negatives pre-extracted): the stack holds the anchors only; `lengths_c` /
+    `feats_c` carry the pre-extracted [pos.., neg..] coarse features."""
+    B = len(data_dicts)
+    merged = _merge_samples(data_dicts)
+    lengths = torch.cat(merged.pop("anc_lengths"), dim=0)
+    feats = torch.cat(merged.pop("anc_feats"), dim=0)
+    points = torch.cat(merged.pop("anc_points"), dim=0)
+    lengths_c = torch.cat(merged.pop("pos_lengths") + merged.pop("neg_lengths"), dim=0)
+    feats_c = torch.cat(merged.pop("pos_feats") + merged.pop("neg_feats"), dim=0)
+    out = _precompute_or_keep(merged, feats, points, lengths, B, num_stages, voxel_size, search_radius, neighbor_limits, precompute_data, device)
+    out["lengths_c"], out["feats_c"] = lengths_c, feats_c
+    return out
+
+
+def all_collate_fn_stack_mode(data_dicts, num_stages, voxel_size, search_radius, neighbor_limits, precompute_data=True, device="cuda"):
+    """data.py:290-348 (feature pre-extraction over a whole sequence): a sample flagged `pass` is handed back as it is; otherwise
+    the `anc_points` of the samples are stacked, `features` = the first sample's `anc_feats`, and EVERY other key is unwrapped for
+    B = 1 (not only `transform`)."""
+    B = len(data_dicts)
+    if data_dicts[0]["pass"] == True:   # noqa: E712  (the reference compares with ==)
+        return data_dicts[0]
+    merged = _merge_samples(data_dicts)
+    feats = merged.pop("anc_feats")
+    points_list = merged.pop("anc_points")
+    lengths = torch.LongTensor([p.shape[0] for p in points_list])
+    points = torch.cat(points_list, dim=0)
+    if B == 1:
+        merged = {k: v[0] for k, v in merged.items()}
+    return _precompute_or_keep(merged, feats[0], points, lengths, B, num_stages, voxel_size, search_radius, neighbor_limits, precompute_data, device)
+
+
 def voxelize_raw_scans(points, lengths, voxel_size, key_bits_hint=32):
     """Raw-scan ingest (replaces the offline Open3D voxel_down_sample(0.3) of data/Kitti/downsample_pcd.py:29
     with the a-1 kernel): stacked raw scans -> stacked voxel barycentres; returns (points, lengths_dev, lengths_host)."""
