@@ -337,8 +337,8 @@ __device__ __forceinline__ int hm_block_excl_scan(int v, int* total, int* lds) {
 // exclusive scan of a[0..n) in place (block-wide, arbitrary n); reversed => scan from the top index downwards.
 // Tiles of 4*HM_T elements, four consecutive entries per thread: neighbouring lanes touch neighbouring 16-B pieces (a
 // thread-contiguous chunking made every load instruction touch 64 different cache lines).
-template <bool REVERSED>
-__device__ void hm_scan_inplace(int32_t* a, int n, int* lds) {
+template <bool REVERSED, typename E>
+__device__ void hm_scan_inplace(E* a, int n, int* lds) {
   int carry = 0;
   for (int base = 0; base < n; base += 4 * HM_T) {
     const int i0 = base + 4 * threadIdx.x;
@@ -346,7 +346,7 @@ __device__ void hm_scan_inplace(int32_t* a, int n, int* lds) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int i = i0 + k;
-      v[k] = i < n ? a[REVERSED ? n - 1 - i : i] : 0;
+      v[k] = i < n ? static_cast<int>(a[REVERSED ? n - 1 - i : i]) : 0;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) s += v[k];
@@ -355,7 +355,7 @@ __device__ void hm_scan_inplace(int32_t* a, int n, int* lds) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int i = i0 + k;
-      if (i < n) a[REVERSED ? n - 1 - i : i] = run;
+      if (i < n) a[REVERSED ? n - 1 - i : i] = static_cast<E>(run);
       run += v[k];
     }
     carry += tot;
@@ -383,10 +383,12 @@ __device__ __forceinline__ int hm_bucket(uint64_t key, uint64_t nb64, double inv
 // One phase of the replay with nb buckets: elements [0, hi) are in the table, those below `lo` carry their list position after
 // the previous phase in t[], the rest are new (timestamp = insertion rank).  Leaves the new list positions in bk[] (the caller
 // swaps t and bk).  The arrays may live in LDS (small phases) or in global memory; the code is the same.
-template <int HU>
-__device__ __forceinline__ void hm_phase(const uint64_t* __restrict__ key, int32_t* __restrict__ t, int32_t* __restrict__ bk,
-                                         int32_t* __restrict__ memt, int32_t* __restrict__ arrv, int32_t* __restrict__ at,
-                                         int32_t* __restrict__ gmin, int32_t* __restrict__ cnt, int32_t* __restrict__ start, int lo,
+// E = int32_t (arrays in global memory, any size) or uint16_t (LDS phases: every value — bucket id, list position, count — is
+// below the phase's bucket count <= 5087); gmin / cnt stay 32-bit, they are the targets of LDS atomics.
+template <int HU, typename E>
+__device__ __forceinline__ void hm_phase(const uint64_t* __restrict__ key, E* __restrict__ t, E* __restrict__ bk,
+                                         E* __restrict__ memt, E* __restrict__ arrv, E* __restrict__ at,
+                                         int32_t* __restrict__ gmin, int32_t* __restrict__ cnt, E* __restrict__ start, int lo,
                                          int hi, int nb, uint64_t nb64, int* lds) {
   const int tid = threadIdx.x;
   const double inv_nb = 1.0 / static_cast<double>(nb64);
@@ -406,7 +408,7 @@ __device__ __forceinline__ void hm_phase(const uint64_t* __restrict__ key, int32
       const int e = e0 + k * HM_T;
       if (e < hi) {
         kk[k] = key[e];
-        tt[k] = e >= lo ? e : t[e];            // new elements: timestamp = insertion rank
+        tt[k] = e >= lo ? e : static_cast<int>(t[e]);            // new elements: timestamp = insertion rank
       }
     }
     int bb[HU], arr[HU];
@@ -423,10 +425,10 @@ __device__ __forceinline__ void hm_phase(const uint64_t* __restrict__ key, int32
     for (int k = 0; k < HU; ++k) {
       const int e = e0 + k * HM_T;
       if (e < hi) {
-        bk[e] = bb[k];
-        if (e >= lo) t[e] = e;
+        bk[e] = static_cast<E>(bb[k]);
+        if (e >= lo) t[e] = static_cast<E>(e);
         at[e] = 0;
-        arrv[e] = arr[k];
+        arrv[e] = static_cast<E>(arr[k]);
       }
     }
   }
@@ -446,14 +448,14 @@ __device__ __forceinline__ void hm_phase(const uint64_t* __restrict__ key, int32
     for (int k = 0; k < HU; ++k) {
       const int i = i0 + k * HM_T;
       if (i < nb) {
-        if (c[k] > 0) at[g[k]] = c[k];
-        start[i] = c[k];
+        if (c[k] > 0) at[g[k]] = static_cast<E>(c[k]);
+        start[i] = static_cast<E>(c[k]);
       }
     }
   }
   __syncthreads();
-  hm_scan_inplace<true>(at, hi, lds);     // at[tt] = number of elements in groups created AFTER time tt
-  hm_scan_inplace<false>(start, nb, lds);  // member-list offsets per bucket
+  hm_scan_inplace<true, E>(at, hi, lds);     // at[tt] = number of elements in groups created AFTER time tt
+  hm_scan_inplace<false, E>(start, nb, lds);  // member-list offsets per bucket
   // pass C: member lists (timestamps), and per bucket the list position of its group (replaces gmin)
   for (int e0 = tid; e0 < hi; e0 += HU * HM_T) {
     int bb[HU], tt[HU], ar[HU], s0[HU];
@@ -474,7 +476,7 @@ __device__ __forceinline__ void hm_phase(const uint64_t* __restrict__ key, int32
 #pragma unroll
     for (int k = 0; k < HU; ++k) {
       const int e = e0 + k * HM_T;
-      if (e < hi) memt[s0[k] + ar[k]] = tt[k];
+      if (e < hi) memt[s0[k] + ar[k]] = static_cast<E>(tt[k]);
     }
   }
   for (int i0 = tid; i0 < nb; i0 += HU * HM_T) {
@@ -521,12 +523,12 @@ __device__ __forceinline__ void hm_phase(const uint64_t* __restrict__ key, int32
     for (int j = 0; j < maxlen; ++j) {        // buckets hold one or two elements almost always
 #pragma unroll
       for (int k = 0; k < HU; ++k)
-        if (s0[k] + j < s1[k]) r[k] += memt[s0[k] + j] > te[k];   // newer members of the bucket come first
+        if (s0[k] + j < s1[k]) r[k] += static_cast<int>(memt[s0[k] + j]) > te[k];   // newer members of the bucket come first
     }
 #pragma unroll
     for (int k = 0; k < HU; ++k) {
       const int e = e0 + k * HM_T;
-      if (e < hi) bk[e] = a0[k] + r[k];        // position in the list after this phase
+      if (e < hi) bk[e] = static_cast<E>(a0[k] + r[k]);        // position in the list after this phase
     }
   }
   __syncthreads();
@@ -534,7 +536,8 @@ __device__ __forceinline__ void hm_phase(const uint64_t* __restrict__ key, int32
 
 // Emit the barycentres in iteration order: pos[rank] = position of the rank-th inserted voxel.  Two dependent gathers per
 // element (segment of the rank, then its barycentre): four elements per thread are requested together.
-__device__ __forceinline__ void hm_emit(const int32_t* __restrict__ pos, const int32_t* __restrict__ ins_seg, const float* __restrict__ bary,
+template <typename E>
+__device__ __forceinline__ void hm_emit(const E* __restrict__ pos, const int32_t* __restrict__ ins_seg, const float* __restrict__ bary,
                                         float* __restrict__ out_xyz, int64_t o, int n) {
   constexpr int EU = 4;
   for (int e0 = threadIdx.x; e0 < n; e0 += EU * HM_T) {
@@ -543,7 +546,7 @@ __device__ __forceinline__ void hm_emit(const int32_t* __restrict__ pos, const i
     for (int k = 0; k < EU; ++k) {
       const int e = e0 + k * HM_T < n ? e0 + k * HM_T : n - 1;
       seg[k] = ins_seg[o + e];
-      dst[k] = pos[e];
+      dst[k] = static_cast<int>(pos[e]);
     }
     float b[EU][3];
 #pragma unroll
@@ -559,11 +562,14 @@ __device__ __forceinline__ void hm_emit(const int32_t* __restrict__ pos, const i
   }
 }
 
-// The first HM_LDS_PHASES phases (up to 2357 buckets) run on LDS-resident arrays: a phase is eight block-wide passes with a
-// barrier between them, full of scattered accesses and atomics — one CU issues those ~30x faster to LDS than to L2/HBM.
-constexpr int HM_LDS_PHASES = 8;
-constexpr int HM_LC = 2357 + 3;         // entries per LDS array (c_sched[HM_LDS_PHASES - 1], padded)
-constexpr size_t HM_LDS_BYTES = static_cast<size_t>(HM_LC) * (8 * sizeof(int32_t) + sizeof(uint64_t));
+// The first HM_LDS_PHASES phases (up to 5087 buckets) run on LDS-resident arrays: a phase is eight block-wide passes with a
+// barrier between them, full of scattered accesses and atomics — one CU issues those ~30x faster to LDS than to L2/HBM.  Every
+// value of these phases is below 5087, so six of the eight per-entry arrays are 16-bit (the two atomic targets stay 32-bit): 28 B
+// per entry with the 8-B key, 142 KB of the CU's 160 KB.  (With 32-bit arrays only the phases up to 2357 buckets fitted: the 5087
+// phase of every stage ran out of global memory.)
+constexpr int HM_LDS_PHASES = 9;
+constexpr int HM_LC = 5087 + 9;         // entries per LDS array (c_sched[HM_LDS_PHASES - 1], padded to a multiple of 8)
+constexpr size_t HM_LDS_BYTES = static_cast<size_t>(HM_LC) * (2 * sizeof(int32_t) + 6 * sizeof(uint16_t) + sizeof(uint64_t));
 
 __global__ __launch_bounds__(HM_T) void k_gs_hashorder(const GsHeader* __restrict__ h, const uint64_t* __restrict__ ins_key,
                                                        const int32_t* __restrict__ ins_seg, const float* __restrict__ bary,
@@ -583,14 +589,14 @@ __global__ __launch_bounds__(HM_T) void k_gs_hashorder(const GsHeader* __restric
   int lo = 0, p = 0;
   {
     uint64_t* lkey = reinterpret_cast<uint64_t*>(hm_dyn);
-    int32_t* lt = reinterpret_cast<int32_t*>(lkey + HM_LC);
-    int32_t* lbk = lt + HM_LC;
-    int32_t* lmem = lbk + HM_LC;
-    int32_t* larr = lmem + HM_LC;
-    int32_t* lat = larr + HM_LC;
-    int32_t* lgmin = lat + HM_LC;
+    int32_t* lgmin = reinterpret_cast<int32_t*>(lkey + HM_LC);
     int32_t* lcnt = lgmin + HM_LC;
-    int32_t* lstart = lcnt + HM_LC;
+    uint16_t* lt = reinterpret_cast<uint16_t*>(lcnt + HM_LC);
+    uint16_t* lbk = lt + HM_LC;
+    uint16_t* lmem = lbk + HM_LC;
+    uint16_t* larr = lmem + HM_LC;
+    uint16_t* lat = larr + HM_LC;
+    uint16_t* lstart = lat + HM_LC;
     const int nl = min(n, static_cast<int>(c_sched[HM_LDS_PHASES - 1]));
     for (int e = tid; e < nl; e += HM_T) lkey[e] = key[e];
     __syncthreads();
@@ -598,8 +604,8 @@ __global__ __launch_bounds__(HM_T) void k_gs_hashorder(const GsHeader* __restric
     for (; p < HM_LDS_PHASES; ++p) {
       const int nb = static_cast<int>(c_sched[p]);
       const int hi = min(n, nb);
-      hm_phase<4>(lkey, lt, lbk, lmem, larr, lat, lgmin, lcnt, lstart, lo, hi, nb, static_cast<uint64_t>(nb), lds);
-      int32_t* sw = lt;                          // the new positions become the next phase's timestamps
+      hm_phase<4, uint16_t>(lkey, lt, lbk, lmem, larr, lat, lgmin, lcnt, lstart, lo, hi, nb, static_cast<uint64_t>(nb), lds);
+      uint16_t* sw = lt;                         // the new positions become the next phase's timestamps
       lt = lbk;
       lbk = sw;
       lo = hi;
@@ -612,7 +618,7 @@ __global__ __launch_bounds__(HM_T) void k_gs_hashorder(const GsHeader* __restric
       hm_emit(lt, ins_seg, bary, out_xyz, o, n);
       return;
     }
-    for (int e = tid; e < lo; e += HM_T) hm_t[o + e] = lt[e];
+    for (int e = tid; e < lo; e += HM_T) hm_t[o + e] = static_cast<int32_t>(lt[e]);
     __syncthreads();
   }
 
@@ -629,7 +635,7 @@ __global__ __launch_bounds__(HM_T) void k_gs_hashorder(const GsHeader* __restric
     const int64_t nb64 = c_sched[p];
     const int hi = static_cast<int>(min(static_cast<int64_t>(n), nb64));
     const int nb = static_cast<int>(min(nb64, static_cast<int64_t>(2147483647)));
-    hm_phase<4>(key, t, bk, memt, arrv, at, gmin, cnt, start, lo, hi, nb, static_cast<uint64_t>(nb64), lds);
+    hm_phase<4, int32_t>(key, t, bk, memt, arrv, at, gmin, cnt, start, lo, hi, nb, static_cast<uint64_t>(nb64), lds);
     int32_t* sw = t;
     t = bk;
     bk = sw;

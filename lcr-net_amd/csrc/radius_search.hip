@@ -436,10 +436,10 @@ __global__ __launch_bounds__(RS_WAVES * 64) void k_radius_query(const float* __r
           const int bb = rq_bin(k, bin_scale);
           const int lo = base[bb], hi = base[bb + 1];
           int rank = lo;
-          for (int j0 = lo; j0 < hi; j0 += 4) {                // four bin mates per trip: two LDS round trips for bins of up to four
-            const int s0 = perm[j0], s1 = perm[min(j0 + 1, hi - 1)], s2 = perm[min(j0 + 2, hi - 1)], s3 = perm[min(j0 + 3, hi - 1)];
-            const uint64_t a0 = keys[s0], a1 = keys[s1], a2 = keys[s2], a3 = keys[s3];
-            rank += (a0 < k) + (j0 + 1 < hi && a1 < k) + (j0 + 2 < hi && a2 < k) + (j0 + 3 < hi && a3 < k);   // keys are unique
+          for (int j0 = lo; j0 < hi; j0 += 2) {                // two bin mates per trip (a bin holds 1.8 keys on average): the LDS unit,
+            const int s0 = perm[j0], s1 = perm[min(j0 + 1, hi - 1)];   // shared by the CU's four SIMDs, is this kernel's scarce resource
+            const uint64_t a0 = keys[s0], a1 = keys[s1];
+            rank += (a0 < k) + (j0 + 1 < hi && a1 < k);        // keys are unique (the index is part of the key)
           }
           if ((dbg & 4) ? rank == -12345 : rank < limit) {
             const int64_t v = static_cast<int64_t>(static_cast<uint32_t>(k));
