@@ -510,11 +510,13 @@ __global__ __launch_bounds__(256) void k_build_padded_scores(const float* __rest
 // rowarg[b][i] = argmax_j P[i][:], rowbeat = P[i][rowarg] > P[i][N];  colarg[b][j] = argmax_i P[:][j], colbeat = P[colarg][j] > P[M][j].
 __global__ __launch_bounds__(256) void k_top1_stats(const float* __restrict__ logS, int M, int N, int32_t* __restrict__ rowarg,
                                                     uint8_t* __restrict__ rowbeat, int32_t* __restrict__ colarg, uint8_t* __restrict__ colbeat) {
-  const int b = blockIdx.x;
+  // grid (B, slices): few large problems (the node-level matrix of a pair, B = 1..P) are spread over `slices` workgroups each
+  // (one workgroup scanning a 351 x 332 matrix twice took 85-965 us); many small ones (patch matrices) use one workgroup each
+  const int b = blockIdx.x, slice = blockIdx.y, nslices = gridDim.y;
   const int M1 = M + 1, N1 = N + 1;
   const float* s = logS + static_cast<int64_t>(b) * M1 * N1;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
-  for (int i = w; i < M1; i += 4) {
+  for (int i = slice * 4 + w; i < M1; i += 4 * nslices) {
     float best = -INFINITY;
     int bj = 0;
     for (int j = lane; j < N1; j += 64) {
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(256) void k_top1_stats(const float* __restrict__ lo
       rowbeat[static_cast<int64_t>(b) * M1 + i] = best > expf(s[i * N1 + N]) ? 1 : 0;
     }
   }
-  for (int j = threadIdx.x; j < N1; j += 256) {
+  for (int j = slice * 256 + threadIdx.x; j < N1; j += 256 * nslices) {
     float best = -INFINITY;
     int bi = 0;
     for (int i = 0; i < M1; ++i) {
@@ -946,7 +948,8 @@ extern "C" int lcr_top1_matching(const float* logS, int64_t B, int M, int N, con
   void* sws = c.take<char>(scan_ws_bytes(B * M + 1));
   hipStream_t st = ST(stream);
   if (!out_bij) {
-    hipLaunchKernelGGL(k_top1_stats, dim3(static_cast<int>(B)), dim3(256), 0, st, logS, M, N, rowarg, rowbeat, colarg, colbeat);
+    const int slices = B >= 64 ? 1 : std::max(1, std::min(32, (M + 1 + 15) / 16));
+    hipLaunchKernelGGL(k_top1_stats, dim3(static_cast<int>(B), slices), dim3(256), 0, st, logS, M, N, rowarg, rowbeat, colarg, colbeat);
     hipLaunchKernelGGL((k_top1_emit<0>), dim3(blocks_for(B * M)), dim3(256), 0, st, logS, B, M, N, rowarg, rowbeat, colarg, colbeat, row_mask, col_mask,
                        counts, offsets, out_bij, out_score);
     hipMemsetAsync(counts + B * M, 0, sizeof(int32_t), st);

@@ -227,17 +227,85 @@ class LCRNet(nn.Module):
         fl = list(feats_list)
         fl[-1] = enhanced                                              # LCRNet.py:154-155
         feats_f = self.kpdecoder(fl, data_dict, pairs=P)[0]
-        # ---- DenseMatchingHEAD (:161-272): pair by pair (shapes depend on each pair's nodes / matches)
+        # ---- DenseMatchingHEAD (:161-272)
+        sl = lambda off, i: slice(off[i], off[i + 1])
+        if P == 1:
+            self._dense_matching(outs[0], pts_f[sl(off_f, 0)].contiguous(), pts_f[sl(off_f, 1)].contiguous(),
+                                 feats_f[sl(off_f, 0)].contiguous(), feats_f[sl(off_f, 1)].contiguous(),
+                                 vd["points_c"][sl(off_m, 0)].contiguous(), vd["points_c"][sl(off_m, 1)].contiguous(),
+                                 vd["feats_c"][sl(off_m, 0)].contiguous(), vd["feats_c"][sl(off_m, 1)].contiguous())
+        else:
+            self._dense_matching_group(outs, P, pts_f, feats_f, off_f, vd, off_m)
         for p in range(P):
             c = 2 * p
-            sl = lambda off, i: slice(off[i], off[i + 1])
-            self._dense_matching(outs[p], pts_f[sl(off_f, c)].contiguous(), pts_f[sl(off_f, c + 1)].contiguous(),
-                                 feats_f[sl(off_f, c)].contiguous(), feats_f[sl(off_f, c + 1)].contiguous(),
-                                 vd["points_c"][sl(off_m, c)].contiguous(), vd["points_c"][sl(off_m, c + 1)].contiguous(),
-                                 vd["feats_c"][sl(off_m, c)].contiguous(), vd["feats_c"][sl(off_m, c + 1)].contiguous())
             outs[p].update({"shifted_pos_points_c": vd["shifted_points_c"][sl(off_c, c)], "shifted_anc_points_c": vd["shifted_points_c"][sl(off_c, c + 1)],
                             "length": vd["length"][c:c + 2], "feats_c": vd["feats_c"][off_m[c]:off_m[c + 2]]})
         return outs
+
+    def _dense_matching_group(self, outs, P, pts_f, feats_f, off_f, vd, off_m):
+        """DenseMatchingHEAD for P pairs, stage by stage: the node-level optimal transport of all pairs in ONE batched problem set
+        (matrices padded to the largest pair with masked rows / columns — LearnableLogOptimalTransport excludes masked entries and
+        normalises by the valid counts, learnable_sinkhorn.py:20-66, so the valid block is the unpadded result), its top-1 matching
+        in one call, the patch gathers over the whole stack, the patch-level transport of all pairs' patches in one call; only the
+        local-to-global registration, whose hypotheses compete inside a pair, runs pair by pair.  Per pair that is 200 / P Sinkhorn
+        launches instead of 200."""
+        K = self.num_points_in_patch
+        dev = pts_f.device
+        n_all = pts_f.shape[0]
+        parts = []
+        for c in range(2 * P):
+            _, nm, knn, km = F.point_to_node_partition(pts_f[off_f[c]:off_f[c + 1]].contiguous(), vd["points_c"][off_m[c]:off_m[c + 1]].contiguous(), K)
+            parts.append((nm, knn, km))
+        m = [off_m[c + 1] - off_m[c] for c in range(2 * P)]
+        Mx, Nx = max(m[0::2]), max(m[1::2])
+        fc = vd["feats_c"]
+        fp = torch.zeros((P, Mx, fc.shape[1]), dtype=fc.dtype, device=dev)
+        fa = torch.zeros((P, Nx, fc.shape[1]), dtype=fc.dtype, device=dev)
+        rm = torch.zeros((P, Mx), dtype=torch.bool, device=dev)
+        cm = torch.zeros((P, Nx), dtype=torch.bool, device=dev)
+        for p in range(P):
+            fp[p, :m[2 * p]] = fc[off_m[2 * p]:off_m[2 * p + 1]]
+            fa[p, :m[2 * p + 1]] = fc[off_m[2 * p + 1]:off_m[2 * p + 2]]
+            rm[p, :m[2 * p]] = parts[2 * p][0]
+            cm[p, :m[2 * p + 1]] = parts[2 * p + 1][0]
+        ns = F.log_optimal_transport(F.bmm_nt(fp, fa), rm, cm, self.node_optimal_transport.alpha,
+                                     scale=1.0 / fc.shape[1] ** 0.5, iters=self.node_optimal_transport.num_iterations)
+        nbij, nscore = F.top1_matching(ns)                              # rows (pair, i, j), pair-major; padding never beats a dustbin
+        per_pair = torch.bincount(nbij[:, 0].long(), minlength=P).tolist()          # host sync: node correspondences per pair
+        q_off = [0]
+        for x in per_pair:
+            q_off.append(q_off[-1] + x)
+        pk_g, ak_g, pkm, akm, node_idx = [], [], [], [], []
+        for p in range(P):
+            rows = nbij[q_off[p]:q_off[p + 1]]
+            pi, ai = rows[:, 1].long(), rows[:, 2].long()
+            node_idx.append((pi, ai))
+            for side, idx, out_g, out_m in ((2 * p, pi, pk_g, pkm), (2 * p + 1, ai, ak_g, akm)):
+                knn = parts[side][1][idx]                                # (Q, K) point indices inside the cloud, pad = its point count
+                n_f = off_f[side + 1] - off_f[side]
+                out_g.append(torch.where(knn == n_f, torch.full_like(knn, n_all), knn + off_f[side]))   # -> rows of the whole stack
+                out_m.append(parts[side][2][idx])
+        pk_g, ak_g = torch.cat(pk_g).contiguous(), torch.cat(ak_g).contiguous()
+        pkm, akm = torch.cat(pkm).contiguous(), torch.cat(akm).contiguous()
+        pkp, akp = F.gather_rows(pts_f, pk_g), F.gather_rows(pts_f, ak_g)
+        pkf, akf = F.gather_rows(feats_f, pk_g), F.gather_rows(feats_f, ak_g)
+        ms = F.log_optimal_transport(F.bmm_nt(pkf, akf), pkm, akm, self.optimal_transport.alpha,
+                                     scale=1.0 / feats_f.shape[1] ** 0.5, iters=self.optimal_transport.num_iterations)
+        for p in range(P):
+            q = slice(q_off[p], q_off[p + 1])
+            c = 2 * p
+            rp, sp, sc, T = self._local_global_registration(pkp[q], akp[q], pkm[q], akm[q], ms[q])
+            pi, ai = node_idx[p]
+            outs[p].update({
+                "pos_points_c": vd["points_c"][off_m[c]:off_m[c + 1]], "anc_points_c": vd["points_c"][off_m[c + 1]:off_m[c + 2]],
+                "pos_feats_c": fc[off_m[c]:off_m[c + 1]], "anc_feats_c": fc[off_m[c + 1]:off_m[c + 2]],
+                "pos_points_f": pts_f[off_f[c]:off_f[c + 1]], "anc_points_f": pts_f[off_f[c + 1]:off_f[c + 2]],
+                "pos_node_knn_indices": parts[c][1], "pos_node_knn_masks": parts[c][2], "anc_node_knn_indices": parts[c + 1][1],
+                "anc_node_knn_masks": parts[c + 1][2], "pos_node_corr_indices": pi, "anc_node_corr_indices": ai,
+                "node_corr_scores": nscore[q], "pos_feats_f": feats_f[off_f[c]:off_f[c + 1]], "anc_feats_f": feats_f[off_f[c + 1]:off_f[c + 2]],
+                "pos_node_corr_knn_points": pkp[q], "anc_node_corr_knn_points": akp[q], "pos_node_corr_knn_masks": pkm[q],
+                "anc_node_corr_knn_masks": akm[q], "matching_scores": ms[q],
+                "pos_corr_points": rp, "anc_corr_points": sp, "corr_scores": sc, "estimated_transform": T})
 
     def _dense_matching(self, out, pos_f, anc_f, pos_ff, anc_ff, pos_nodes, anc_nodes, pos_fc, anc_fc):
         K = self.num_points_in_patch
