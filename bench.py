@@ -247,7 +247,15 @@ def main():
 
     run_steps(8)                 # priming, untimed and not counted: allocator growth for the batches in flight, lazy code-object loads
     run_steps(args.warmup)
-    stage_points = [sum(l) for l in pipe.preprocess(raw_pts, raw_lens)["lengths_host"]]
+    dd0 = pipe.preprocess(raw_pts, raw_lens)
+    stage_points = [sum(l) for l in dd0["lengths_host"]]
+    # valid (non-padding) entries of the index lists the KPConv layers gather: the aggregation's flops are 2 * 15 * nnz * C
+    nnz = {}
+    for i in range(NUM_STAGES):
+        nnz[(stage_points[i], stage_points[i])] = int((dd0["neighbors"][i] < stage_points[i]).sum())
+        if i + 1 < NUM_STAGES:
+            nnz[(stage_points[i + 1], stage_points[i])] = int((dd0["subsampling"][i] < stage_points[i]).sum())
+    del dd0
     # ---- timed region: exactly K steps between barrier + synchronize
     timer = F.KernelTimer({"kpconv_aggregate", "gemm", "radius_query"})
     if world > 1:
@@ -301,6 +309,8 @@ def main():
         bytes_kp = sum(M * H * isz + (M + Ns) * 12 + Ns * C * 4 for _, (M, Ns, H, C, isz) in agg) + \
             sum(M * N * 4 + K * N * 4 for _, (M, N, K) in contr)
         t_kp = t_agg + sum(t for t, _ in contr)
+        # the aggregation is MFMA work too (D[16 kernel points x C] += W[16 x 4] F[4 x C] per four neighbours): 2*15*nnz*C flops
+        flops_agg = sum(2.0 * 15 * nnz.get((M, Ns), M * H) * C for _, (M, Ns, H, C, isz) in agg)
         n_search = 7 if args.no_upsampling else 10
         bytes_rs = search_bytes(stage_points, not args.no_upsampling)
         traffic, traffic_src = None, None
@@ -313,7 +323,8 @@ def main():
                 "achieved_alone": round(iso, 2), "frac_alone": round(iso / FP32_PEAK_TFLOPS, 4),
                 "avg_launch_us": round(t_gemm / max(len(gem), 1) * 1e6, 2),
                 "gflop_per_launch": round(flops / max(len(gem), 1) / 1e9, 3),
-                "share_of_step": {"gemm": round(t_gemm / dt, 3), "kpconv_aggregate": round(t_agg / dt, 3), "radius_query": round(t_rs / dt, 3)},
+                "event_time_over_step_time": {"gemm": round(t_gemm / dt, 3), "kpconv_aggregate": round(t_agg / dt, 3), "radius_query": round(t_rs / dt, 3),
+                                              "note": "sum of launch-to-completion event times / wall time; streams overlap, so the shares do not add up to 1"},
                 "neighbor": {"kernel": "lcr::k_radius_query (%d searches/step)" % n_search, "bound": "hbm",
                              "algorithmic_mb_per_step": round(bytes_rs / 1e6, 2),
                              "achieved": round(bytes_rs * args.steps / t_rs / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -321,6 +332,13 @@ def main():
                              "ms_per_step": round(t_rs / args.steps * 1e3, 4),
                              "achieved_alone": round(bytes_rs / iso_rs / 1e9, 1), "frac_alone": round(bytes_rs / iso_rs / 1e9 / HBM_PEAK_GBS, 4),
                              "ms_per_step_alone": round(iso_rs * 1e3, 4)},
+                "aggregation": {"kernel": "lcr::k_kpconv_aggregate (fp32 MFMA 16x16x4, %d launches/step)" % (len(agg) // max(args.steps, 1)), "bound": "mfma",
+                                "achieved": round(flops_agg / t_agg / 1e12, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(flops_agg / t_agg / 1e12 / FP32_PEAK_TFLOPS, 4), "gflop_per_step": round(flops_agg / args.steps / 1e9, 2),
+                                "note": "2*15*nnz*C flops over the valid neighbours; event time inside the pipeline (other streams share the CUs)"},
+                "whole_step": {"gflop_per_step": round((flops + flops_agg) / args.steps / 1e9, 1), "what": "GEMMs + KPConv aggregation (fp32 MFMA work of a step)",
+                               "tflops": round((flops + flops_agg) / dt / 1e12, 2),
+                               "frac_of_fp32_mfma_peak": round((flops + flops_agg) / dt / 1e12 / FP32_PEAK_TFLOPS, 4)},
                 "secondary": {"kernel": "KPConv layers: lcr::k_kpconv_aggregate + its (15C x Cout) contraction", "bound": "hbm",
                               "achieved": round(bytes_kp / t_kp / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(bytes_kp / t_kp / 1e9 / HBM_PEAK_GBS, 4),

@@ -26,7 +26,8 @@ def _hip():
 
 
 def destroy_streams(streams):
-    """hipStreamDestroy for streams made by `_native_streams` (torch's ExternalStream wrapper does not own its handle)."""
+    """hipStreamDestroy for streams made by `_native_streams` that never carried tensors (probe candidates that lost): torch's
+    ExternalStream wrapper does not own its handle.  Streams that did carry work go through `release_streams` instead."""
     import ctypes
     for st in streams:
         h = getattr(st, "_lcr_handle", None)
@@ -36,19 +37,50 @@ def destroy_streams(streams):
             st._lcr_handle = None
 
 
+# Streams that carried a pipeline's work are never destroyed: torch's caching allocator remembers the streams a block was used on
+# (`record_stream`) and records an event on each of them when the block is finally freed — possibly long after `close()`, e.g.
+# while a traceback keeps a generator frame alive — and an event record on a destroyed stream poisons the context ("operation not
+# permitted when stream is capturing" at the next unrelated call).  `close()` parks them here; the next pipeline on the device takes
+# them back, so the number of native streams is bounded by the pipelines alive at the same time.
+_PARKED = {}
+_PARK_LOCK = None
+
+
+def release_streams(streams):
+    """Hand worked-on native streams back for reuse (idempotent per stream)."""
+    import threading
+    global _PARK_LOCK
+    if _PARK_LOCK is None:
+        _PARK_LOCK = threading.Lock()
+    for st in streams:
+        if getattr(st, "_lcr_handle", None) and not getattr(st, "_lcr_parked", False):
+            st.synchronize()
+            st._lcr_parked = st._lcr_used = True
+            with _PARK_LOCK:
+                _PARKED.setdefault((st.device.index, st._lcr_priority), []).append(st)
+
+
 def _native_streams(device, n, priority=0):
-    """n HIP streams created back to back, wrapped for torch (handle kept in `_lcr_handle` for `destroy_streams`)."""
+    """n HIP streams wrapped for torch: parked ones of the same device / priority first, then new ones created back to back (handle
+    kept in `_lcr_handle` for `destroy_streams`)."""
     import ctypes
     hip = _hip()
     out = []
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    parked = _PARKED.get((idx, int(priority)), [])
+    while parked and len(out) < n:
+        st = parked.pop()
+        st._lcr_parked = False
+        out.append(st)
     with torch.cuda.device(device):
-        for _ in range(n):
+        for _ in range(n - len(out)):
             h = ctypes.c_void_p()
             rc = hip.hipStreamCreateWithPriority(ctypes.byref(h), 1, int(priority))      # hipStreamNonBlocking
             if rc != 0:
                 raise RuntimeError("hipStreamCreateWithPriority failed: %d" % rc)
             st = torch.cuda.ExternalStream(h.value, device=device)
-            st._lcr_handle = h.value
+            st._lcr_handle, st._lcr_priority, st._lcr_parked, st._lcr_used = h.value, int(priority), False, False
             out.append(st)
     return out
 
@@ -104,7 +136,9 @@ def distinct_queue_streams(device, n, priority=0, pool=10):
             break
         if c not in chosen:
             chosen.append(c)
-    destroy_streams([c for c in cand if c not in chosen])     # the candidates that lost the probe are not kept alive
+    losers = [c for c in cand if not any(c is x for x in chosen)]
+    destroy_streams([c for c in losers if not getattr(c, "_lcr_used", False)])     # fresh candidates that lost the probe are not kept alive
+    release_streams([c for c in losers if getattr(c, "_lcr_used", False)])           # parked ones taken for the probe go back
     return chosen
 
 
@@ -142,8 +176,8 @@ class DescriptorPipeline:
         self.enc_streams = None      # set by enable_dual_encoder(): consecutive batches' encoders on alternating streams
 
     def close(self):
-        """Destroy the pipeline's native streams (idempotent).  The pipeline cannot run afterwards."""
-        destroy_streams(self._streams)
+        """Give the pipeline's native streams back (idempotent; see `release_streams`).  The pipeline cannot run afterwards."""
+        release_streams(self._streams)
         self._streams, self.pre_streams, self.pre_stream, self.enc_streams = [], [], None, None
 
     def __enter__(self):
@@ -369,8 +403,8 @@ class PairPipeline:
         self._streams = distinct_queue_streams(self.device, self.workers) if self.workers > 1 else []
 
     def close(self):
-        """Destroy the worker streams (idempotent)."""
-        destroy_streams(self._streams)
+        """Give the worker streams back (idempotent; see `release_streams`)."""
+        release_streams(self._streams)
         self._streams = []
 
     def __enter__(self):
