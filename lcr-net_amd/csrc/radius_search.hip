@@ -277,8 +277,7 @@ __global__ __launch_bounds__(RS_WAVES * 64) void k_radius_query(const float* __r
                                                                   const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
                                                                   float r2, int limit, int64_t* __restrict__ out64,
                                                                   int32_t* __restrict__ out32, int32_t* __restrict__ out_cnt,
-                                                                  const int32_t* __restrict__ q_order, int qb_dbg) {
-  const int qb = qb_dbg & 0xff, dbg = qb_dbg >> 8;   // dbg: timing ablations (tools/radius_bench.py), 0 in production
+                                                                  const int32_t* __restrict__ q_order, int qb) {
   __shared__ __attribute__((aligned(16))) uint64_t s_keys[RS_WAVES][RQ_CAP];
   __shared__ uint16_t s_perm[RS_WAVES][RQ_CAP];             // bin-ordered position -> slot in s_keys
   __shared__ int s_cnt[RS_WAVES][RQ_BINS];
@@ -375,7 +374,7 @@ __global__ __launch_bounds__(RS_WAVES * 64) void k_radius_query(const float* __r
       const int l0 = 16 * j;                                   // wave-uniform lane base of query j
       const int64_t qi = static_cast<int64_t>(__builtin_amdgcn_readlane(qi_lo, l0));
       const float qx = rdlane(mx, l0), qy = rdlane(my, l0), qz = rdlane(mz, l0);
-      const int total = (dbg & 2) ? 0 : rdlane(incl, l0 + 8);
+      const int total = rdlane(incl, l0 + 8);
       RqRuns R;
       R.c0 = rdlane(ck_all, l0);
       R.p1 = rdlane(pk_all, l0 + 1), R.c1 = rdlane(ck_all, l0 + 1);
@@ -398,7 +397,7 @@ __global__ __launch_bounds__(RS_WAVES * 64) void k_radius_query(const float* __r
       if (out_cnt) {
         if (lane == 0) out_cnt[qi] = n;
       }
-      if (limit <= 0 || (dbg & 1)) {
+      if (limit <= 0) {                                        // count-only mode
         if (n > 0) cnt[lane] = 0;
         continue;
       }
@@ -441,7 +440,7 @@ __global__ __launch_bounds__(RS_WAVES * 64) void k_radius_query(const float* __r
             const uint64_t a0 = keys[s0], a1 = keys[s1];
             rank += (a0 < k) + (j0 + 1 < hi && a1 < k);        // keys are unique (the index is part of the key)
           }
-          if ((dbg & 4) ? rank == -12345 : rank < limit) {
+          if (rank < limit) {
             const int64_t v = static_cast<int64_t>(static_cast<uint32_t>(k));
             if (HAS64) row64[rank] = v;
             if (HAS32) row32[rank] = static_cast<int32_t>(v);
@@ -477,11 +476,10 @@ __global__ __launch_bounds__(RS_WAVES * 64) void k_radius_query(const float* __r
           }
         }
       }
-      if (!(dbg & 8))
-        for (int col = n + lane; col < limit; col += 64) {
-          if (HAS64) row64[col] = ns_total;
-          if (HAS32) row32[col] = static_cast<int32_t>(ns_total);
-        }
+      for (int col = n + lane; col < limit; col += 64) {
+        if (HAS64) row64[col] = ns_total;
+        if (HAS32) row32[col] = static_cast<int32_t>(ns_total);
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
@@ -570,8 +568,7 @@ extern "C" int lcr_radius_query_ordered(const float* q, const int64_t* qlen, int
     // queries per wavefront turn: four (one per DPP row) when the search is large enough to fill the chip anyway, fewer for the
     // small coarse-stage searches, which are latency-bound and want as many wavefronts as they have queries
     static const int qb_env = getenv("LCR_RS_QB") ? atoi(getenv("LCR_RS_QB")) : 0;
-    static const int dbg_env = getenv("LCR_RS_DBG") ? atoi(getenv("LCR_RS_DBG")) : 0;
-    const int qb = (qb_env ? qb_env : (nq_cap >= 65536 ? 4 : (nq_cap >= 16384 ? 2 : 1))) | (dbg_env << 8);
+    const int qb = qb_env ? qb_env : (nq_cap >= 65536 ? 4 : (nq_cap >= 16384 ? 2 : 1));
     // One resident generation of workgroups, each with an equal share of the queries: with more workgroups than fit, the last
     // generation runs on a part-empty chip (2048 workgroups on 6-per-CU residency: 2 of 8 ran alone, measured 3.3 wavefronts per
     // SIMD on average instead of 6).  Residency from the kernel's register count (the occupancy API is one workgroup per CU high
@@ -581,17 +578,17 @@ extern "C" int lcr_radius_query_ordered(const float* q, const int64_t* qlen, int
       hipFuncAttributes fa;
       int api = 0;
       if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_radius_query<false, true>)) != hipSuccess) return 4;
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, reinterpret_cast<const void*>(&k_radius_query<false, true>), RS_WAVES * 64, 0);
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, reinterpret_cast<const void*>(&k_radius_query<false, true>), RS_WAVES * 64, 0);
       const int by_vgpr = 512 / ((fa.numRegs + 7) / 8 * 8);
       return max(1, min(min(api > 0 ? api : 8, by_vgpr), 6));
     }();
     static const int n_cu = []() {
       int dev = 0, n = 256;
-      hipGetDevice(&dev);
-      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
       return n;
     }();
-    const int nblk2 = (min(div_up(nq_cap, RS_WAVES * (qb & 0xff)), getenv("LCR_RS_NBLK") ? atoi(getenv("LCR_RS_NBLK")) : n_cu * wg_per_cu) + 7) / 8 * 8;
+    const int nblk2 = (min(div_up(nq_cap, RS_WAVES * qb), getenv("LCR_RS_NBLK") ? atoi(getenv("LCR_RS_NBLK")) : n_cu * wg_per_cu) + 7) / 8 * 8;
     const dim3 grid2(nblk2);
     if (out_idx64 && out_idx32)
       hipLaunchKernelGGL((k_radius_query<true, true>), grid2, block, 0, st, q, qlen, B, nq_cap, L.hdr, L.cell_start, L.sorted, r2, limit,
