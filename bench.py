@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--pre-workers", type=int, default=2, help="host threads / streams pre-processing consecutive batches concurrently")
     ap.add_argument("--depth", type=int, default=2, help="batches pre-processed ahead of the encoder")
     ap.add_argument("--single-encoder", action="store_true", help="one encoder stream (default: consecutive batches alternate between two)")
+    ap.add_argument("--distinct-batches", type=int, default=4, help="distinct input batches the steps cycle through (the batch of 8 scans "
+                    "rotated about the vertical axis by k * 37 degrees: other voxels, other neighbourhoods, same scene statistics)")
     ap.add_argument("--cpu-worker", nargs=4, metavar=("MODE", "SCAN", "THREADS", "START"), help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -219,8 +221,15 @@ def main():
     model = model.to(dev)
 
     scans = make_batch(rank)
-    raw_pts = torch.from_numpy(np.concatenate(scans)).to(dev)
-    raw_lens = torch.tensor([len(s) for s in scans], dtype=torch.int64, device=dev)
+    # the steps cycle through a few DISTINCT resident batches (not one buffer re-fed every step): the scans rotated about z
+    nb_in = max(1, args.distinct_batches)
+    inputs = []
+    for k in range(nb_in):
+        a = np.deg2rad(float(os.environ.get("LCR_BENCH_ROT_DEG", "37")) * k)
+        R = np.array([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]], dtype=np.float32)
+        inputs.append((torch.from_numpy(np.concatenate([s @ R.T for s in scans]).astype(np.float32)).to(dev),
+                       torch.tensor([len(s) for s in scans], dtype=torch.int64, device=dev)))
+    raw_pts, raw_lens = inputs[0]
     gathered = torch.empty((world * BATCH, 256), dtype=torch.float32, device=dev) if world > 1 else None
 
     from lcrnet_amd.pipeline import DescriptorPipeline
@@ -234,7 +243,7 @@ def main():
         k+1 overlaps the encoder of step k on a second stream (DescriptorPipeline)."""
         last = None
         dual = pipe.enc_streams is not None and not (args.no_overlap or args.no_thread)
-        for item in pipe.run(((raw_pts, raw_lens) for _ in range(n)), sync_to_caller=not dual):
+        for item in pipe.run((inputs[k % nb_in] for k in range(n)), sync_to_caller=not dual):
             desc, es = (item[0], item[2]) if dual else (item, None)
             if world > 1:
                 if es is not None:
@@ -247,15 +256,19 @@ def main():
 
     run_steps(8)                 # priming, untimed and not counted: allocator growth for the batches in flight, lazy code-object loads
     run_steps(args.warmup)
-    dd0 = pipe.preprocess(raw_pts, raw_lens)
-    stage_points = [sum(l) for l in dd0["lengths_host"]]
-    # valid (non-padding) entries of the index lists the KPConv layers gather: the aggregation's flops are 2 * 15 * nnz * C
-    nnz = {}
-    for i in range(NUM_STAGES):
-        nnz[(stage_points[i], stage_points[i])] = int((dd0["neighbors"][i] < stage_points[i]).sum())
-        if i + 1 < NUM_STAGES:
-            nnz[(stage_points[i + 1], stage_points[i])] = int((dd0["subsampling"][i] < stage_points[i]).sum())
-    del dd0
+    # per distinct batch: stage sizes and the valid (non-padding) entries of the index lists the KPConv layers gather (the
+    # aggregation's flops are 2 * 15 * nnz * C)
+    stage_points_all, nnz = [], {}
+    for pts_k, lens_k in inputs:
+        dd0 = pipe.preprocess(pts_k, lens_k)
+        sp = [sum(l) for l in dd0["lengths_host"]]
+        stage_points_all.append(sp)
+        for i in range(NUM_STAGES):
+            nnz[(sp[i], sp[i])] = int((dd0["neighbors"][i] < sp[i]).sum())
+            if i + 1 < NUM_STAGES:
+                nnz[(sp[i + 1], sp[i])] = int((dd0["subsampling"][i] < sp[i]).sum())
+        del dd0
+    stage_points = stage_points_all[0]
     # ---- timed region: exactly K steps between barrier + synchronize
     timer = F.KernelTimer({"kpconv_aggregate", "gemm", "radius_query"})
     if world > 1:
@@ -312,7 +325,8 @@ def main():
         # the aggregation is MFMA work too (D[16 kernel points x C] += W[16 x 4] F[4 x C] per four neighbours): 2*15*nnz*C flops
         flops_agg = sum(2.0 * 15 * nnz.get((M, Ns), M * H) * C for _, (M, Ns, H, C, isz) in agg)
         n_search = 7 if args.no_upsampling else 10
-        bytes_rs = search_bytes(stage_points, not args.no_upsampling)
+        uses = [len(range(k, args.steps, nb_in)) for k in range(nb_in)]              # how often the timed region fed each batch
+        bytes_rs = sum(u * search_bytes(sp, not args.no_upsampling) for u, sp in zip(uses, stage_points_all)) / max(args.steps, 1)
         traffic, traffic_src = None, None
         if os.path.exists(PMC_JSON):
             traffic = json.load(open(PMC_JSON)).get("k_gemm_f32", {}).get("traffic_bytes")
@@ -330,7 +344,8 @@ def main():
                              "achieved": round(bytes_rs * args.steps / t_rs / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(bytes_rs * args.steps / t_rs / 1e9 / HBM_PEAK_GBS, 4),
                              "ms_per_step": round(t_rs / args.steps * 1e3, 4),
-                             "achieved_alone": round(bytes_rs / iso_rs / 1e9, 1), "frac_alone": round(bytes_rs / iso_rs / 1e9 / HBM_PEAK_GBS, 4),
+                             "achieved_alone": round(search_bytes(stage_points, not args.no_upsampling) / iso_rs / 1e9, 1),
+                             "frac_alone": round(search_bytes(stage_points, not args.no_upsampling) / iso_rs / 1e9 / HBM_PEAK_GBS, 4),
                              "ms_per_step_alone": round(iso_rs * 1e3, 4)},
                 "aggregation": {"kernel": "lcr::k_kpconv_aggregate (fp32 MFMA 16x16x4, %d launches/step)" % (len(agg) // max(args.steps, 1)), "bound": "mfma",
                                 "achieved": round(flops_agg / t_agg / 1e12, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -353,7 +368,7 @@ def main():
                                    "voxelise + 3 subsamples + %d radius searches + KPConv encoder + NetVLAD, seeded random weights"
                                    % n_search,
                        "scans_per_step_per_gpu": BATCH, "raw_points_per_scan": int(raw_pts.shape[0] // BATCH),
-                       "stage_points_per_batch": stage_points, "neighbor_limits": LIMITS,
+                       "stage_points_per_batch": stage_points, "distinct_input_batches": nb_in, "neighbor_limits": LIMITS,
                        "streams": "1" if args.no_overlap else ("pre-processing stream (own host thread, 2 batches ahead) + %d encoder stream(s)"
                                                                % (1 if (args.single_encoder or args.no_thread) else 2)),
                        "parallelism": "scan-parallel x%d, all-gather of descriptors%s" % (world, (" (%s)" % backend) if backend else "")},
