@@ -283,3 +283,48 @@ def test_radius_query_processing_order_does_not_change_the_result():
     for od in orders:
         got, cnt = grid.query(dev(q), dev(qlens), 40, want_counts=True, q_order=od)
         assert torch.equal(got, base) and torch.equal(cnt, base_cnt)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_radius_search_fuzz_against_the_oracle(seed):
+    """Randomised configurations through every path of the query kernel — 1 / 2 / 4 queries set up per wavefront turn (query counts
+    below / above 16 384 / 65 536), sphere culling with coordinates quantised to a lattice commensurate with nothing in particular
+    AND with the cell size, balls denser than the 512-key LDS capacity (exact fallback), empty and one-point clouds, queries far
+    outside the support box, limits below and above the densest ball — bit-exact rows and counts vs the C++ oracle."""
+    from lcrnet_amd.modules.ops import SupportGrid
+    rng = np.random.default_rng(1000 + seed)
+    B = int(rng.integers(1, 6))
+    radius = float(rng.choice([0.4, 0.75, 1.0, 1.275, 2.55]))
+    big = seed % 4 == 3
+    s_sizes = rng.integers(0, 30000 if big else 4000, B)
+    s_sizes[rng.integers(0, B)] = max(s_sizes.max(), 1)
+    q_sizes = rng.integers(0, 30000 if big else 3000, B)
+    if seed % 6 == 5:
+        q_sizes[:] = 0
+        q_sizes[0] = 70000                                   # > 65 536 queries: four per turn
+    extent = np.array([rng.uniform(5, 60), rng.uniform(5, 60), rng.uniform(0.5, 6)])
+    s_list, q_list = [], []
+    for b in range(B):
+        s = rng.random((int(s_sizes[b]), 3)) * extent - extent / 2
+        if seed % 3 == 0:
+            s = np.round(s / 0.25) * 0.25                    # lattice: exact ties, points on common planes
+        if seed % 3 == 1 and len(s) > 700:
+            s[:700] = s[0] + rng.standard_normal((700, 3)) * 0.05 * radius      # a ball with > 512 points inside the radius
+        q = rng.random((int(q_sizes[b]), 3)) * extent * 1.3 - extent * 0.65       # some queries outside the support box
+        if len(q) and len(s):
+            k = min(len(q), len(s)) // 2
+            q[:k] = s[rng.integers(0, len(s), k)]           # half of the queries ON support points
+        s_list.append(s.astype(np.float32))
+        q_list.append(q.astype(np.float32))
+    s, q = np.concatenate(s_list), np.concatenate(q_list)
+    sl, ql = s_sizes.astype(np.int64), q_sizes.astype(np.int64)
+    if len(q) == 0 or len(s) == 0:
+        pytest.skip("degenerate draw")
+    limit = int(rng.choice([1, 16, 40, 80]))
+    want, cnt = oracle_ops.radius_search(q, s, ql, sl, radius, limit, return_counts=True)
+    grid = SupportGrid(dev(s), dev(sl), radius)
+    got, gcnt = grid.query(dev(q), dev(ql), limit, want_counts=True)
+    assert np.array_equal(gcnt.cpu().numpy(), cnt), "in-radius counts"
+    assert np.array_equal(got.cpu().numpy().astype(np.int64), want), "neighbour rows"
+    if seed % 3 == 1 and len(s) > 700:
+        assert cnt.max() > 512                               # the storage-free fallback ran
