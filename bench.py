@@ -327,9 +327,11 @@ def main():
         n_search = 7 if args.no_upsampling else 10
         uses = [len(range(k, args.steps, nb_in)) for k in range(nb_in)]              # how often the timed region fed each batch
         bytes_rs = sum(u * search_bytes(sp, not args.no_upsampling) for u, sp in zip(uses, stage_points_all)) / max(args.steps, 1)
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_rs = None, None, None
         if os.path.exists(PMC_JSON):
-            traffic = json.load(open(PMC_JSON)).get("k_gemm_f32", {}).get("traffic_bytes")
+            pmc = json.load(open(PMC_JSON))
+            traffic = pmc.get("k_gemm_f32", {}).get("traffic_bytes")
+            traffic_rs = pmc.get("k_radius_query", {}).get("traffic_bytes")
             traffic_src = "profiles/pmc_traffic.json: separate rocprofv3 --pmc passes of this command (2*FETCH_SIZE + WRITE_SIZE per launch), not measured in this run"
         roof = {"bound": "mfma", "kernel": "lcr::k_gemm_f32 (fp32 MFMA, %d launches/step)" % (len(gem) // max(args.steps, 1)),
                 "achieved": round(flops / t_gemm / 1e12, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -344,6 +346,7 @@ def main():
                              "achieved": round(bytes_rs * args.steps / t_rs / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(bytes_rs * args.steps / t_rs / 1e9 / HBM_PEAK_GBS, 4),
                              "ms_per_step": round(t_rs / args.steps * 1e3, 4),
+                             "algorithmic_bytes_per_launch": round(bytes_rs / n_search), "traffic": traffic_rs,
                              "achieved_alone": round(search_bytes(stage_points, not args.no_upsampling) / iso_rs / 1e9, 1),
                              "frac_alone": round(search_bytes(stage_points, not args.no_upsampling) / iso_rs / 1e9 / HBM_PEAK_GBS, 4),
                              "ms_per_step_alone": round(iso_rs * 1e3, 4)},
