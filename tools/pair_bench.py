@@ -74,11 +74,25 @@ def main():
                            "attention_tflops": round(flops / max(t_att, 1e-12) / 1e12, 3),
                            "attention_frac_of_fp32_mfma_peak": round(flops / max(t_att, 1e-12) / 1e12 / FP32_PEAK_TFLOPS, 4),
                            "mean_correspondences": round(n_corr / len(work), 1)}
+    # the reference's per-pair output file (demo/demo.py:84-105) and its registration metrics on a few results (formats only: the
+    # demo pairs carry no ground-truth pose here, identity stands in, and random weights give random poses)
+    import shutil
+    import tempfile
+    from lcrnet_amd import evaluation as ev
+    from lcrnet_amd import io_formats as io
+    tmp = tempfile.mkdtemp(prefix="lcr_reg_")
+    with PairPipeline(m, neighbor_limits=limits, workers=1, pairs_per_call=4) as pp:
+        outs = list(pp.run(work[:4]))
+    paths = [io.save_registration(tmp, 0, i, i + 1, o, np.eye(4, dtype=np.float32)) for i, o in enumerate(outs)]
+    back = [io.load_registration(p) for p in paths]
+    summary = ev.registration_summary([b["transform"] for b in back], [b["estimated_transform"] for b in back])
+    files = {"written": len(paths), "keys": len(back[0]), "bytes": sum(os.path.getsize(p) for p in paths), "registration_summary_vs_identity": summary}
+    shutil.rmtree(tmp, ignore_errors=True)
     best = max(results, key=lambda k: results[k]["pairs_per_s"])
     print(json.dumps({"metric": "registration pairs/s (pair model end to end, 1 GPU)", "value": results[best]["pairs_per_s"], "unit": "pairs/s",
                       "pairs_per_call_best": int(best), "workers": args.workers, "pairs": len(work),
                       "config": "15 combinations of the 6 KITTI demo scans (~17k pts each after 0.3 m voxels), limits [74,68,70,67], seeded random weights",
-                      "by_pairs_per_call": results}))
+                      "by_pairs_per_call": results, "registration_files": files}))
 
 
 if __name__ == "__main__":
