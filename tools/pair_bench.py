@@ -86,6 +86,7 @@ def main():
     paths = [io.save_registration(tmp, 0, i, i + 1, o, np.eye(4, dtype=np.float32)) for i, o in enumerate(outs)]
     back = [io.load_registration(p) for p in paths]
     summary = ev.registration_summary([b["transform"] for b in back], [b["estimated_transform"] for b in back])
+    summary = {k: (None if isinstance(v, float) and v != v else v) for k, v in summary.items()}       # NaN means (no accepted pair) -> null
     files = {"written": len(paths), "keys": len(back[0]), "bytes": sum(os.path.getsize(p) for p in paths), "registration_summary_vs_identity": summary}
     shutil.rmtree(tmp, ignore_errors=True)
     best = max(results, key=lambda k: results[k]["pairs_per_s"])
