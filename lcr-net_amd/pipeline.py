@@ -7,6 +7,7 @@ batch k (throughput-bound MFMA/HBM kernels) run on stream B.  Ordering is by eve
 are `record_stream`ed so the caching allocator cannot recycle them early.
 """
 import os
+import threading
 import time
 
 import torch
@@ -43,15 +44,11 @@ def destroy_streams(streams):
 # permitted when stream is capturing" at the next unrelated call).  `close()` parks them here; the next pipeline on the device takes
 # them back, so the number of native streams is bounded by the pipelines alive at the same time.
 _PARKED = {}
-_PARK_LOCK = None
+_PARK_LOCK = threading.Lock()
 
 
 def release_streams(streams):
     """Hand worked-on native streams back for reuse (idempotent per stream)."""
-    import threading
-    global _PARK_LOCK
-    if _PARK_LOCK is None:
-        _PARK_LOCK = threading.Lock()
     for st in streams:
         if getattr(st, "_lcr_handle", None) and not getattr(st, "_lcr_parked", False):
             st.synchronize()
@@ -68,11 +65,12 @@ def _native_streams(device, n, priority=0):
     out = []
     idx = torch.device(device).index
     idx = torch.cuda.current_device() if idx is None else idx
-    parked = _PARKED.get((idx, int(priority)), [])
-    while parked and len(out) < n:
-        st = parked.pop()
-        st._lcr_parked = False
-        out.append(st)
+    with _PARK_LOCK:
+        parked = _PARKED.get((idx, int(priority)), [])
+        while parked and len(out) < n:
+            st = parked.pop()
+            st._lcr_parked = False
+            out.append(st)
     with torch.cuda.device(device):
         for _ in range(n - len(out)):
             h = ctypes.c_void_p()
