@@ -17,7 +17,7 @@ from conftest import LIMITS, NUM_STAGES, RADIUS, VOXEL, load_scan
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CANDIDATES = [os.environ.get("LCR_WEIGHTS", ""), os.path.join(ROOT, "weights", "best-model-mixed.tar"), "/root/reference/weights/best-model-mixed.tar"]
+CANDIDATES = [os.environ.get("LCR_WEIGHTS", ""), os.path.join(ROOT, "weights", "best-model-mixed.tar")]
 README_L2 = 0.809192
 README_T = np.array([[3.8640183e-01, -9.2232913e-01, -1.6882520e-03, -5.1863933e+00],
                      [9.2216253e-01, 3.8629568e-01, 1.9789029e-02, 5.1413069e+00],
