@@ -331,7 +331,7 @@ def main():
         if os.path.exists(PMC_JSON):
             pmc = json.load(open(PMC_JSON))
             traffic = pmc.get("k_gemm_f32", {}).get("traffic_bytes")
-            traffic_rs = pmc.get("k_radius_query", {}).get("traffic_bytes")
+            traffic_rs = (pmc.get("k_radius_query_multi") or pmc.get("k_radius_query") or {}).get("traffic_bytes")
             traffic_src = "profiles/pmc_traffic.json: separate rocprofv3 --pmc passes of this command (2*FETCH_SIZE + WRITE_SIZE per launch), not measured in this run"
         roof = {"bound": "mfma", "kernel": "lcr::k_gemm_f32 (fp32 MFMA, %d launches/step)" % (len(gem) // max(args.steps, 1)),
                 "achieved": round(flops / t_gemm / 1e12, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -341,12 +341,13 @@ def main():
                 "gflop_per_launch": round(flops / max(len(gem), 1) / 1e9, 3),
                 "event_time_over_step_time": {"gemm": round(t_gemm / dt, 3), "kpconv_aggregate": round(t_agg / dt, 3), "radius_query": round(t_rs / dt, 3),
                                               "note": "sum of launch-to-completion event times / wall time; streams overlap, so the shares do not add up to 1"},
-                "neighbor": {"kernel": "lcr::k_radius_query (%d searches/step)" % n_search, "bound": "hbm",
+                "neighbor": {"kernel": "lcr::k_radius_query[_multi] (%d searches in %d launch(es) per step)" % (n_search, max(1, round(len(rsq) / max(args.steps, 1)))),
+                             "bound": "hbm",
                              "algorithmic_mb_per_step": round(bytes_rs / 1e6, 2),
                              "achieved": round(bytes_rs * args.steps / t_rs / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(bytes_rs * args.steps / t_rs / 1e9 / HBM_PEAK_GBS, 4),
                              "ms_per_step": round(t_rs / args.steps * 1e3, 4),
-                             "algorithmic_bytes_per_launch": round(bytes_rs / n_search), "traffic": traffic_rs,
+                             "algorithmic_bytes_per_launch": round(bytes_rs * args.steps / max(len(rsq), 1)), "traffic": traffic_rs,
                              "achieved_alone": round(search_bytes(stage_points, not args.no_upsampling) / iso_rs / 1e9, 1),
                              "frac_alone": round(search_bytes(stage_points, not args.no_upsampling) / iso_rs / 1e9 / HBM_PEAK_GBS, 4),
                              "ms_per_step_alone": round(iso_rs * 1e3, 4)},

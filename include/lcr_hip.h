@@ -93,6 +93,21 @@ int lcr_radius_query(const float* q, const int64_t* qlen, int B, int64_t nq_cap,
 int lcr_radius_query_ordered(const float* q, const int64_t* qlen, int B, int64_t nq_cap,
                              const void* grid_ws, int64_t ns_cap, float radius, int limit,
                              int64_t* out_idx64, int32_t* out_idx32, int32_t* out_cnt, const int32_t* q_order, void* stream);
+/* Several searches (<= 12) of one collate in ONE launch: the ten searches of precompute_data_stack_mode (data.py:28-66) run against
+ * four grids; alone, the coarse-stage ones are a handful of workgroups on the launch floor.  int32 rows only (limit >= 1), same
+ * rows as lcr_radius_query_ordered search by search.  All searches share the cloud count B. */
+typedef struct LcrRadiusQuery {
+    const float*   q;          /* [nq_cap,3] */
+    const int64_t* qlen;       /* [B] device */
+    int64_t        nq_cap;
+    const void*    grid_ws;    /* a built support grid */
+    int64_t        ns_cap;     /* as passed to its build */
+    float          radius;
+    int            limit;
+    int32_t*       out_idx32;  /* [nq_cap, limit] */
+    const int32_t* q_order;    /* processing order or NULL */
+} LcrRadiusQuery;
+int lcr_radius_query_multi(const LcrRadiusQuery* list, int n, int B, void* stream);
 /* Same build that also writes the cell-sorted processing order (what lcr_support_grid_order returns) into order i32[ns_cap]. */
 int lcr_support_grid_build_ex(const float* s, const int64_t* slen, int B, int64_t ns_cap, float radius,
                               uint32_t* status, void* grid_ws, size_t grid_ws_bytes, int32_t* order, void* stream);

@@ -232,6 +232,17 @@ extern "C" int lcr_precompute_batch(const float* points0, const int64_t* lengths
   }
   float v = voxel_size, r = radius;
   float radii[LCR_MAX_STAGES];
+  // Default: the searches are collected and issued as ONE launch after the last grid is built (lcr_radius_query_multi: the small
+  // coarse-stage searches ride in the tail of the large ones).  LCR_PRE_FORK=1 / LCR_PRE_SPLIT_SEARCHES=1: one launch per search.
+  static const bool split_searches = getenv("LCR_PRE_FORK") != nullptr || getenv("LCR_PRE_SPLIT_SEARCHES") != nullptr;
+  LcrRadiusQuery searches[3 * LCR_MAX_STAGES];
+  int n_search = 0;
+  auto search = [&](const float* q, const int64_t* ql, int64_t nq_cap, void* gws, int64_t ns_cap, float rad, int limit, int32_t* out,
+                    const int32_t* order, hipStream_t s) -> int {
+    if (split_searches) return TURN(lcr_radius_query_ordered(q, ql, B, nq_cap, gws, ns_cap, rad, limit, nullptr, out, nullptr, order, s));
+    searches[n_search++] = LcrRadiusQuery{q, ql, nq_cap, gws, ns_cap, rad, limit, out, order};
+    return LCR_OK;
+  };
   for (int i = 0; i < S; ++i) {
     if (i > 0) {
       v *= 2.f;
@@ -250,22 +261,25 @@ extern "C" int lcr_precompute_batch(const float* points0, const int64_t* lengths
     rc = TURN(lcr_support_grid_build_ex(pts[i], lens[i], B, L->cap[i], r, W.status, W.grid_ws[i], W.grid_bytes[i], i32(L->off_order[i]), s));
     if (rc) return rc;
     // every search walks its queries in the QUERY set's own cell order (written by that stage's grid build, earlier in the chain)
-    rc = TURN(lcr_radius_query_ordered(pts[i], lens[i], B, L->cap[i], W.grid_ws[i], L->cap[i], r, L->limits[i], nullptr,
-                                       i32(L->off_neighbors[i]), nullptr, i32(L->off_order[i]), s));
+    rc = search(pts[i], lens[i], L->cap[i], W.grid_ws[i], L->cap[i], r, L->limits[i], i32(L->off_neighbors[i]), i32(L->off_order[i]), s);
     if (rc) return rc;
     if (i > 0 && L->upsampling) {
-      rc = TURN(lcr_radius_query_ordered(pts[i - 1], lens[i - 1], B, L->cap[i - 1], W.grid_ws[i], L->cap[i], r, L->limits[i], nullptr,
-                                         i32(L->off_upsampling[i - 1]), nullptr, i32(L->off_order[i - 1]), s));
+      rc = search(pts[i - 1], lens[i - 1], L->cap[i - 1], W.grid_ws[i], L->cap[i], r, L->limits[i], i32(L->off_upsampling[i - 1]),
+                  i32(L->off_order[i - 1]), s);
       if (rc) return rc;
     }
     if (i > 0) {
       hipStream_t sp = no_fork ? main : C.side[i - 1];
       if (!no_fork) hipStreamWaitEvent(sp, C.ready[i], 0);
-      rc = TURN(lcr_radius_query_ordered(pts[i], lens[i], B, L->cap[i], W.grid_ws[i - 1], L->cap[i - 1], radii[i - 1], L->limits[i - 1],
-                                         nullptr, i32(L->off_subsampling[i - 1]), nullptr, no_fork ? i32(L->off_order[i]) : nullptr, sp));   // forked: order[i] is written on another stream
+      rc = search(pts[i], lens[i], L->cap[i], W.grid_ws[i - 1], L->cap[i - 1], radii[i - 1], L->limits[i - 1], i32(L->off_subsampling[i - 1]),
+                  no_fork ? i32(L->off_order[i]) : nullptr, sp);   // forked: order[i] is written on another stream
       if (rc) return rc;
     }
     r *= 2.f;
+  }
+  if (n_search > 0) {
+    rc = TURN(lcr_radius_query_multi(searches, n_search, B, main));
+    if (rc) return rc;
   }
   for (int i = 0; i < S && getenv("LCR_PRE_FORK"); ++i) {
     hipEventRecord(C.done[i], C.side[i]);

@@ -271,36 +271,57 @@ __device__ __forceinline__ void rq_chunks(const RqRuns R, const float4* __restri
   }
 }
 
-template <bool HAS64, bool HAS32>
-__global__ __launch_bounds__(RS_WAVES * 64) void k_radius_query(const float* __restrict__ q, const int64_t* __restrict__ qlen, int B,
-                                                                  int64_t nq_cap, const GridHeader* __restrict__ h,
-                                                                  const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
-                                                                  float r2, int limit, int64_t* __restrict__ out64,
-                                                                  int32_t* __restrict__ out32, int32_t* __restrict__ out_cnt,
-                                                                  const int32_t* __restrict__ q_order, int qb) {
-  __shared__ __attribute__((aligned(16))) uint64_t s_keys[RS_WAVES][RQ_CAP];
-  __shared__ uint16_t s_perm[RS_WAVES][RQ_CAP];             // bin-ordered position -> slot in s_keys
-  __shared__ int s_cnt[RS_WAVES][RQ_BINS];
-  __shared__ int s_fill[RS_WAVES][RQ_BINS];
-  __shared__ int s_base[RS_WAVES][RQ_BINS + 1];
-  __shared__ int64_t s_qoff[GRID_MAX_B + 1];
+// One search: queries, the support grid it runs against, outputs.  Passed by value (single-search kernel) or as a list (multi).
+struct RqSearch {
+  const float*      q;
+  const int64_t*    qlen;
+  int64_t           nq_cap;
+  const GridHeader* h;
+  const int32_t*    cell_start;
+  const float4*     sorted;
+  float             r2;
+  int               limit;
+  int64_t*          out64;
+  int32_t*          out32;
+  int32_t*          out_cnt;
+  const int32_t*    q_order;
+  int               qb;        // queries set up per wavefront turn (1, 2 or 4)
+};
 
+// exclusive prefix of a search's query lengths into LDS (one wavefront)
+// (32-bit: a search has fewer than 2^31 queries, checked on the host; lengths beyond that saturate)
+__device__ __forceinline__ void rq_offsets(const int64_t* __restrict__ qlen, int B, int32_t* s_qoff) {
+  const int lane = threadIdx.x & 63;
+  const int64_t l64 = lane < B ? qlen[lane] : 0;
+  const int len_b = static_cast<int>(l64 < 0 ? 0 : (l64 > 0x3fffffff ? 0x3fffffff : l64));
+  const int inc = wave_incl_scan(len_b);
+  if (lane < B) s_qoff[lane] = inc - len_b;
+  if (lane == B - 1) s_qoff[B] = inc;
+}
+__device__ __forceinline__ int rq_cloud_of(const int32_t* off, int B, int i) {
+  int b = 0;
+  while (b + 1 < B && i >= off[b + 1]) ++b;
+  return b;
+}
+
+// this wavefront's share of one search (see the file header); wave-private LDS: keys, perm, cnt (all zero on entry and exit), fill, base
+template <bool HAS64, bool HAS32>
+__device__ __forceinline__ void rq_search(const RqSearch& A, int B, const int32_t* s_qoff, uint64_t* keys, uint16_t* perm, int* cnt, int* fill,
+                                          int* base) {
+  const float* __restrict__ q = A.q;
+  const GridHeader* __restrict__ h = A.h;
+  const int32_t* __restrict__ cell_start = A.cell_start;
+  const float4* __restrict__ sorted = A.sorted;
+  const int32_t* __restrict__ q_order = A.q_order;
+  int64_t* __restrict__ out64 = A.out64;
+  int32_t* __restrict__ out32 = A.out32;
+  int32_t* __restrict__ out_cnt = A.out_cnt;
+  const float r2 = A.r2;
+  const int limit = A.limit, qb = A.qb;
+  const int64_t nq_cap = A.nq_cap;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (threadIdx.x < 64) {
-    const int64_t len_b = threadIdx.x < B ? qlen[threadIdx.x] : 0;
-    const int64_t inc = wave_incl_scan(len_b);
-    if (threadIdx.x < B) s_qoff[threadIdx.x] = inc - len_b;
-    if (threadIdx.x == B - 1) s_qoff[B] = inc;
-  }
-  s_cnt[w][lane] = 0;
-  __syncthreads();
-  const int64_t nq = min(s_qoff[B], nq_cap);
+  const int64_t nq = min(static_cast<int64_t>(s_qoff[B]), nq_cap);
   const int64_t ns_total = h->ns_total;
-  uint64_t* keys = s_keys[w];
-  uint16_t* perm = s_perm[w];
-  int* cnt = s_cnt[w];
-  int* fill = s_fill[w];
-  int* base = s_base[w];
   const float bin_scale = fdiv(static_cast<float>(RQ_BINS), r2);
 
   // every XCD walks a contiguous eighth of the processing order; inside it a wavefront takes `qb` (1, 2 or 4) CONSECUTIVE queries per
@@ -321,9 +342,9 @@ __global__ __launch_bounds__(RS_WAVES * 64) void k_radius_query(const float* __r
     const int64_t t_me = t_blk + (mine ? row : 0);
     const int64_t qi_me = q_order ? static_cast<int64_t>(q_order[t_me]) : t_me;
     if (qi_me < off_b || qi_me >= off_b1) {      // rare in cell order (a turn seldom straddles two clouds)
-      b = cloud_of(s_qoff, B, qi_me);
-      off_b = static_cast<int>(s_qoff[b]);
-      off_b1 = static_cast<int>(s_qoff[b + 1]);
+      b = rq_cloud_of(s_qoff, B, static_cast<int>(qi_me));
+      off_b = s_qoff[b];
+      off_b1 = s_qoff[b + 1];
     }
     const GridCloud& c = h->cloud[b];
     const float mx = q[3 * qi_me + 0], my = q[3 * qi_me + 1], mz = q[3 * qi_me + 2];
@@ -486,6 +507,43 @@ __global__ __launch_bounds__(RS_WAVES * 64) void k_radius_query(const float* __r
   }
 }
 
+template <bool HAS64, bool HAS32>
+__global__ __launch_bounds__(RS_WAVES * 64) void k_radius_query(RqSearch A, int B) {
+  __shared__ __attribute__((aligned(16))) uint64_t s_keys[RS_WAVES][RQ_CAP];
+  __shared__ uint16_t s_perm[RS_WAVES][RQ_CAP];             // bin-ordered position -> slot in s_keys
+  __shared__ int s_cnt[RS_WAVES][RQ_BINS];
+  __shared__ int s_fill[RS_WAVES][RQ_BINS];
+  __shared__ int s_base[RS_WAVES][RQ_BINS + 1];
+  __shared__ int32_t s_qoff[GRID_MAX_B + 1];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (threadIdx.x < 64) rq_offsets(A.qlen, B, s_qoff);
+  s_cnt[w][lane] = 0;
+  __syncthreads();
+  rq_search<HAS64, HAS32>(A, B, s_qoff, s_keys[w], s_perm[w], s_cnt[w], s_fill[w], s_base[w]);
+}
+
+// All searches of a collate in ONE launch (int32 rows): every wavefront works through its share of search 0, then of search 1, ...
+// without a barrier in between, so the small coarse-stage searches — alone they sit on the ~10 us launch floor with a handful of
+// workgroups — ride in the tail of the large ones.
+constexpr int RQ_MAX_SEARCHES = 12;
+struct RqMulti {
+  int      n, B;
+  RqSearch s[RQ_MAX_SEARCHES];
+};
+__global__ __launch_bounds__(RS_WAVES * 64) void k_radius_query_multi(RqMulti m) {
+  __shared__ __attribute__((aligned(16))) uint64_t s_keys[RS_WAVES][RQ_CAP];
+  __shared__ uint16_t s_perm[RS_WAVES][RQ_CAP];
+  __shared__ int s_cnt[RS_WAVES][RQ_BINS];
+  __shared__ int s_fill[RS_WAVES][RQ_BINS];
+  __shared__ int s_base[RS_WAVES][RQ_BINS + 1];
+  __shared__ int32_t s_qoff[RQ_MAX_SEARCHES][GRID_MAX_B + 1];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int i = w; i < m.n; i += RS_WAVES) rq_offsets(m.s[i].qlen, m.B, s_qoff[i]);
+  s_cnt[w][lane] = 0;
+  __syncthreads();
+  for (int i = 0; i < m.n; ++i) rq_search<false, true>(m.s[i], m.B, s_qoff[i], s_keys[w], s_perm[w], s_cnt[w], s_fill[w], s_base[w]);
+}
+
 }  // namespace lcr
 
 using namespace lcr;
@@ -537,6 +595,39 @@ extern "C" int lcr_radius_query(const float* q, const int64_t* qlen, int B, int6
   return lcr_radius_query_ordered(q, qlen, B, nq_cap, grid_ws, ns_cap, radius, limit, out_idx64, out_idx32, out_cnt, nullptr, stream);
 }
 
+// residency of the query kernels (workgroups per CU the grids are sized for) and the CU count, once per process
+static int rq_wg_per_cu() {
+  // One resident generation of workgroups, each with an equal share of the queries: with more workgroups than fit, the last
+  // generation runs on a part-empty chip (2048 workgroups on 6-per-CU residency: 2 of 8 ran alone, measured 3.3 wavefronts per
+  // SIMD on average instead of 6).  Residency from the kernel's register count (the occupancy API is one workgroup per CU high
+  // for kernels with 97-112 SGPRs on this stack, MI355X_MICROARCH.md).
+  static const int v = []() {
+    if (getenv("LCR_RS_WG_PER_CU")) return atoi(getenv("LCR_RS_WG_PER_CU"));
+    hipFuncAttributes fa;
+    int api = 0;
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_radius_query<false, true>)) != hipSuccess) return 4;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, reinterpret_cast<const void*>(&k_radius_query<false, true>), RS_WAVES * 64, 0);
+    const int by_vgpr = 512 / ((fa.numRegs + 7) / 8 * 8);
+    return max(1, min(min(api > 0 ? api : 8, by_vgpr), 6));
+  }();
+  return v;
+}
+static int rq_n_cu() {
+  static const int v = []() {
+    int dev = 0, n = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n;
+  }();
+  return v;
+}
+// queries per wavefront turn: four (one per DPP row) when the search is large enough to fill the chip anyway, fewer for the small
+// coarse-stage searches, which are latency-bound and want as many wavefronts as they have queries
+static int rq_qb(int64_t nq_cap) {
+  static const int qb_env = getenv("LCR_RS_QB") ? atoi(getenv("LCR_RS_QB")) : 0;
+  return qb_env ? qb_env : (nq_cap >= 65536 ? 4 : (nq_cap >= 16384 ? 2 : 1));
+}
+
 extern "C" int lcr_radius_query_ordered(const float* q, const int64_t* qlen, int B, int64_t nq_cap, const void* grid_ws, int64_t ns_cap,
                                         float radius, int limit, int64_t* out_idx64, int32_t* out_idx32, int32_t* out_cnt,
                                         const int32_t* q_order, void* stream) {
@@ -561,46 +652,53 @@ extern "C" int lcr_radius_query_ordered(const float* q, const int64_t* qlen, int
   if (no_order) q_order = nullptr;
   GridLayout L = grid_layout(const_cast<void*>(grid_ws), ns_cap, B);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const float r2 = radius * radius;   // fp32 product, as radius_neighbors_cpu.cpp:12
+  RqSearch A;
+  A.q = q, A.qlen = qlen, A.nq_cap = nq_cap, A.h = L.hdr, A.cell_start = L.cell_start, A.sorted = L.sorted;
+  A.r2 = radius * radius;   // fp32 product, as radius_neighbors_cpu.cpp:12
+  A.limit = limit, A.out64 = out_idx64, A.out32 = out_idx32, A.out_cnt = out_cnt, A.q_order = q_order, A.qb = rq_qb(nq_cap);
   const dim3 block(RS_WAVES * 64);
   KernelTimerScope timed(KT_RADIUS, st, nq_cap, ns_cap, limit, out_idx64 ? 8 : 4, B);
-  {
-    // queries per wavefront turn: four (one per DPP row) when the search is large enough to fill the chip anyway, fewer for the
-    // small coarse-stage searches, which are latency-bound and want as many wavefronts as they have queries
-    static const int qb_env = getenv("LCR_RS_QB") ? atoi(getenv("LCR_RS_QB")) : 0;
-    const int qb = qb_env ? qb_env : (nq_cap >= 65536 ? 4 : (nq_cap >= 16384 ? 2 : 1));
-    // One resident generation of workgroups, each with an equal share of the queries: with more workgroups than fit, the last
-    // generation runs on a part-empty chip (2048 workgroups on 6-per-CU residency: 2 of 8 ran alone, measured 3.3 wavefronts per
-    // SIMD on average instead of 6).  Residency from the kernel's register count (the occupancy API is one workgroup per CU high
-    // for kernels with 97-112 SGPRs on this stack, MI355X_MICROARCH.md).
-    static const int wg_per_cu = []() {
-      if (getenv("LCR_RS_WG_PER_CU")) return atoi(getenv("LCR_RS_WG_PER_CU"));
-      hipFuncAttributes fa;
-      int api = 0;
-      if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_radius_query<false, true>)) != hipSuccess) return 4;
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, reinterpret_cast<const void*>(&k_radius_query<false, true>), RS_WAVES * 64, 0);
-      const int by_vgpr = 512 / ((fa.numRegs + 7) / 8 * 8);
-      return max(1, min(min(api > 0 ? api : 8, by_vgpr), 6));
-    }();
-    static const int n_cu = []() {
-      int dev = 0, n = 256;
-      (void)hipGetDevice(&dev);
-      (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-      return n;
-    }();
-    const int nblk2 = (min(div_up(nq_cap, RS_WAVES * qb), getenv("LCR_RS_NBLK") ? atoi(getenv("LCR_RS_NBLK")) : n_cu * wg_per_cu) + 7) / 8 * 8;
-    const dim3 grid2(nblk2);
-    if (out_idx64 && out_idx32)
-      hipLaunchKernelGGL((k_radius_query<true, true>), grid2, block, 0, st, q, qlen, B, nq_cap, L.hdr, L.cell_start, L.sorted, r2, limit,
-                         out_idx64, out_idx32, out_cnt, q_order, qb);
-    else if (out_idx64)
-      hipLaunchKernelGGL((k_radius_query<true, false>), grid2, block, 0, st, q, qlen, B, nq_cap, L.hdr, L.cell_start, L.sorted, r2, limit,
-                         out_idx64, out_idx32, out_cnt, q_order, qb);
-    else
-      hipLaunchKernelGGL((k_radius_query<false, true>), grid2, block, 0, st, q, qlen, B, nq_cap, L.hdr, L.cell_start, L.sorted, r2, limit,
-                         out_idx64, out_idx32, out_cnt, q_order, qb);
-    return check_launch("lcr_radius_query");
+  const int nblk = (min(div_up(nq_cap, RS_WAVES * A.qb), getenv("LCR_RS_NBLK") ? atoi(getenv("LCR_RS_NBLK")) : rq_n_cu() * rq_wg_per_cu()) + 7) / 8 * 8;
+  const dim3 grid(nblk);
+  if (out_idx64 && out_idx32) hipLaunchKernelGGL((k_radius_query<true, true>), grid, block, 0, st, A, B);
+  else if (out_idx64) hipLaunchKernelGGL((k_radius_query<true, false>), grid, block, 0, st, A, B);
+  else hipLaunchKernelGGL((k_radius_query<false, true>), grid, block, 0, st, A, B);
+  return check_launch("lcr_radius_query");
+}
+
+extern "C" int lcr_radius_query_multi(const LcrRadiusQuery* list, int n, int B, void* stream) {
+  if (!list || n < 1 || n > RQ_MAX_SEARCHES || B < 1 || B > GRID_MAX_B) {
+    set_error("lcr_radius_query_multi: bad argument (1 <= n <= %d searches)", RQ_MAX_SEARCHES);
+    return LCR_EARG;
   }
+  static const bool no_order = getenv("LCR_RS_NO_ORDER") != nullptr;
+  RqMulti m;
+  m.n = 0, m.B = B;
+  int64_t turns = 0, nq_sum = 0;
+  for (int i = 0; i < n; ++i) {
+    const LcrRadiusQuery& e = list[i];
+    if (!e.qlen || !e.grid_ws || !e.out_idx32 || e.nq_cap < 0 || e.ns_cap < 0 || e.limit < 1 || !(e.radius > 0.f) ||
+        e.nq_cap > (int64_t(1) << 31) - 1) {
+      set_error("lcr_radius_query_multi: bad search %d", i);
+      return LCR_EARG;
+    }
+    if (e.nq_cap == 0) continue;
+    GridLayout L = grid_layout(const_cast<void*>(e.grid_ws), e.ns_cap, B);
+    RqSearch& A = m.s[m.n++];
+    A.q = e.q, A.qlen = e.qlen, A.nq_cap = e.nq_cap, A.h = L.hdr, A.cell_start = L.cell_start, A.sorted = L.sorted;
+    A.r2 = e.radius * e.radius;
+    A.limit = e.limit, A.out64 = nullptr, A.out32 = e.out_idx32, A.out_cnt = nullptr, A.q_order = no_order ? nullptr : e.q_order;
+    A.qb = rq_qb(e.nq_cap);
+    turns += div_up(e.nq_cap, RS_WAVES * A.qb);
+    nq_sum += e.nq_cap;
+  }
+  if (m.n == 0) return LCR_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  KernelTimerScope timed(KT_RADIUS, st, nq_sum, 0, 0, 4, B);
+  const int64_t cap = static_cast<int64_t>(rq_n_cu()) * rq_wg_per_cu();
+  const int nblk = static_cast<int>(((turns < cap ? turns : cap) + 7) / 8 * 8);
+  hipLaunchKernelGGL(k_radius_query_multi, dim3(nblk), dim3(RS_WAVES * 64), 0, st, m);
+  return check_launch("lcr_radius_query_multi");
 }
 
 // order[i] = stacked row index of the i-th support in cell-sorted order: a spatially coherent processing order for any kernel

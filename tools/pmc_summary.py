@@ -25,7 +25,7 @@ def load(path, name):
 
 
 def family(k):
-    for f in ("k_gemm_f32", "k_kpconv_aggregate", "k_radius_query", "k_gn_apply", "k_maxpool"):
+    for f in ("k_gemm_f32", "k_kpconv_aggregate", "k_radius_query_multi", "k_radius_query", "k_gn_apply", "k_maxpool"):
         if f in k:
             return f
     return k.split("(")[0].replace("void ", "")
