@@ -358,15 +358,19 @@ def voxelize_raw_scans(points, lengths, voxel_size, key_bits_hint=32):
 
 
 def calibrate_neighbors_stack_mode(clouds, num_stages, voxel_size, search_radius, keep_ratio=0.8, sample_threshold=2000):
-    """Neighbour-limit calibration of data.py:408-433 from device-side counts: `clouds` is an iterable of f32[N,3] device
-    tensors (one stack each; the reference feeds dataset items through the collate with limit = hist_n).  Only per-row
-    in-radius counts are needed, so the searches run in count-only mode."""
+    """Neighbour-limit calibration of data.py:408-433 from device-side counts: `clouds` is an iterable of dataset items, each either
+    an f32[N,3] device tensor (a single cloud) or a `(points, lengths)` pair (a stack of clouds, e.g. a registration pair
+    [ref, src] — the reference feeds dataset items through the collate with limit = hist_n, and the histogram is checked against
+    `sample_threshold` after every ITEM).  Only per-row in-radius counts are needed: count-only searches."""
     import numpy as np
     from .modules.ops import grid_subsample, radius_count
     hist_n = int(np.ceil(4 / 3 * np.pi * (search_radius / voxel_size + 1) ** 3))
     hists = np.zeros((num_stages, hist_n), dtype=np.int64)
-    for pts in clouds:
-        lens = torch.tensor([pts.shape[0]], dtype=torch.int64, device=pts.device)
+    for item in clouds:
+        if isinstance(item, (tuple, list)):
+            pts, lens = item[0], item[1].to(item[0].device)
+        else:
+            pts, lens = item, torch.tensor([item.shape[0]], dtype=torch.int64, device=item.device)
         v, r = voxel_size, search_radius
         for i in range(num_stages):
             if i > 0:

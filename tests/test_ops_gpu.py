@@ -133,6 +133,8 @@ def test_neighbor_limit_calibration_matches_reference_demo_values():
     clouds = [dev(load_scan("003854")), dev(load_scan("000958"))]
     limits = calibrate_neighbors_stack_mode(clouds, NUM_STAGES, VOXEL, RADIUS)
     assert limits.tolist() == LIMITS
+    pair = (torch.cat(clouds), torch.tensor([len(c) for c in clouds], dtype=torch.int64, device="cuda"))
+    assert calibrate_neighbors_stack_mode([pair], NUM_STAGES, VOXEL, RADIUS).tolist() == LIMITS      # the demo's item: the stacked pair
 
 
 def test_key_bits_promise_broken_then_retried():
