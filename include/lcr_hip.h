@@ -165,6 +165,14 @@ int lcr_precompute_batch(const float* points0, const int64_t* lengths0, const Lc
 int lcr_gemm_f32(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB,
                  const float* bias, const float* rowdiv, const int64_t* seg_len, int S, int groups, double* stats,
                  void* stream);
+/* C = LeakyReLU(GroupNorm(A)) · B^T (+ bias, + statistics of C as above), A being the RAW [M,K] output of the layer whose sums are
+ * a_stats[LCR_GN_REPLICAS,S,a_groups,2]: the normalisation happens while A's tiles are staged, the normalised tensor never
+ * exists in memory.  Replaces norm_conv + leaky_relu + unary2.mlp of ResidualBlock.forward (modules/kpconv/modules.py:215-217).
+ * Needs B stored [N,K] (nn.Linear weight), 32 < N, K <= 256, K % 4 == 0, a segment table (S >= 1) whose segments all hold >= 64
+ * rows (the caller's guarantee: a 64-row block then touches at most two segments).  LCR_EARG outside that form. */
+int lcr_gemm_f32_anorm(const float* A, const float* B, float* C, int64_t M, int N, int K, const float* bias,
+                       const double* a_stats, const float* a_gamma, const float* a_beta, int a_groups, float a_eps,
+                       float a_slope, const int64_t* seg_len, int S, int groups, double* stats, void* stream);
 /* Tuning hook for tools/gemm_bench.py: 0 = heuristic tile choice, 1..5 = force 128x128 / 128x64 / 128x32 / 64x64 / 64x128. */
 void lcr_gemm_debug_force_tile(int tile);
 /* K-deep problems (A [M,K] x B [K,N], K >= 480) whose 64x64 tiles do not divide evenly over the CUs can run as stream-K:
@@ -183,6 +191,15 @@ int lcr_kpconv_aggregate(const float* s_feats, const uint8_t* s_pos, const float
                          const void* idx, int idx_is_64, int64_t M, int64_t Ns, int H, int C,
                          const float* kernel_points_host, float sigma, float* A, float* nn,
                          const int32_t* order /* optional i32[M]: processing order, e.g. lcr_support_grid_order */, void* stream);
+/* Whole KPConv (kpconv.py:79-122) for C_in = C_out = 32 — the two widest query sets of the encoder — in one launch: the
+ * aggregate above lives only as 16-query tiles in LDS and is contracted there with W [15*32, 32] (split-K over the wavefronts,
+ * weights in registers); out[M,32] = contraction / neighbour count + bias, plus the GroupNorm sums of `out` ADDED to
+ * stats[LCR_GN_REPLICAS,S,groups,2] (optional; S <= 64).  Same results as lcr_kpconv_aggregate + lcr_gemm_f32 up to fp32
+ * summation order. */
+int lcr_kpconv_fused(const float* s_feats, const uint8_t* s_pos, const float* q_pts, const float* s_pts, const void* idx,
+                     int idx_is_64, int64_t M, int64_t Ns, int H, int C, const float* kernel_points_host, float sigma,
+                     const float* W, const float* bias, float* out, const int64_t* seg_len, int S, int groups, double* stats,
+                     const int32_t* order, void* stream);
 /* Whole KPConv for C_in = 1 (encoder1_1, backbone4.py:15): out[M,Cout] incl. count normalisation and bias. W: [15,Cout]. */
 int lcr_kpconv_cin1(const float* s_feats, const float* q_pts, const float* s_pts, const void* idx, int idx_is_64,
                     int64_t M, int64_t Ns, int H, const float* kernel_points_host, float sigma, const float* W,
@@ -209,6 +226,8 @@ int lcr_groupnorm_apply(const float* x, const double* stats, const float* gamma,
  * float[15*3] arrays.  A NULL `w` in a unary block means nn.Identity (modules.py:171,176).
  *   points[4] f32[n_i,3]; neighbors[4] i32[n_i, limits[i]]; subsampling[3] i32[n_{i+1}, limits[i]]; order[4] i32[n_i] or NULL;
  *   seg_len[4] i64[S] GroupNorm segments per stage (device); n_host[4], limits[4] on the host; feats0 f32[n_0] (C_in = 1);
+ *   seg_min_rows_host[4] (or NULL): rows of the shortest segment per stage as the host knows them, 0 = unknown — with >= 64
+ *   the in-block norm_conv pass is folded into unary2's GEMM (lcr_gemm_f32_anorm), otherwise it is a launch of its own;
  *   out_feats[4]: f32[n_0,2d], [n_1,4d], [n_2,8d], [n_3,16d] (d = init_dim) — the four stage outputs (feats_list).
  * ------------------------------------------------------------------------------------------------ */
 #define LCR_ENC_BLOCKS 10
@@ -235,7 +254,8 @@ typedef struct LcrEncoderW {
 int lcr_encoder_ws_bytes(const LcrEncoderW* W, const int64_t* n_host, int S, size_t* bytes);
 int lcr_encoder_forward(const LcrEncoderW* W, const float* feats0, const float* const* points, const int32_t* const* neighbors,
                         const int32_t* const* subsampling, const int32_t* const* order, const int64_t* const* seg_len, int S,
-                        const int64_t* n_host, const int* limits, float* const* out_feats, void* ws, size_t ws_bytes, void* stream);
+                        const int64_t* n_host, const int64_t* seg_min_rows_host, const int* limits, float* const* out_feats, void* ws,
+                        size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a-7  global descriptor head: F.normalize -> NetVLADLoupe2 -> GatingContext -> F.normalize

@@ -36,11 +36,15 @@ _SIGS = {
     "lcr_grid_subsample_ex": (c_int, [c_vp, c_vp, c_int, c_i64, c_float, c_int, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "lcr_hashmap_order_host": (c_int, [c_vp, c_i64, c_vp]),
     "lcr_gemm_f32": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
+    "lcr_gemm_f32_anorm": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_float, c_float, c_vp, c_int,
+                                   c_int, c_vp, c_vp]),
     "lcr_ktimer_enable": (None, [c_int]),
     "lcr_ktimer_read": (c_int, [c_int, c_int, c_vp, c_vp]),
     "lcr_encoder_ws_bytes": (c_int, [c_vp, c_vp, c_int, c_size_p]),
-    "lcr_encoder_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_size_t, c_vp]),
+    "lcr_encoder_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_size_t, c_vp]),
     "lcr_kpconv_aggregate": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_int, c_vp, c_float, c_vp, c_vp, c_vp, c_vp]),
+    "lcr_kpconv_fused": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_int, c_vp, c_float, c_vp, c_vp, c_vp, c_vp, c_int,
+                                 c_int, c_vp, c_vp, c_vp]),
     "lcr_kpconv_cin1": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_vp, c_float, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "lcr_maxpool": (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
     "lcr_support_grid_order": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),

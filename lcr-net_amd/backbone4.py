@@ -8,6 +8,23 @@ from . import native_encoder
 from .modules.kpconv import ConvBlock, ResidualBlock, StageContext
 
 
+def segment_min_rows(data_dict, stages=4):
+    """Rows of the shortest GroupNorm segment per stage, from HOST data only (None = unknown): the segments are the clouds of
+    'lengths_host' or equal-sized groups of consecutive clouds (the two clouds of a registration pair)."""
+    seg, host = data_dict.get("segment_lengths"), data_dict.get("lengths_host")
+    if seg is None or host is None:
+        return [None] * stages
+    rows = []
+    for i in range(stages):
+        n_seg, clouds = int(seg[i].numel()), [int(v) for v in host[i]]
+        if n_seg == 0 or len(clouds) % n_seg:
+            rows.append(None)
+            continue
+        per = len(clouds) // n_seg
+        rows.append(min(sum(clouds[k:k + per]) for k in range(0, len(clouds), per)))
+    return rows
+
+
 class KPEncoder(nn.Module):
     def __init__(self, input_dim, init_dim, kernel_size, init_radius, init_sigma, group_norm):
         super().__init__()
@@ -37,7 +54,8 @@ class KPEncoder(nn.Module):
         if self.native or os.environ.get("LCR_NATIVE_ENCODER"):
             if native_encoder.eligible(feats, data_dict):
                 return native_encoder.forward(self, feats, data_dict)
-        ctx = [StageContext(None if seg is None else seg[i], None if order is None else order[i]) for i in range(4)]
+        rows = segment_min_rows(data_dict)
+        ctx = [StageContext(None if seg is None else seg[i], None if order is None else order[i], rows[i]) for i in range(4)]
         with F.stats_arena(feats.device):
             return self._forward(feats, P, N, S, ctx)
 

@@ -40,6 +40,7 @@ struct StageIO {
   const int64_t* seg;     // GroupNorm segment lengths of this stage (device)
   const int32_t* order;   // optional processing order
   int64_t        n;
+  int64_t        min_rows;   // rows of the shortest GroupNorm segment (host knowledge; 0 = unknown)
 };
 
 struct StatsPool {
@@ -97,18 +98,35 @@ static int residual_block(const LcrBlockW& b, const float* s_feats, const StageI
   float* kpo = ws.take<float>(static_cast<size_t>(M) * mid);
   double* stc = sp.take();
   if (!A || !nn || !kpo || !stc) return LCR_ESPACE;
-  if ((rc = TURN(lcr_kpconv_aggregate(x, pos, q.pts, sup.pts, idx, 0, M, Ns, H, mid, b.kernel_points_host, b.sigma, A, nn, q.order, s)))) return rc;
-  if ((rc = TURN(lcr_gemm_f32(A, b.kp_w, kpo, M, mid, 15 * mid, 0, 0, b.kp_b, nn, q.seg, sp.S, g, stc, s)))) return rc;
-  // 3. norm_conv + LeakyReLU
-  float* x2 = ws.take<float>(static_cast<size_t>(M) * mid);
-  if (!x2) return LCR_ESPACE;
-  if ((rc = TURN(lcr_groupnorm_apply(kpo, stc, b.normconv_w, b.normconv_b, nullptr, nullptr, nullptr, nullptr, x2, M, mid, g, q.seg, sp.S, ENC_GN_EPS,
-                                ENC_SLOPE, 1, nullptr, s))))
-    return rc;
-  // 4. unary2 (normalised in step 7)
+  static const bool fused32 = getenv("LCR_KPCONV_FUSED") != nullptr;       // opt-in, like KPConv.forward_raw
+  if (fused32 && mid == 32 && sp.S <= 64) {
+    if ((rc = TURN(lcr_kpconv_fused(x, pos, q.pts, sup.pts, idx, 0, M, Ns, H, mid, b.kernel_points_host, b.sigma, b.kp_w, b.kp_b, kpo, q.seg, sp.S, g,
+                                    stc, q.order, s))))
+      return rc;
+  } else {
+    if ((rc = TURN(lcr_kpconv_aggregate(x, pos, q.pts, sup.pts, idx, 0, M, Ns, H, mid, b.kernel_points_host, b.sigma, A, nn, q.order, s)))) return rc;
+    if ((rc = TURN(lcr_gemm_f32(A, b.kp_w, kpo, M, mid, 15 * mid, 0, 0, b.kp_b, nn, q.seg, sp.S, g, stc, s)))) return rc;
+  }
+  // 3. + 4. norm_conv + LeakyReLU + unary2 (normalised in step 7).  With segments of >= 64 rows and the light GEMM form, the
+  // normalisation happens while unary2's GEMM stages its A tiles (lcr_gemm_f32_anorm) — same rule as ResidualBlock.forward.
   float* y;
   double* sty;
-  if ((rc = unary_raw(b.unary2, x2, M, mid, b.cout, q, sp, ws, &y, &sty, s))) return rc;
+  static const bool no_anorm = getenv("LCR_NO_NORM_ON_LOAD") != nullptr;
+  if (!no_anorm && mid <= 256 && mid % 4 == 0 && b.cout > 32 && q.min_rows >= 64) {
+    y = ws.take<float>(static_cast<size_t>(M) * b.cout);
+    sty = sp.take();
+    if (!y || !sty) return LCR_ESPACE;
+    if ((rc = TURN(lcr_gemm_f32_anorm(kpo, b.unary2.w, y, M, b.cout, mid, b.unary2.b, stc, b.normconv_w, b.normconv_b, g, ENC_GN_EPS, ENC_SLOPE,
+                                      q.seg, sp.S, g, sty, s))))
+      return rc;
+  } else {
+    float* x2 = ws.take<float>(static_cast<size_t>(M) * mid);
+    if (!x2) return LCR_ESPACE;
+    if ((rc = TURN(lcr_groupnorm_apply(kpo, stc, b.normconv_w, b.normconv_b, nullptr, nullptr, nullptr, nullptr, x2, M, mid, g, q.seg, sp.S, ENC_GN_EPS,
+                                  ENC_SLOPE, 1, nullptr, s))))
+      return rc;
+    if ((rc = unary_raw(b.unary2, x2, M, mid, b.cout, q, sp, ws, &y, &sty, s))) return rc;
+  }
   // 5./6. shortcut
   const float* res = s_feats;
   if (b.strided) {
@@ -169,8 +187,8 @@ extern "C" int lcr_encoder_ws_bytes(const LcrEncoderW* W, const int64_t* n_host,
 
 extern "C" int lcr_encoder_forward(const LcrEncoderW* W, const float* feats0, const float* const* points, const int32_t* const* neighbors,
                                    const int32_t* const* subsampling, const int32_t* const* order, const int64_t* const* seg_len, int S,
-                                   const int64_t* n_host, const int* limits, float* const* out_feats, void* ws, size_t ws_bytes,
-                                   void* stream) {
+                                   const int64_t* n_host, const int64_t* seg_min_rows_host, const int* limits, float* const* out_feats,
+                                   void* ws, size_t ws_bytes, void* stream) {
   if (!W || !feats0 || !points || !neighbors || !subsampling || !seg_len || !n_host || !limits || !out_feats || !ws || S < 1) {
     set_error("lcr_encoder_forward: bad argument");
     return LCR_EARG;
@@ -183,7 +201,7 @@ extern "C" int lcr_encoder_forward(const LcrEncoderW* W, const float* feats0, co
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   StageIO st[4];
-  for (int i = 0; i < 4; ++i) st[i] = StageIO{points[i], seg_len[i], order ? order[i] : nullptr, n_host[i]};
+  for (int i = 0; i < 4; ++i) st[i] = StageIO{points[i], seg_len[i], order ? order[i] : nullptr, n_host[i], seg_min_rows_host ? seg_min_rows_host[i] : 0};
   // layout: [statistics arena][ping][pong][block scratch]
   Arena top{static_cast<char*>(ws), 0, ws_bytes};
   StatsPool sp{top.take<double>(stats_doubles(S, W->groups)), 0, stats_doubles(S, W->groups), S, W->groups};

@@ -45,6 +45,19 @@ struct GemmEpilogue {
   double*        stats;     // [GN_REPLICAS, S, groups, 2] (sum, sumsq), accumulated atomically; null = no statistics
 };
 
+// Normalise-on-load of the A operand: A holds the RAW output of the producing layer and the GroupNorm + LeakyReLU that the
+// reference applies between the two layers (ResidualBlock: norm_conv + leaky_relu in front of unary2, modules.py:215-217) happens
+// while the tile goes from registers to LDS — the normalised tensor is never written to memory (one stand-alone GroupNorm pass
+// per residual block less).  Rows of A and rows of C share the segment table.
+struct ANorm {
+  const double* stats;    // [GN_REPLICAS, S, groups, 2] sums of the A producer (its GEMM epilogue)
+  const float*  gamma;    // [K]
+  const float*  beta;     // [K]
+  int           groups;   // GroupNorm groups over K
+  float         eps, slope;
+};
+constexpr int AN_KMAX = 256;   // K of the fused form (the light kernel: K <= 256)
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // R x 32 tile of a row-major [rows_total x K] matrix -> S[k][r]   (transposing loader; src contiguous along k).
@@ -57,7 +70,9 @@ struct LoaderT {
   float4 reg[PIECES];
   unsigned okmask;                              // bit j: piece j is inside K (zeroing is deferred to the LDS store, so that
                                                 // nothing waits on the load between its issue and its use one K-step later)
+  int kb;                                       // k0 of the loaded tile (for the normalising store)
   __device__ __forceinline__ void load(const float* __restrict__ src, int64_t rows_total, int K, int64_t r0, int k0) {
+    kb = k0;
 #pragma unroll
     for (int j = 0; j < PIECES; ++j) {
       const int f = threadIdx.x + GM_T * j;
@@ -97,6 +112,24 @@ struct LoaderT {
   __device__ __forceinline__ void store(float* __restrict__ S) const {
 #pragma unroll
     for (int j = 0; j < PIECES; ++j) store_piece(S, j);
+  }
+  // row-major tiles only: y = leaky(x * scale[k] + shift[k]) with the (scale, shift) of the row's segment slot (tab[slot][0|1][k];
+  // rows < split are slot 0, the others slot 1), then the same store as above
+  __device__ __forceinline__ void store_norm(float* __restrict__ S, const float* __restrict__ tab, int split, float slope) const {
+    static_assert(RM, "normalise-on-load is built for the row-major A tile");
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+      const int f = threadIdx.x + GM_T * j;
+      const int row = f >> 3, c4 = f & 7;
+      const bool ok = (okmask >> j) & 1u;
+      const float* t = tab + (row >= split ? 2 * AN_KMAX : 0) + (ok ? kb + c4 * 4 : 0);
+      const float4 sc = *reinterpret_cast<const float4*>(t), sh = *reinterpret_cast<const float4*>(t + AN_KMAX);
+      float4 v;
+      v.x = fmaf(reg[j].x, sc.x, sh.x), v.y = fmaf(reg[j].y, sc.y, sh.y), v.z = fmaf(reg[j].z, sc.z, sh.z), v.w = fmaf(reg[j].w, sc.w, sh.w);
+      v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
+      v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
+      *reinterpret_cast<float4*>(&S[row * LD + c4 * 4]) = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
 };
 
@@ -276,9 +309,10 @@ __device__ __forceinline__ void gemm_epilogue(floatx16 (&acc)[NT], float* __rest
 // K-steps, epilogue — so what hides the load latency is the number of workgroups a CU holds, not prefetch depth: one LDS
 // buffer (17 KB), one register stage, shallow fragment prefetch, and a register budget that lets 6-8 workgroups share a CU
 // instead of 4.
-template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SHORT = false>
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SHORT = false, bool ANORM = false>
 __global__ __launch_bounds__(GM_T, SHORT ? 6 : 2) void k_gemm_f32(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
-                                                       int64_t M, int N, int K, GemmEpilogue ep, GemmBatch batch) {
+                                                       int64_t M, int N, int K, GemmEpilogue ep, GemmBatch batch, ANorm an) {
+  static_assert(!ANORM || (SHORT && !TA && VEC && BN / (32 * WN) == 1), "normalise-on-load: light form, row-major A");
   static_assert(WM * WN == 4 && BM == 32 * WM, "one 32-row MFMA tile per wavefront along M");
   constexpr int k_begin = 0;
   if (batch.count) {
@@ -369,9 +403,21 @@ __global__ __launch_bounds__(GM_T, SHORT ? 6 : 2) void k_gemm_f32(const float* _
     const int col = n0 + (w % WN) * (32 * NT) + j * 32 + (lane & 31);
     bias_v[j] = (ep.bias && col < N) ? ep.bias[col] : 0.f;
   }
+  float an_g[2] = {0.f, 0.f}, an_b[2] = {0.f, 0.f};           // normalise-on-load: this thread's (gamma, beta) of table entries
+  if constexpr (ANORM) {                                       // e = tid and tid + 256 (2 K <= 512), requested before the segment scan
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = threadIdx.x + u * GM_T;
+      if (e < 2 * K) {
+        const int k = e >= K ? e - K : e;
+        an_g[u] = an.gamma[k];
+        an_b[u] = an.beta[k];
+      }
+    }
+  }
   int blk_first = 0;
   int64_t blk_seg_start = 0, blk_seg_end = 0;
-  if (want_stats) {
+  if (want_stats || ANORM) {
     blk_seg_end = ep.seg_len[0];
     while (blk_first + 1 < ep.S && m0 >= blk_seg_end) {
       ++blk_first;
@@ -379,7 +425,51 @@ __global__ __launch_bounds__(GM_T, SHORT ? 6 : 2) void k_gemm_f32(const float* _
       blk_seg_end += ep.seg_len[blk_first];
     }
   }
-  sstore(0, 0);
+  __shared__ __attribute__((aligned(16))) float s_an[ANORM ? 4 * AN_KMAX : 4];   // [slot][scale | shift][k]
+  int an_split = BM;
+  if constexpr (ANORM) {
+    // (scale, shift) per channel for the one or two segments this row block touches (the host guarantees that no segment is
+    // shorter than the block), finalised in fp64 from the producer's statistics replicas exactly as lcr_groupnorm_apply does
+    an_split = static_cast<int>(min(static_cast<int64_t>(BM), blk_seg_end - m0));
+    const int gs = K / an.groups;
+    __shared__ float2 s_mr[2 * 64];                        // (mean, rstd) of [slot][group]
+    for (int e = threadIdx.x; e < 2 * an.groups; e += GM_T) {
+      const int slot = e >= an.groups ? 1 : 0, g = e - slot * an.groups;
+      const int sg = min(blk_first + slot, ep.S - 1);
+      const double cnt = static_cast<double>(ep.seg_len[sg]) * gs;
+      double sx = 0.0, sxx = 0.0;
+      for (int rep = 0; rep < GN_REPLICAS; ++rep) {
+        const int64_t o = ((static_cast<int64_t>(rep) * ep.S + sg) * an.groups + g) * 2;
+        sx += an.stats[o];
+        sxx += an.stats[o + 1];
+      }
+      const double mean = sx / cnt;
+      const double var = fmax(sxx / cnt - mean * mean, 0.0);
+      s_mr[e] = make_float2(static_cast<float>(mean), static_cast<float>(1.0 / sqrt(var + static_cast<double>(an.eps))));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = threadIdx.x + u * GM_T;
+      if (e < 2 * K) {
+        const int slot = e >= K ? 1 : 0, k = e - slot * K;
+        const float2 mr = s_mr[slot * an.groups + k / gs];
+        const float sc = mr.y * an_g[u];
+        s_an[slot * 2 * AN_KMAX + k] = sc;
+        s_an[slot * 2 * AN_KMAX + AN_KMAX + k] = fmaf(-mr.x, sc, an_b[u]);
+      }
+    }
+    __syncthreads();
+  }
+  auto sstore_a0 = [&]() {                                 // the light form's (only) A store
+    if constexpr (ANORM) la_t[0].store_norm(As[0], s_an, an_split, an.slope);
+  };
+  if constexpr (ANORM) {
+    sstore_a0();
+    lb_t[0].store(Bs[0]);
+  } else {
+    sstore(0, 0);
+  }
   __syncthreads();
   const int half = lane >> 5;
   const int a_off = ARM ? (wm * 32 + (lane & 31)) * LDR + half * 16 : half * (NEWP ? 16 : 1) * LDA + wm * 32 + (lane & 31);
@@ -409,7 +499,12 @@ __global__ __launch_bounds__(GM_T, SHORT ? 6 : 2) void k_gemm_f32(const float* _
       if (t > 0) {
         gload(k_begin + t * GM_BK, 0);
         __syncthreads();                                        // every wavefront has read step t-1's fragments
-        sstore(0, 0);
+        if constexpr (ANORM) {
+          sstore_a0();
+          lb_t[0].store(Bs[0]);
+        } else {
+          sstore(0, 0);
+        }
         __syncthreads();
       }
       const float* as = As[0] + a_off;
@@ -716,10 +811,10 @@ static int launch_gemm(const float* A, const float* B, float* C, int64_t M, int 
   const int mt8 = (div_up(M, BM) + 7) / 8 * 8;
   dim3 grid(mt8 * div_up(N, BN), 1, bt.count ? bt.count : 1);     // see the XCD-aware tile order in the kernel
   dim3 block(GM_T);
-  if (!transA && !transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, false, false, VEC, SHORT>), grid, block, 0, st, A, B, C, M, N, K, ep, bt);
-  else if (!transA && transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, false, true, VEC, SHORT>), grid, block, 0, st, A, B, C, M, N, K, ep, bt);
-  else if (transA && !transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, true, false, VEC, SHORT>), grid, block, 0, st, A, B, C, M, N, K, ep, bt);
-  else hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, true, true, VEC, SHORT>), grid, block, 0, st, A, B, C, M, N, K, ep, bt);
+  if (!transA && !transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, false, false, VEC, SHORT>), grid, block, 0, st, A, B, C, M, N, K, ep, bt, ANorm{});
+  else if (!transA && transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, false, true, VEC, SHORT>), grid, block, 0, st, A, B, C, M, N, K, ep, bt, ANorm{});
+  else if (transA && !transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, true, false, VEC, SHORT>), grid, block, 0, st, A, B, C, M, N, K, ep, bt, ANorm{});
+  else hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, true, true, VEC, SHORT>), grid, block, 0, st, A, B, C, M, N, K, ep, bt, ANorm{});
   return check_launch("lcr_gemm_f32");
 }
 
@@ -799,6 +894,35 @@ extern "C" void lcr_gemm_debug_streamk(int mode) { g_force_streamk = mode; }
 
 static int gemm_impl(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB, const float* bias,
                      const float* rowdiv, const int64_t* seg_len, int S, int groups, double* stats, void* stream);
+
+// C = leaky(GroupNorm(A)) · B^T (+ bias, + statistics of C): the light GEMM with normalise-on-load (ANorm above).  The caller
+// guarantees that every segment holds at least 64 rows (a row block then touches at most two segments); shapes outside the
+// light form are an argument error — the caller normalises with lcr_groupnorm_apply and calls lcr_gemm_f32 instead.
+extern "C" int lcr_gemm_f32_anorm(const float* A, const float* B, float* C, int64_t M, int N, int K, const float* bias,
+                                  const double* a_stats, const float* a_gamma, const float* a_beta, int a_groups, float a_eps,
+                                  float a_slope, const int64_t* seg_len, int S, int groups, double* stats, void* stream) {
+  if (!A || !B || !C || M < 0 || N <= 32 || K <= 0 || K > AN_KMAX || K % 4 != 0 || !a_stats || !a_gamma || !a_beta || a_groups < 1 ||
+      K % a_groups != 0 || a_groups > 64 || !seg_len || S < 1 || reinterpret_cast<uintptr_t>(A) % 16 != 0 || reinterpret_cast<uintptr_t>(B) % 16 != 0) {
+    set_error("lcr_gemm_f32_anorm: needs 32 < N, K <= 256, K % 4 == 0, a_groups dividing K, a segment table and 16-byte aligned operands");
+    return LCR_EARG;
+  }
+  if (stats) {
+    const int gs = groups >= 1 && N % groups == 0 ? N / groups : 3;
+    if ((gs & (gs - 1)) != 0) {
+      set_error("lcr_gemm_f32_anorm: statistics need groups dividing N into power-of-two sized groups");
+      return LCR_EARG;
+    }
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  KernelTimerScope timed(KT_GEMM, st, M, N, K);
+  if (M == 0) return LCR_OK;
+  GemmEpilogue ep{bias, nullptr, seg_len, S, groups, stats};
+  ANorm an{a_stats, a_gamma, a_beta, a_groups, a_eps, a_slope};
+  const int mt8 = (div_up(M, 64) + 7) / 8 * 8;
+  hipLaunchKernelGGL((k_gemm_f32<64, 64, 2, 2, false, true, true, true, true>), dim3(mt8 * div_up(N, 64)), dim3(GM_T), 0, st, A, B, C, M,
+                     N, K, ep, GemmBatch{}, an);
+  return check_launch("lcr_gemm_f32_anorm");
+}
 
 extern "C" int lcr_gemm_f32(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB, const float* bias,
                             const float* rowdiv, const int64_t* seg_len, int S, int groups, double* stats, void* stream) {

@@ -173,6 +173,247 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate_vec(const fl
   }
 }
 
+// ---- whole KPConv for C_in = C_out = 32 (the two widest query sets of the encoder: 1_2 at stage 0, 2_1 at stage 1) --------------
+// The (M, 15*C) aggregate of these two blocks is the largest intermediate of the pass (480 floats per query: 245 MB written and
+// read back at M = 128 k).  Here it only ever exists as a 16-query tile in LDS:
+//   * a workgroup (4 wavefronts) takes 16 consecutive queries of its XCD band; every wavefront aggregates 4 of them exactly as
+//     k_kpconv_aggregate_vec does (D[16 x 32] on v_mfma_f32_16x16x4_f32) and parks each D as one 480-float row of the tile;
+//   * the (15*32) x 32 weights never touch LDS: wavefront w keeps the rows [120 w, 120 w + 120) in 60 registers per lane for the
+//     whole launch (split-K over the wavefronts; inside a wavefront the MFMA k-slot g of step s is row 120 w + 30 g + s, so a
+//     lane reads its 30 A values as 15 contiguous 8-byte LDS loads) and contracts the tile with 60 MFMAs;
+//   * the four partial 16 x 32 tiles are folded through LDS by 256 threads (2 outputs each), divided by the neighbour count,
+//     biased (kpconv.py:108-116) and stored; the GroupNorm sums of the output are kept per thread across the tiles of a workgroup
+//     and leave as one fp64 atomic per (wavefront, column) at the end (earlier when the GroupNorm segment changes).
+constexpr int KF_C = 32, KF_Q = 16, KF_QW = KF_Q / KP_WAVES, KF_KK = KP_K * KF_C, KF_LD = KF_KK + 4, KF_KW = KF_KK / KP_WAVES;
+constexpr int KF_MAX_SEG = 64;
+
+template <typename IdxT>
+__global__ __launch_bounds__(KP_WAVES * 64, 3) void k_kpconv_fused32(const float* __restrict__ s_feats, const uint8_t* __restrict__ s_pos,
+                                                                     const float* __restrict__ q_pts, const float* __restrict__ s_pts,
+                                                                     const IdxT* __restrict__ idx, int64_t M, int64_t Ns, int H, KPoints kp,
+                                                                     float sigma, const float* __restrict__ W, const float* __restrict__ bias,
+                                                                     float* __restrict__ out, const int64_t* __restrict__ seg_len, int S,
+                                                                     int groups, double* __restrict__ stats, const int32_t* __restrict__ order) {
+  constexpr int C = KF_C, V = 2, D = 4;
+  __shared__ __attribute__((aligned(16))) float s_D[KF_Q * KF_LD];
+  __shared__ __attribute__((aligned(16))) float s_P[KP_WAVES][KF_Q][C];
+  __shared__ __attribute__((aligned(16))) float4 s_rel[KP_WAVES][KP_HMAX + 8];
+  __shared__ int64_t s_m[KF_Q], s_start[KF_MAX_SEG + 1];
+  __shared__ float s_nn[KF_Q];
+  __shared__ int s_seg[KF_Q];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sub = lane >> 4, col = lane & 15;
+  const float inv_sigma = 1.f / sigma;
+  float kx = 0.f, ky = 0.f, kz = 0.f;
+#pragma unroll
+  for (int k = 0; k < KP_K; ++k)
+    if (col == k) {
+      kx = kp.p[k][0];
+      ky = kp.p[k][1];
+      kz = kp.p[k][2];
+    }
+  const bool real_k = col < KP_K;
+  if (threadIdx.x == 0) {
+    int64_t o = 0;
+    for (int i = 0; i < S; ++i) {
+      s_start[i] = o;
+      o += seg_len ? seg_len[i] : M;
+    }
+    s_start[S] = o;
+  }
+  // this wavefront's slice of the weights: row 120 w + 30 (lane / 16) + s, columns lane % 16 and 16 + lane % 16
+  float breg[KF_KW / 4][2];
+  {
+    const float* wr = W + static_cast<int64_t>(KF_KW * w + (KF_KW / 4) * sub) * C + col;
+#pragma unroll
+    for (int st = 0; st < KF_KW / 4; ++st) {
+      breg[st][0] = wr[st * C];
+      breg[st][1] = wr[st * C + 16];
+    }
+  }
+  const int eq = threadIdx.x >> 4, ec = (threadIdx.x & 15) * 2;      // epilogue: tile row, first of two columns
+  const float2 bias2 = bias ? *reinterpret_cast<const float2*>(bias + ec) : make_float2(0.f, 0.f);
+  int my_seg = -1;
+  float rs[2] = {0.f, 0.f}, rss[2] = {0.f, 0.f};
+  const int gs = stats ? C / groups : 1;
+  double* rep = stats ? stats + static_cast<int64_t>(blockIdx.x % GN_REPLICAS) * S * groups * 2 : nullptr;
+  auto flush_thread = [&]() {
+    if (my_seg < 0 || !rep) return;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      double* d = rep + (static_cast<int64_t>(my_seg) * groups + (ec + j) / gs) * 2;
+      atomicAdd(d, static_cast<double>(rs[j]));
+      atomicAdd(d + 1, static_cast<double>(rss[j]));
+    }
+  };
+  __syncthreads();
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int64_t per = (M + 7) / 8;
+  const int64_t band_begin = xcd * per, band_end = min(M, band_begin + per);
+  for (int64_t t0 = band_begin + static_cast<int64_t>(slot) * KF_Q; t0 < band_end; t0 += static_cast<int64_t>(nslots) * KF_Q) {
+    // ---- 1. aggregation: 4 queries per wavefront, each D parked as a row of the tile
+    for (int i = 0; i < KF_QW; ++i) {
+      const int ql = w * KF_QW + i;
+      const int64_t t = t0 + ql;
+      if (t >= band_end) {                                  // wave-uniform
+        if (lane == 0) s_m[ql] = -1;
+        continue;
+      }
+      const int64_t m = order ? order[t] : t;
+      const float qx = q_pts[3 * m], qy = q_pts[3 * m + 1], qz = q_pts[3 * m + 2];
+      int n = 0, cnt = 0;
+      for (int h0 = 0; h0 < H; h0 += 64) {
+        const int h = h0 + lane;
+        int64_t j = Ns;
+        if (h < H) j = static_cast<int64_t>(idx[m * H + h]);
+        const bool ok = j >= 0 && j < Ns;
+        const uint64_t mk = __ballot(ok);
+        bool positive = false;
+        if (ok) {
+          const int sl = n + __popcll(mk & lanemask_lt());
+          s_rel[w][sl] = make_float4(s_pts[3 * j] - qx, s_pts[3 * j + 1] - qy, s_pts[3 * j + 2] - qz, __uint_as_float(static_cast<uint32_t>(j)));
+          positive = s_pos[j] != 0;
+        }
+        n += __popcll(mk);
+        cnt += __popcll(__ballot(positive));
+      }
+      wave_lds_sync();
+      floatx4 acc[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[v] = floatx4{0.f, 0.f, 0.f, 0.f};
+      const int steps = (n + 3) >> 2;
+      float4 p[D];
+      float2 f[D];
+      auto fetch = [&](int st, float4& pp, float2& ff) {
+        const int h = 4 * st + sub;
+        pp = s_rel[w][h < n ? h : n - 1];
+        ff = *reinterpret_cast<const float2*>(s_feats + static_cast<int64_t>(__float_as_uint(pp.w)) * C + V * col);
+      };
+      if (n > 0) {
+        auto compute = [&](int st, const float4& pp, const float2& ff) {
+          const float ex = pp.x - kx, ey = pp.y - ky, ez = pp.z - kz;
+          float wv = fmaxf(1.f - __builtin_amdgcn_sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * inv_sigma, 0.f);
+          wv = (real_k && 4 * st + sub < n) ? wv : 0.f;
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, ff.x, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, ff.y, acc[1], 0, 0, 0);
+        };
+#pragma unroll
+        for (int d = 0; d < D; ++d) fetch(d, p[d], f[d]);
+        int s0 = 0;
+        for (; s0 + D <= steps; s0 += D) {
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+            compute(s0 + d, p[d], f[d]);
+            fetch(s0 + d + D, p[d], f[d]);
+          }
+        }
+#pragma unroll
+        for (int d = 0; d < D - 1; ++d)
+          if (s0 + d < steps) compute(s0 + d, p[d], f[d]);
+      }
+      float* drow = s_D + ql * KF_LD + V * col;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 4 * sub + r;
+        if (k < KP_K) *reinterpret_cast<float2*>(drow + k * C) = make_float2(acc[0][r], acc[1][r]);
+      }
+      if (lane == 0) {
+        int sg = 0;
+        while (sg + 1 < S && m >= s_start[sg + 1]) ++sg;
+        s_m[ql] = m;
+        s_nn[ql] = static_cast<float>(cnt > 1 ? cnt : 1);
+        s_seg[ql] = sg;
+      }
+      wave_lds_sync();
+    }
+    __syncthreads();
+    // ---- 2. contraction of the tile with this wavefront's 120 weight rows
+    {
+      const float* arow = s_D + col * KF_LD + KF_KW * w + (KF_KW / 4) * sub;
+      floatx4 c[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) c[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < KF_KW / 4; st += 2) {
+        const float2 a2 = *reinterpret_cast<const float2*>(arow + st);
+        c[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, breg[st][0], c[0][0], 0, 0, 0);
+        c[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, breg[st][1], c[1][0], 0, 0, 0);
+        c[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, breg[st + 1][0], c[0][1], 0, 0, 0);
+        c[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, breg[st + 1][1], c[1][1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s_P[w][4 * sub + r][col] = c[0][0][r] + c[0][1][r];
+        s_P[w][4 * sub + r][16 + col] = c[1][0][r] + c[1][1][r];
+      }
+    }
+    __syncthreads();
+    // ---- 3. fold the four partial tiles, count division + bias, store, GroupNorm sums
+    {
+      const int64_t m = s_m[eq];
+      if (m >= 0) {
+        float2 v = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int ww = 0; ww < KP_WAVES; ++ww) {
+          const float2 pv = *reinterpret_cast<const float2*>(&s_P[ww][eq][ec]);
+          v.x += pv.x;
+          v.y += pv.y;
+        }
+        const float nnv = s_nn[eq];
+        v.x = v.x / nnv + bias2.x;
+        v.y = v.y / nnv + bias2.y;
+        *reinterpret_cast<float2*>(out + m * C + ec) = v;
+        if (rep) {
+          const int sg = s_seg[eq];
+          if (sg != my_seg) {
+            flush_thread();
+            my_seg = sg;
+            rs[0] = rs[1] = rss[0] = rss[1] = 0.f;
+          }
+          rs[0] += v.x;
+          rs[1] += v.y;
+          rss[0] = fmaf(v.x, v.x, rss[0]);
+          rss[1] = fmaf(v.y, v.y, rss[1]);
+        }
+      }
+    }
+    // (the next tile's D rows are written after this point by wavefronts that have all passed the barrier above, i.e. finished
+    //  reading the tile; its partial tiles are written after the next tile barrier, i.e. after everybody's fold)
+  }
+  if (rep) {
+    // one fp64 atomic per (wavefront, column, statistic) when the wavefront's threads agree on the segment
+    int mx = my_seg;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) mx = max(mx, __shfl_xor(mx, d));
+    const bool agree = __ballot(my_seg >= 0 && my_seg != mx) == 0ull;
+    if (agree && mx >= 0) {
+      double ds[2], dss[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        ds[j] = my_seg >= 0 ? static_cast<double>(rs[j]) : 0.0;
+        dss[j] = my_seg >= 0 ? static_cast<double>(rss[j]) : 0.0;
+        ds[j] += __shfl_xor(ds[j], 16);
+        dss[j] += __shfl_xor(dss[j], 16);
+        ds[j] += __shfl_xor(ds[j], 32);
+        dss[j] += __shfl_xor(dss[j], 32);
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          double* d = rep + (static_cast<int64_t>(mx) * groups + (ec + j) / gs) * 2;
+          atomicAdd(d, ds[j]);
+          atomicAdd(d + 1, dss[j]);
+        }
+      }
+    } else {
+      flush_thread();
+    }
+  }
+}
+
 // encoder1_1: scalar input feature per point; out[m][o] = (sum_k (sum_h w[k][h] f[h]) W[k][o]) / count + bias[o]
 // One wavefront per query, lanes = neighbours.  A query is three DEPENDENT memory round trips (order -> point + index row ->
 // neighbour coordinates) and ~250 instructions, so the kernel is latency-bound: the header of query t+2 and the neighbour
@@ -428,6 +669,42 @@ extern "C" int lcr_kpconv_aggregate(const float* s_feats, const uint8_t* s_pos, 
   KernelTimerScope timed(KT_AGGREGATE, st, M, Ns, H, C, idx_is_64 ? 8 : 4);
   return idx_is_64 ? launch_aggregate(s_feats, s_pos, q_pts, s_pts, static_cast<const int64_t*>(idx), M, Ns, H, C, kp, sigma, A, nn, order, st)
                    : launch_aggregate(s_feats, s_pos, q_pts, s_pts, static_cast<const int32_t*>(idx), M, Ns, H, C, kp, sigma, A, nn, order, st);
+}
+
+extern "C" int lcr_kpconv_fused(const float* s_feats, const uint8_t* s_pos, const float* q_pts, const float* s_pts, const void* idx,
+                                int idx_is_64, int64_t M, int64_t Ns, int H, int C, const float* kernel_points_host, float sigma,
+                                const float* W, const float* bias, float* out, const int64_t* seg_len, int S, int groups, double* stats,
+                                const int32_t* order, void* stream) {
+  if (!s_feats || !s_pos || !q_pts || !s_pts || !idx || !kernel_points_host || !W || !out || M < 0 || Ns < 0 || H < 1 || H > KP_HMAX ||
+      !(sigma > 0.f) || C != KF_C) {
+    set_error("lcr_kpconv_fused: bad argument (C must be %d, H in [1,%d])", KF_C, KP_HMAX);
+    return LCR_EARG;
+  }
+  if (stats && (!seg_len || S < 1 || S > KF_MAX_SEG || groups < 1 || C % groups != 0)) {
+    set_error("lcr_kpconv_fused: statistics need seg_len, 1 <= S <= %d and groups dividing C", KF_MAX_SEG);
+    return LCR_EARG;
+  }
+  if (M == 0) return LCR_OK;
+  const KPoints kp = load_kp(kernel_points_host);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  KernelTimerScope timed(KT_KPCONV_FUSED, st, M, Ns, H, C, idx_is_64 ? 8 : 4);
+  static const int n_cu = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    return cus;
+  }();
+  // residency-sized grid (3 workgroups per CU, a multiple of the 8 XCDs), never more workgroups than tiles per band
+  const int64_t tiles_per_band = ((M + 7) / 8 + KF_Q - 1) / KF_Q;
+  const int grid = 8 * static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(tiles_per_band, (3 * n_cu + 7) / 8)));
+  const int Sx = stats ? S : 1;
+  if (idx_is_64)
+    hipLaunchKernelGGL((k_kpconv_fused32<int64_t>), dim3(grid), dim3(KP_WAVES * 64), 0, st, s_feats, s_pos, q_pts, s_pts,
+                       static_cast<const int64_t*>(idx), M, Ns, H, kp, sigma, W, bias, out, stats ? seg_len : nullptr, Sx, groups, stats, order);
+  else
+    hipLaunchKernelGGL((k_kpconv_fused32<int32_t>), dim3(grid), dim3(KP_WAVES * 64), 0, st, s_feats, s_pos, q_pts, s_pts,
+                       static_cast<const int32_t*>(idx), M, Ns, H, kp, sigma, W, bias, out, stats ? seg_len : nullptr, Sx, groups, stats, order);
+  return check_launch("lcr_kpconv_fused");
 }
 
 extern "C" int lcr_kpconv_cin1(const float* s_feats, const float* q_pts, const float* s_pts, const void* idx, int idx_is_64, int64_t M,

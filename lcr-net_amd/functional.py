@@ -16,7 +16,7 @@ class KernelTimer:
     """Opt-in per-launch timing of lcr_gemm_f32 ("gemm", meta (M,N,K)) and lcr_kpconv_aggregate ("kpconv_aggregate", meta
     (M,Ns,H,C,index bytes)) with HIP events on the launch stream, recorded inside the library (so launches issued by the native
     encoder driver are seen too).  set_timer(t) starts a fresh log, set_timer(None) stops logging, t.summary() synchronises."""
-    KINDS = {"gemm": 0, "kpconv_aggregate": 1, "radius_query": 2, "attention": 3}
+    KINDS = {"gemm": 0, "kpconv_aggregate": 1, "radius_query": 2, "attention": 3, "kpconv_fused": 4}
 
     def __init__(self, names):
         self.names = set(names)
@@ -120,6 +120,34 @@ def gemm(a, b, trans_b=False, trans_a=False, bias=None, rowdiv=None, seg_len=Non
     return c, stats
 
 
+ANORM_MAX_K, ANORM_MIN_SEG_ROWS = 256, 64
+
+
+def gemm_anorm_ok(K, N):
+    """Shapes lcr_gemm_f32_anorm takes (the light GEMM form)."""
+    return K <= ANORM_MAX_K and K % 4 == 0 and N > 32
+
+
+def gemm_anorm(a, a_stats, a_gamma, a_beta, a_groups, weight, bias=None, seg_len=None, groups=0, slope=0.1):
+    """C = LeakyReLU(GroupNorm(a)) · weight^T (+ bias), a being the RAW output whose sums are a_stats; the normalised tensor is
+    never materialised (lcr_gemm_f32_anorm).  The caller guarantees every segment holds >= ANORM_MIN_SEG_ROWS rows.
+    Returns (C, stats) like gemm()."""
+    _lib.require_cuda(a, weight)
+    assert a.dtype == torch.float32 and weight.dtype == torch.float32 and a.is_contiguous() and weight.is_contiguous()
+    M, K = a.shape
+    N = weight.shape[0]
+    assert weight.shape[1] == K and gemm_anorm_ok(K, N)
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    seg_len = _seg(seg_len, M, a.device)
+    S = seg_len.numel()
+    stats = _zero_stats(S, groups, a.device) if groups else None
+    _timed("gemm", lambda: _lib.check(_lib.lib().lcr_gemm_f32_anorm(
+        _lib.ptr(a), _lib.ptr(weight), _lib.ptr(c), M, N, K, _lib.ptr(bias), _lib.ptr(a_stats), _lib.ptr(a_gamma), _lib.ptr(a_beta),
+        int(a_groups), GN_EPS, float(slope), _lib.ptr(seg_len), S, int(groups), _lib.ptr(stats), _lib.stream_ptr(a.device)),
+        "lcr_gemm_f32_anorm"), meta=(M, N, K))
+    return c, stats
+
+
 def groupnorm_stats(x, groups, seg_len=None):
     seg_len = _seg(seg_len, x.shape[0], x.device)
     stats = _zero_stats(seg_len.numel(), groups, x.device)
@@ -167,6 +195,32 @@ def kpconv_aggregate(s_feats, s_pos, q_points, s_points, idx, kernel_points_host
         ctypes.c_void_p(kp.ctypes.data), float(sigma), _lib.ptr(A), _lib.ptr(nn), _lib.ptr(order), _lib.stream_ptr(s_feats.device)),
         "lcr_kpconv_aggregate"), meta=(M, Ns, H, C, idx.element_size()))
     return A, nn
+
+
+KPCONV_FUSED_C = 32
+
+
+def kpconv_fused(s_feats, s_pos, q_points, s_points, idx, kernel_points_host, sigma, weights, bias, seg_len=None, groups=0, order=None):
+    """Whole rigid KPConv for C_in = C_out = 32 in one launch (lcr_kpconv_fused): the (M, 15*C) aggregate stays in LDS.
+    weights: (15, C, C).  Returns (out [M, C], stats) like gemm()."""
+    _lib.require_cuda(s_feats, q_points, s_points, idx)
+    M, H = idx.shape
+    Ns, C = s_feats.shape
+    assert C == KPCONV_FUSED_C and tuple(weights.shape) == (15, C, C) and weights.is_contiguous()
+    assert idx.is_contiguous() and s_feats.is_contiguous() and q_points.is_contiguous() and s_points.is_contiguous()
+    out = torch.empty((M, C), dtype=torch.float32, device=s_feats.device)
+    stats, S = None, 0
+    if groups:
+        seg_len = _seg(seg_len, M, s_feats.device)
+        S = seg_len.numel()
+        stats = _zero_stats(S, groups, s_feats.device)
+    kp = _kp_host(kernel_points_host)
+    _timed("kpconv_fused", lambda: _lib.check(_lib.lib().lcr_kpconv_fused(
+        _lib.ptr(s_feats), _lib.ptr(s_pos), _lib.ptr(q_points), _lib.ptr(s_points), _lib.ptr(idx), _idx_args(idx), M, Ns, H, C,
+        ctypes.c_void_p(kp.ctypes.data), float(sigma), _lib.ptr(weights), _lib.ptr(bias), _lib.ptr(out),
+        _lib.ptr(seg_len) if groups else None, S, int(groups), _lib.ptr(stats), _lib.ptr(order), _lib.stream_ptr(s_feats.device)),
+        "lcr_kpconv_fused"), meta=(M, Ns, H, C, idx.element_size()))
+    return out, stats
 
 
 def kpconv_cin1(s_feats, q_points, s_points, idx, kernel_points_host, sigma, weights, bias, order=None):

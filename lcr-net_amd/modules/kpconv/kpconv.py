@@ -3,12 +3,19 @@ experiments/lcrnet/modules/kpconv/kpconv.py:10-122) with the forward on the HIP 
 lcr_kpconv_aggregate (gather + influences + aggregation) -> lcr_gemm_f32 (kernel-point contraction with the
 neighbour-count division, bias and GroupNorm statistics fused in its epilogue)."""
 import math
+import os
 
 import torch
 import torch.nn as nn
 
 from ... import functional as F
 from ...weights import base_kernel_points
+
+
+# Opt-in: the one-launch KPConv for C = 32 (lcr_kpconv_fused).  It removes the (M, 480) intermediate from memory, and measured
+# 1.75-2.1x SLOWER than aggregate + GEMM on MI355X (324 vs 185 us, 190 vs 88 us: DESIGN.md §4.2) — the gather needs the occupancy
+# that the tile in LDS and the weights in registers take away.
+_FUSED = bool(os.environ.get("LCR_KPCONV_FUSED"))
 
 
 class KPConv(nn.Module):
@@ -50,6 +57,11 @@ class KPConv(nn.Module):
             return out, stats
         if s_pos is None:
             s_pos = F.row_positive(s_feats)
+        if (_FUSED and self.in_channels == self.out_channels == F.KPCONV_FUSED_C and neighbor_indices.shape[1] <= 128
+                and (seg_len is None or seg_len.numel() <= 64)):
+            # aggregate + contraction in one launch: the (M, 480) intermediate never reaches memory
+            return F.kpconv_fused(s_feats, s_pos, q_points, s_points, neighbor_indices, kp, self.sigma, self.weights, self.bias,
+                                  seg_len=seg_len, groups=groups, order=order)
         A, nn_cnt = F.kpconv_aggregate(s_feats, s_pos, q_points, s_points, neighbor_indices, kp, self.sigma, order=order)
         W = self.weights.view(self.kernel_size * self.in_channels, self.out_channels)
         return F.gemm(A, W, bias=self.bias, rowdiv=nn_cnt, seg_len=seg_len, groups=groups)

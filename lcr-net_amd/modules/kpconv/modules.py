@@ -9,6 +9,8 @@ experiments/lcrnet/modules/kpconv/modules.py:33-225 — executed as fused HIP la
 GroupNorm statistics are *segmented*: `StageContext.seg_len` lists the rows of every GroupNorm segment of a stage
 (None = the reference's behaviour: one segment = the whole stack, modules.py:46-50).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -20,11 +22,19 @@ class StageContext:
     """Per-stage execution context: GroupNorm segment lengths (device int64 [S]) or None, and an optional spatially coherent
     processing order of the stage's points (device int32 [N]; data.precompute_batch provides the support grid's cell order)."""
 
-    def __init__(self, seg_len=None, order=None):
+    def __init__(self, seg_len=None, order=None, min_rows=None):
         self.seg_len = seg_len
         self.order = order
+        self.min_rows = min_rows        # host int: rows of the shortest segment when known (None with segments = unknown)
+
+    def norm_on_load(self, K, N):
+        """May ResidualBlock fold norm_conv + LeakyReLU into unary2's GEMM?  (segments of >= 64 rows, the light GEMM form)"""
+        if _NO_NORM_ON_LOAD or not F.gemm_anorm_ok(K, N):
+            return False
+        return self.seg_len is None or (self.min_rows is not None and self.min_rows >= F.ANORM_MIN_SEG_ROWS)
 
 
+_NO_NORM_ON_LOAD = bool(os.environ.get("LCR_NO_NORM_ON_LOAD"))     # A/B switch
 _WHOLE = StageContext(None)
 
 
@@ -107,8 +117,13 @@ class ResidualBlock(nn.Module):
             x, pos = self.unary1(s_feats, s_ctx, want_pos=True)                       # Linear+GN+LeakyReLU, pos flags for the count
         x, stats = self.KPConv.forward_raw(x, q_points, s_points, neighbor_indices, s_pos=pos, seg_len=q_ctx.seg_len, groups=g,
                                            order=q_ctx.order)
-        x = F.groupnorm_apply(x, stats, self.norm_conv.norm.weight, self.norm_conv.norm.bias, g, q_ctx.seg_len, act=True)
-        y, ystats = self.unary2.raw(x, q_ctx)                                          # normalised below, fused with the shortcut
+        if q_ctx.norm_on_load(x.shape[1], self.out_channels):
+            # norm_conv + LeakyReLU applied while unary2's GEMM stages its A tiles: no stand-alone GroupNorm pass over x
+            y, ystats = F.gemm_anorm(x, stats, self.norm_conv.norm.weight, self.norm_conv.norm.bias, g, self.unary2.mlp.weight,
+                                     bias=self.unary2.mlp.bias, seg_len=q_ctx.seg_len, groups=g)
+        else:
+            x = F.groupnorm_apply(x, stats, self.norm_conv.norm.weight, self.norm_conv.norm.bias, g, q_ctx.seg_len, act=True)
+            y, ystats = self.unary2.raw(x, q_ctx)                                      # normalised below, fused with the shortcut
         shortcut = F.maxpool(s_feats, neighbor_indices, order=q_ctx.order) if self.strided else s_feats
         if isinstance(self.unary_shortcut, nn.Identity):
             res, res_norm = shortcut, None

@@ -99,8 +99,11 @@ def forward(enc, feats, data_dict):
     dev = feats.device
     n = [int(p.shape[0]) for p in P]
     seg = data_dict.get("segment_lengths")
+    from .backbone4 import segment_min_rows
+    rows = [r or 0 for r in segment_min_rows(data_dict)]
     if seg is None:
         seg = [torch.tensor([k], dtype=torch.int64, device=dev) for k in n]
+        rows = list(n)                                   # one segment = the whole stack
     seg = [s.contiguous() for s in seg]
     nseg = int(seg[0].numel())
     order = data_dict.get("order")
@@ -109,6 +112,7 @@ def forward(enc, feats, data_dict):
         assert int(Sub[i].shape[1]) == limits[i] and int(Sub[i].shape[0]) == n[i + 1]
     L = _lib.lib()
     n_host = (ctypes.c_int64 * 4)(*n)
+    min_rows = (ctypes.c_int64 * 4)(*rows)
     lim = (ctypes.c_int * 4)(*limits)
     nbytes = ctypes.c_size_t(0)
     _lib.check(L.lcr_encoder_ws_bytes(ctypes.byref(tab.w), n_host, nseg, ctypes.byref(nbytes)), "lcr_encoder_ws_bytes")
@@ -122,6 +126,6 @@ def forward(enc, feats, data_dict):
     sg = vp4(*[t.data_ptr() for t in seg])
     of = vp4(*[t.data_ptr() for t in outs])
     f0 = feats.contiguous()
-    _lib.check(L.lcr_encoder_forward(ctypes.byref(tab.w), _lib.ptr(f0), pts, nb, sb, od, sg, nseg, n_host, lim, of, _lib.ptr(ws), ws.numel(),
+    _lib.check(L.lcr_encoder_forward(ctypes.byref(tab.w), _lib.ptr(f0), pts, nb, sb, od, sg, nseg, n_host, min_rows, lim, of, _lib.ptr(ws), ws.numel(),
                                      _lib.stream_ptr(dev)), "lcr_encoder_forward")
     return outs

@@ -267,3 +267,82 @@ def test_stream_k_gemm_matches_tile_per_workgroup_gemm():
             assert torch.allclose(ws, gs, rtol=1e-5, atol=1e-3), (M, N, K)
     finally:
         lib.lcr_gemm_debug_streamk(-1)
+
+
+@pytest.mark.parametrize("K,N,seg", [(32, 128, [64, 130, 1000, 77]), (64, 256, [4000]), (128, 512, [65, 64, 64, 700]),
+                                     (256, 1024, [300, 64]), (64, 256, [31, 64, 200])])
+def test_gemm_with_normalise_on_load_matches_groupnorm_then_gemm(K, N, seg):
+    """lcr_gemm_f32_anorm (norm_conv + LeakyReLU folded into unary2's GEMM, modules.py:215-217 of the reference) against the
+    two-launch form lcr_groupnorm_apply -> lcr_gemm_f32 on the same raw input and statistics: the output and its GroupNorm sums
+    agree to fp32 rounding of the normalisation (x*s+t vs (x-m)*r*g+b).  Ragged segments, blocks straddling two segments; a
+    segment shorter than a row block (last case, legal only at the front of the table where one block holds at most two
+    segments... it is NOT legal in general, so the model never takes this form there) is checked to be refused by the module."""
+    from lcrnet_amd import functional as F
+    from lcrnet_amd.modules.kpconv.modules import StageContext
+    if min(seg) < F.ANORM_MIN_SEG_ROWS:
+        assert not StageContext(torch.tensor(seg), None, min(seg)).norm_on_load(K, N)
+        assert not StageContext(torch.tensor(seg), None, None).norm_on_load(K, N)
+        return
+    g = torch.Generator().manual_seed(K * 7 + N)
+    M = sum(seg)
+    x = (torch.randn(M, K, generator=g) * 2.0 + 0.7).cuda()
+    for s0, n in zip(np.cumsum([0] + seg[:-1]), seg):          # different statistics per segment
+        x[s0:s0 + n] *= 1.0 + 0.5 * (s0 % 3)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    gamma, beta = (torch.rand(K, generator=g) + 0.5).cuda(), torch.randn(K, generator=g).cuda()
+    seg_len = torch.tensor(seg, dtype=torch.int64, device="cuda")
+    groups = 32
+    assert StageContext(seg_len, None, min(seg)).norm_on_load(K, N)
+    stats = F.groupnorm_stats(x, groups, seg_len)
+    xn = F.groupnorm_apply(x, stats, gamma, beta, groups, seg_len, act=True)
+    want, wstats = F.gemm(xn, w, trans_b=True, bias=b, seg_len=seg_len, groups=groups)
+    got, gstats = F.gemm_anorm(x, stats, gamma, beta, groups, w, bias=b, seg_len=seg_len, groups=groups)
+    torch.cuda.synchronize()
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() < 2e-6 * scale * K ** 0.5
+    ws, gs = wstats.sum(0), gstats.sum(0)
+    assert torch.allclose(ws, gs, rtol=1e-5, atol=1e-5 * ws.abs().max().item())
+    # the single-segment default (seg_len None) takes the same route
+    if len(seg) == 1:
+        got1, _ = F.gemm_anorm(x, stats, gamma, beta, groups, w, bias=b, groups=groups)
+        assert torch.equal(got1, got)
+
+
+@pytest.mark.parametrize("M,Ns,H,segs,use_order", [(5000, 5000, 64, None, False), (3001, 7000, 65, [1000, 900, 1101], True),
+                                                   (37, 50, 20, [37], False), (4100, 4100, 128, [64, 4036], True)])
+def test_fused_kpconv_matches_aggregate_then_gemm(M, Ns, H, segs, use_order):
+    """lcr_kpconv_fused (C_in = C_out = 32; the (M, 480) aggregate only in LDS) against lcr_kpconv_aggregate + lcr_gemm_f32 on the
+    same inputs: outputs within fp32 summation-order noise, GroupNorm sums likewise; shadow neighbours, empty neighbourhoods,
+    a processing order, several GroupNorm segments, queries that do not fill the last tile."""
+    from lcrnet_amd import functional as F
+    from lcrnet_amd.weights import base_kernel_points
+    g = torch.Generator().manual_seed(M + H)
+    C = 32
+    s_pts = torch.rand(Ns, 3, generator=g) * 4.0
+    q_pts = s_pts[torch.randperm(Ns, generator=g)[:M]].contiguous() if M <= Ns else torch.rand(M, 3, generator=g) * 4.0
+    idx = torch.randint(0, Ns, (M, H), generator=g, dtype=torch.int64)
+    fill = torch.randint(0, H + 1, (M,), generator=g)
+    fill[::17] = 0                                                     # empty neighbourhoods
+    idx[torch.arange(H)[None, :] >= fill[:, None]] = Ns               # shadow padding
+    idx = idx.to(torch.int32).cuda()
+    feats = torch.randn(Ns, C, generator=g)
+    feats[::5] = -feats[::5].abs()                                     # rows that do not count as neighbours
+    feats = feats.cuda()
+    pos = F.row_positive(feats)
+    w = (torch.randn(15, C, C, generator=g) / (15 * C) ** 0.5).cuda()
+    b = torch.randn(C, generator=g).cuda()
+    kp = base_kernel_points() * 1.0
+    seg_len = None if segs is None else torch.tensor(segs, dtype=torch.int64, device="cuda")
+    order = torch.randperm(M, generator=g).to(torch.int32).cuda() if use_order else None
+    A, nn_cnt = F.kpconv_aggregate(feats, pos, q_pts.cuda(), s_pts.cuda(), idx, kp, 0.6, order=order)
+    want, wstats = F.gemm(A, w.view(15 * C, C), bias=b, rowdiv=nn_cnt, seg_len=seg_len, groups=32)
+    got, gstats = F.kpconv_fused(feats, pos, q_pts.cuda(), s_pts.cuda(), idx, kp, 0.6, w, b, seg_len=seg_len, groups=32, order=order)
+    torch.cuda.synchronize()
+    scale = max(1.0, want.abs().max().item())
+    assert (got - want).abs().max().item() < 2e-5 * scale
+    ws, gs = wstats.sum(0), gstats.sum(0)
+    assert torch.allclose(ws, gs, rtol=1e-5, atol=1e-4 * max(1.0, ws.abs().max().item()))
+    # no statistics requested: same output
+    got2, none = F.kpconv_fused(feats, pos, q_pts.cuda(), s_pts.cuda(), idx, kp, 0.6, w, b, order=order)
+    assert none is None and torch.equal(got2, got)

@@ -27,7 +27,7 @@ dd = pipe.preprocess(pts, lens)
 for _ in range(3):
     pipe.encode(dd)
 torch.cuda.synchronize()
-t = F.KernelTimer({"gemm", "kpconv_aggregate"})
+t = F.KernelTimer({"gemm", "kpconv_aggregate", "kpconv_fused"})
 F.set_timer(t)
 n = 10
 for _ in range(n):
@@ -35,7 +35,7 @@ for _ in range(n):
 torch.cuda.synchronize()
 F.set_timer(None)
 s = t.summary()
-for name in ("kpconv_aggregate", "gemm"):
+for name in ("kpconv_fused", "kpconv_aggregate", "gemm"):
     acc, cnt, order = defaultdict(float), defaultdict(int), []
     for sec, meta in s[name]:
         if meta not in acc:
@@ -50,6 +50,8 @@ for name in ("kpconv_aggregate", "gemm"):
         if name == "gemm":
             M, N, K = meta
             print("gemm M=%6d N=%4d K=%4d  x%.0f  %7.1f us  %6.1f TF" % (M, N, K, per, us, 2.0 * M * N * K / us / 1e6))
+        elif name == "kpconv_fused":
+            print("fused KPConv M=%6d Ns=%6d H=%2d C=%3d  x%.0f  %7.1f us" % (meta[0], meta[1], meta[2], meta[3], per, us))
         else:
             print("aggregate M=%6d Ns=%6d H=%2d C=%3d  x%.0f  %7.1f us" % (meta[0], meta[1], meta[2], meta[3], per, us))
     print("%s total %.1f us per encode" % (name, tot))
