@@ -125,6 +125,38 @@ def compute_registration_error(gt_transform, est_transform):
     return rre, relative_translation_error(gt[:3, 3], est[:3, 3]), rx, ry, rz
 
 
+def registration_partial(gt_transforms, est_transforms, rre_threshold=5.0, rte_threshold=2.0):
+    """This rank's share of the registration block as SUMS (float64 [7]: pairs, accepted, then RRE / RTE / Rx / Ry / Rz summed over
+    the accepted pairs) — what the sharded evaluation (pairs dealt to the ranks, BASELINE configs[4]) exchanges; the reference
+    reduces its per-rank meters the same way (one all-reduce of scalars, utils/utils/torch.py:16-34)."""
+    v = np.zeros(7, dtype=np.float64)
+    for gt, est in zip(gt_transforms, est_transforms):
+        e = compute_registration_error(gt, est)
+        v[0] += 1.0
+        if e[0] < rre_threshold and e[1] < rte_threshold:
+            v[1] += 1.0
+            v[2:] += np.asarray(e, dtype=np.float64)
+    return v
+
+
+def registration_reduce(partial, group=None, device=None):
+    """Sum the ranks' registration_partial vectors (one all-reduce when torch.distributed is initialised; the identity otherwise)
+    and return the summary dict of registration_summary.  `device`: where the all-reduce runs (the rank's GPU for RCCL)."""
+    import torch
+    import torch.distributed as dist
+    v = np.asarray(partial, dtype=np.float64)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        t = torch.from_numpy(v.copy())
+        if device is not None:
+            t = t.to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        v = t.cpu().numpy()
+    n, k = int(round(v[0])), int(round(v[1]))
+    m = v[2:] / k if k else np.full(5, np.nan)
+    return {"RR": float(k / n) if n else 0.0, "RRE": float(m[0]), "RTE": float(m[1]), "Rx": float(m[2]), "Ry": float(m[3]),
+            "Rz": float(m[4]), "pairs": n, "accepted": k}
+
+
 def registration_summary(gt_transforms, est_transforms, rre_threshold=5.0, rte_threshold=2.0):
     """The registration block of experiments/registration/eval.py:222-236,269-277: a pair is accepted when RRE < 5 deg and
     RTE < 2 m (config_reg.py:66-67); RR = mean acceptance over all pairs, RRE / RTE / Rx / Ry / Rz = means over the ACCEPTED pairs

@@ -2,7 +2,11 @@
 """Pairs/s of the full pair model (BASELINE configs[4]: registration pairs — encoder over the pair stack, 3D-RoFormer, vote
 encoder, node / point matching, local-to-global registration) on one GPU; one JSON line.  Not the headline metric.
 
-    python tools/pair_bench.py [--pairs-per-call P ...] [--pairs N]
+    python tools/pair_bench.py [--pairs-per-call P ...] [--pairs N] [--gpus G]
+
+--gpus G: one process per GPU (spawned here, or by torch.distributed.run), the pairs dealt round-robin to the ranks, replicas only —
+no collective on the data path; the slowest rank's time counts and the registration sums are reduced with one all-reduce
+(lcrnet_amd.evaluation.registration_partial / registration_reduce, the reference's utils/utils/torch.py:16-34).
 
 Pairs: the 15 combinations of the 6 committed KITTI demo scans (tests/golden/scans), cycled.  For every P the same pairs go
 through PairPipeline(pairs_per_call=P): P = 1 is the reference's loop (one pair per forward, model_family/LCRNet.py:274-321; two
@@ -13,6 +17,7 @@ import argparse
 import itertools
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,13 +34,35 @@ def main():
     ap.add_argument("--pairs-per-call", type=int, nargs="+", default=[1, 4, 8])
     ap.add_argument("--pairs", type=int, default=64)
     ap.add_argument("--workers", type=int, default=2)
+    ap.add_argument("--gpus", type=int, default=1)
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:          # launch the ranks ourselves (torchrun's environment contract)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                  env=dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                                           MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")) for r in range(args.gpus)]
+        sys.exit(max(p.wait() for p in procs))
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = 0 if os.environ.get("LCR_BENCH_SINGLE_DEVICE") else int(os.environ.get("LOCAL_RANK", 0))
     from lcrnet_amd import functional as F
     from lcrnet_amd.config import make_cfg
     from lcrnet_amd.model_family import LCRNet
     from lcrnet_amd.pipeline import PairPipeline
     from lcrnet_amd.weights import seeded_state_dict
-    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        backend = os.environ.get("LCR_BENCH_BACKEND", "gloo" if os.environ.get("LCR_BENCH_SINGLE_DEVICE") else "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    red_dev = dev if (dist is not None and dist.get_backend() == "nccl") else None
     limits = [74, 68, 70, 67]
     cfg = make_cfg()
     cfg["neighbor_limits"] = limits
@@ -50,12 +77,16 @@ def main():
     for i in range(args.pairs):
         a, b = combos[i % len(combos)]
         work.append((torch.cat([scans[a], scans[b]]), torch.tensor([len(scans[a]), len(scans[b])], dtype=torch.int64, device=dev)))
+    n_total = len(work)
+    work = work[rank::world]                                      # this rank's pairs
     results = {}
     for P in args.pairs_per_call:
         with PairPipeline(m, neighbor_limits=limits, workers=args.workers, pairs_per_call=P) as pp:
             for _ in pp.run(work[:max(2 * P * args.workers, 4)]):      # warm-up: allocator, code objects
                 pass
             torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
             timer = F.KernelTimer({"attention"})
             F.set_timer(timer)
             t0 = time.perf_counter()
@@ -65,10 +96,14 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             F.set_timer(None)
+            if dist is not None:                                  # the slowest rank's time counts
+                tt = torch.tensor([dt], dtype=torch.float64, device=red_dev or "cpu")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt[0])
         att = timer.summary()["attention"]
         t_att = sum(t for t, _ in att)
         flops = sum(4.0 * meta[0] * meta[2] * meta[3] for _, meta in att)
-        results[str(P)] = {"pairs_per_s": round(len(work) / dt, 2), "ms_per_pair": round(dt / len(work) * 1e3, 3),
+        results[str(P)] = {"pairs_per_s": round(n_total / dt, 2), "ms_per_pair": round(dt / n_total * 1e3, 3),
                            "attention_launches_per_pair": round(len(att) / len(work), 2),
                            "attention_us_per_launch": round(t_att / max(len(att), 1) * 1e6, 2),
                            "attention_tflops": round(flops / max(t_att, 1e-12) / 1e12, 3),
@@ -85,13 +120,20 @@ def main():
         outs = list(pp.run(work[:4]))
     paths = [io.save_registration(tmp, 0, i, i + 1, o, np.eye(4, dtype=np.float32)) for i, o in enumerate(outs)]
     back = [io.load_registration(p) for p in paths]
-    summary = ev.registration_summary([b["transform"] for b in back], [b["estimated_transform"] for b in back])
+    summary = ev.registration_reduce(ev.registration_partial([b["transform"] for b in back], [b["estimated_transform"] for b in back]),
+                                     device=red_dev)             # N > 1: every rank's four pairs, one all-reduce of the sums
     summary = {k: (None if isinstance(v, float) and v != v else v) for k, v in summary.items()}       # NaN means (no accepted pair) -> null
     files = {"written": len(paths), "keys": len(back[0]), "bytes": sum(os.path.getsize(p) for p in paths), "registration_summary_vs_identity": summary}
     shutil.rmtree(tmp, ignore_errors=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
     best = max(results, key=lambda k: results[k]["pairs_per_s"])
-    print(json.dumps({"metric": "registration pairs/s (pair model end to end, 1 GPU)", "value": results[best]["pairs_per_s"], "unit": "pairs/s",
-                      "pairs_per_call_best": int(best), "workers": args.workers, "pairs": len(work),
+    print(json.dumps({"metric": "registration pairs/s (pair model end to end, %d GPU%s)" % (world, "s" if world > 1 else ""),
+                      "value": results[best]["pairs_per_s"], "unit": "pairs/s", "n_gpus": world,
+                      "pairs_per_call_best": int(best), "workers": args.workers, "pairs": n_total,
                       "config": "15 combinations of the 6 KITTI demo scans (~17k pts each after 0.3 m voxels), limits [74,68,70,67], seeded random weights",
                       "by_pairs_per_call": results, "registration_files": files}))
 
