@@ -346,3 +346,23 @@ def test_fused_kpconv_matches_aggregate_then_gemm(M, Ns, H, segs, use_order):
     # no statistics requested: same output
     got2, none = F.kpconv_fused(feats, pos, q_pts.cuda(), s_pts.cuda(), idx, kp, 0.6, w, b, order=order)
     assert none is None and torch.equal(got2, got)
+
+
+def test_normalise_on_load_single_short_segment():
+    """One segment shorter than a row block (M = 37 < 64; the whole-stack default of a tiny cloud): legal — a block still touches
+    one segment — and equal to the two-launch form; rows beyond M never reach the output or the statistics."""
+    from lcrnet_amd import functional as F
+    from lcrnet_amd.modules.kpconv.modules import StageContext
+    g = torch.Generator().manual_seed(11)
+    M, K, N = 37, 64, 256
+    x = (torch.randn(M, K, generator=g) * 1.5 - 0.3).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    gamma, beta = (torch.rand(K, generator=g) + 0.5).cuda(), torch.randn(K, generator=g).cuda()
+    assert StageContext(None).norm_on_load(K, N)
+    stats = F.groupnorm_stats(x, 32)
+    want, wstats = F.gemm(F.groupnorm_apply(x, stats, gamma, beta, 32, act=True), w, trans_b=True, bias=b, groups=32)
+    got, gstats = F.gemm_anorm(x, stats, gamma, beta, 32, w, bias=b, groups=32)
+    torch.cuda.synchronize()
+    assert (got - want).abs().max().item() < 2e-5 * want.abs().max().item()
+    assert torch.allclose(wstats.sum(0), gstats.sum(0), rtol=1e-5, atol=1e-5 * wstats.sum(0).abs().max().item())
