@@ -234,7 +234,7 @@ __global__ __launch_bounds__(KP_WAVES * 64, 3) void k_kpconv_fused32(const float
   const int eq = threadIdx.x >> 4, ec = (threadIdx.x & 15) * 2;      // epilogue: tile row, first of two columns
   const float2 bias2 = bias ? *reinterpret_cast<const float2*>(bias + ec) : make_float2(0.f, 0.f);
   int my_seg = -1;
-  float rs[2] = {0.f, 0.f}, rss[2] = {0.f, 0.f};
+  double rs[2] = {0.0, 0.0}, rss[2] = {0.0, 0.0};     // fp64: exact sums of fp32 values and squares, i.e. independent of the processing order
   const int gs = stats ? C / groups : 1;
   double* rep = stats ? stats + static_cast<int64_t>(blockIdx.x % GN_REPLICAS) * S * groups * 2 : nullptr;
   auto flush_thread = [&]() {
@@ -242,8 +242,8 @@ __global__ __launch_bounds__(KP_WAVES * 64, 3) void k_kpconv_fused32(const float
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       double* d = rep + (static_cast<int64_t>(my_seg) * groups + (ec + j) / gs) * 2;
-      atomicAdd(d, static_cast<double>(rs[j]));
-      atomicAdd(d + 1, static_cast<double>(rss[j]));
+      atomicAdd(d, rs[j]);
+      atomicAdd(d + 1, rss[j]);
     }
   };
   __syncthreads();
@@ -371,12 +371,13 @@ __global__ __launch_bounds__(KP_WAVES * 64, 3) void k_kpconv_fused32(const float
           if (sg != my_seg) {
             flush_thread();
             my_seg = sg;
-            rs[0] = rs[1] = rss[0] = rss[1] = 0.f;
+            rs[0] = rs[1] = rss[0] = rss[1] = 0.0;
           }
-          rs[0] += v.x;
-          rs[1] += v.y;
-          rss[0] = fmaf(v.x, v.x, rss[0]);
-          rss[1] = fmaf(v.y, v.y, rss[1]);
+          const double vx = v.x, vy = v.y;
+          rs[0] += vx;
+          rs[1] += vy;
+          rss[0] += vx * vx;
+          rss[1] += vy * vy;
         }
       }
     }
@@ -393,8 +394,8 @@ __global__ __launch_bounds__(KP_WAVES * 64, 3) void k_kpconv_fused32(const float
       double ds[2], dss[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        ds[j] = my_seg >= 0 ? static_cast<double>(rs[j]) : 0.0;
-        dss[j] = my_seg >= 0 ? static_cast<double>(rss[j]) : 0.0;
+        ds[j] = my_seg >= 0 ? rs[j] : 0.0;
+        dss[j] = my_seg >= 0 ? rss[j] : 0.0;
         ds[j] += __shfl_xor(ds[j], 16);
         dss[j] += __shfl_xor(dss[j], 16);
         ds[j] += __shfl_xor(ds[j], 32);

@@ -279,6 +279,8 @@ def test_gemm_with_normalise_on_load_matches_groupnorm_then_gemm(K, N, seg):
     segments... it is NOT legal in general, so the model never takes this form there) is checked to be refused by the module."""
     from lcrnet_amd import functional as F
     from lcrnet_amd.modules.kpconv.modules import StageContext
+    if os.environ.get("LCR_NO_NORM_ON_LOAD"):
+        pytest.skip("the A/B switch turns the form under test off")
     if min(seg) < F.ANORM_MIN_SEG_ROWS:
         assert not StageContext(torch.tensor(seg), None, min(seg)).norm_on_load(K, N)
         assert not StageContext(torch.tensor(seg), None, None).norm_on_load(K, N)
@@ -359,6 +361,8 @@ def test_normalise_on_load_single_short_segment():
     w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
     b = torch.randn(N, generator=g).cuda()
     gamma, beta = (torch.rand(K, generator=g) + 0.5).cuda(), torch.randn(K, generator=g).cuda()
+    if os.environ.get("LCR_NO_NORM_ON_LOAD"):
+        pytest.skip("the A/B switch turns the form under test off")
     assert StageContext(None).norm_on_load(K, N)
     stats = F.groupnorm_stats(x, 32)
     want, wstats = F.gemm(F.groupnorm_apply(x, stats, gamma, beta, 32, act=True), w, trans_b=True, bias=b, groups=32)
