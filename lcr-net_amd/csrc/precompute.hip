@@ -265,7 +265,7 @@ extern "C" int lcr_precompute_batch(const float* points0, const int64_t* lengths
     if (rc) return rc;
     if (i > 0 && L->upsampling) {
       rc = search(pts[i - 1], lens[i - 1], L->cap[i - 1], W.grid_ws[i], L->cap[i], r, L->limits[i], i32(L->off_upsampling[i - 1]),
-                  i32(L->off_order[i - 1]), s);
+                  no_fork ? i32(L->off_order[i - 1]) : nullptr, s);   // forked: order[i-1] is written on another side stream
       if (rc) return rc;
     }
     if (i > 0) {
