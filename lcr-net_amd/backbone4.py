@@ -40,7 +40,8 @@ class KPEncoder(nn.Module):
         self.encoder4_1 = ResidualBlock(d * 8, d * 8, k, r * 4, s * 4, g, strided=True)
         self.encoder4_2 = ResidualBlock(d * 8, d * 16, k, r * 8, s * 8, g)
         self.encoder4_3 = ResidualBlock(d * 16, d * 16, k, r * 8, s * 8, g)
-        self.native = False          # True: forward through lcr_encoder_forward when the inputs allow it
+        # forward through lcr_encoder_forward (one native call) when the inputs allow it; LCR_NATIVE_ENCODER=0: the module tree below
+        self.native = os.environ.get("LCR_NATIVE_ENCODER", "1") != "0"
 
     def forward(self, feats, data_dict):
         """data_dict: 'points'[4], 'neighbors'[4], 'subsampling'[3] (+ optional 'segment_lengths'[4]: per-stage device
@@ -48,12 +49,12 @@ class KPEncoder(nn.Module):
         P, N, S = data_dict["points"], data_dict["neighbors"], data_dict["subsampling"]
         seg = data_dict.get("segment_lengths")
         order = data_dict.get("order")
-        # One native call (csrc/encoder.hip: same launches, bit-identical outputs, ~30 % less host time per pass).  Opt-in: in
-        # the three-stream descriptor pipeline it measured 10 % SLOWER than this module tree — its launch
-        # bursts keep the encoder queues full, which stretches the latency-bound pre-processing chain the pipeline waits for.
-        if self.native or os.environ.get("LCR_NATIVE_ENCODER"):
-            if native_encoder.eligible(feats, data_dict):
-                return native_encoder.forward(self, feats, data_dict)
+        # One native call (csrc/encoder.hip): the same launches in the same order issued by C++ — bit-identical outputs
+        # (tests/test_encoder_gpu.py), ~30 % less host time per pass and no interpreter lock held while the pass is issued.  In the
+        # descriptor pipeline both drivers measure the same rate today (2 413 vs 2 421 scans/s; round 1's 10 % deficit
+        # went away with the launch-turn gate and the prioritised pre-processing stream), so the native one is the default.
+        if self.native and native_encoder.eligible(feats, data_dict):
+            return native_encoder.forward(self, feats, data_dict)
         rows = segment_min_rows(data_dict)
         ctx = [StageContext(None if seg is None else seg[i], None if order is None else order[i], rows[i]) for i in range(4)]
         with F.stats_arena(feats.device):
