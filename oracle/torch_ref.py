@@ -310,7 +310,7 @@ def log_optimal_transport(scores, row_masks, col_masks, alpha, iters=100, inf=1e
     pcm[:, :N] = ~col_masks
     S = torch.cat([torch.cat([scores, alpha.expand(B, M, 1)], -1), alpha.expand(B, 1, N + 1)], 1)
     S = S.masked_fill(prm[:, :, None] | pcm[:, None, :], -inf)
-    nr, nc = row_masks.float().sum(1), col_masks.float().sum(1)
+    nr, nc = row_masks.to(scores.dtype).sum(1), col_masks.to(scores.dtype).sum(1)      # fp64 scores -> an fp64 run (tests)
     norm = -torch.log(nr + nc)
     log_mu = norm[:, None].expand(B, M + 1).clone()
     log_mu[:, M] = torch.log(nc) + norm

@@ -14,6 +14,17 @@ can be required to meet north_star's 1e-4 on identical inputs:
                                                   output = correspondences, scores, per-hypothesis inlier counts, best hypothesis,
                                                            estimated transform — the module re-run on that subset, plus the
                                                            intermediate quantities recomputed with the module's own methods
+  D. the matching link in between (the part of a-10 that was only checked against the torch restatement before):
+     `point_to_node_partition` (ops/pointcloud_partition.py:60-107)   input  = stage-0 points of each cloud + the reference's node centres
+                                                  output = node masks, (M, 128) knn indices + masks of both clouds
+     `node_optimal_transport` (sinkhorn/learnable_sinkhorn.py:20-66)  input  = the reference's scaled node score matrix + node masks
+                                                  output = (M+1, N+1) log matching scores
+     `coarse_matching` = SuperPointMatching_OT (geotransformer/superpoint_matching.py:91-187)
+                                                  output = node correspondences + scores
+     `optimal_transport` (patch level)            input  = the reference's scaled (128 x 128) patch score matrices + masks of
+                                                           D_N_PATCH of its patch correspondences;  output = their (129 x 129) log scores
+     Function `point_to_node_partition` is captured by wrapping the name the reference model module imported; the three modules
+     by forward hooks.
   C. the same module on a seeded WELL-CONDITIONED synthetic case (`synthetic_lgr_case` below: 24 patches, a known rigid motion,
      2 cm noise, peaked scores, 6 outlier patches with a different motion) where the pose is determined by the data — inputs are
      regenerated from the seed by the tests, only the outputs are stored.
@@ -31,6 +42,7 @@ sys.path.insert(0, HERE)
 import make_golden_model as mgm  # noqa: E402
 
 N_SUBSET = 40
+D_N_PATCH = 20
 
 
 def synthetic_lgr_case(seed=0, P=24, K=128, n_out=6):
@@ -154,10 +166,24 @@ def main():
     cap = {}
     h1 = full.vote_encoder.register_forward_hook(lambda m, i, o: cap.__setitem__("vote", (i[0].clone(), {k: v for k, v in o.items()})))
     h2 = full.fine_matching.register_forward_hook(lambda m, i, o: cap.__setitem__("lgr", ([t.clone() for t in i], o)))
+    h3 = full.node_optimal_transport.register_forward_hook(lambda m, i, o: cap.__setitem__("node_ot", ([t.clone() for t in i], o.clone())))
+    h4 = full.optimal_transport.register_forward_hook(lambda m, i, o: cap.__setitem__("patch_ot", ([t.clone() for t in i], o.clone())))
+    h5 = full.coarse_matching.register_forward_hook(lambda m, i, o: cap.__setitem__("coarse", ([t.clone() for t in i], [t.clone() for t in o])))
+    import experiments.lcrnet.model_family.LCRNet as ref_mod
+    ref_partition = ref_mod.point_to_node_partition
+    cap["partition"] = []
+
+    def partition_spy(points, nodes, limit, *a, **k):
+        out = ref_partition(points, nodes, limit, *a, **k)
+        cap["partition"].append((points.clone(), nodes.clone(), limit, [t.clone() for t in out]))
+        return out
+
+    ref_mod.point_to_node_partition = partition_spy
     with torch.no_grad():
         out = full(dd)
-    h1.remove()
-    h2.remove()
+    for h in (h1, h2, h3, h4, h5):
+        h.remove()
+    ref_mod.point_to_node_partition = ref_partition
     store = {}
     # ---- A: vote encoder on the reference's enhanced features
     enhanced, vo = cap["vote"]
@@ -189,6 +215,53 @@ def main():
                  B_corr_scores=sc.numpy(), B_corr_bij=np.stack([bb.numpy(), ii.numpy(), jj.numpy()], 1).astype(np.int32), B_chunks=chunks,
                  B_hypotheses=hyp.numpy(), B_inlier_counts=counts.numpy().astype(np.int64), B_best=np.array(best), B_transform=T.numpy(),
                  B_full_transform=T_all.numpy(), B_full_num_corr=np.array(rp_all.shape[0]), B_hyp_stable=hyp_stable, B_fit_stable=fit_stable, B_T_stable=np.array(T_stable))
+    # ---- D: partition -> node-level transport -> coarse matching -> patch-level transport, on the reference's own tensors
+    assert len(cap["partition"]) == 2
+    for side, (p_in, n_in, limit, (p2n, nmask, knn, kmask)) in zip(("pos", "anc"), cap["partition"]):
+        assert limit == 128
+        assert np.array_equal(n_in.numpy(), store["A_%s_points_c" % side])      # nodes = stage A's centres; points = stage-0 points of the scan
+        store["D_%s_point_to_node" % side] = p2n.numpy().astype(np.int32)
+        store["D_%s_node_masks" % side] = nmask.numpy()
+        store["D_%s_node_knn_indices" % side] = knn.numpy().astype(np.int32)
+        store["D_%s_node_knn_masks" % side] = kmask.numpy()
+        store["D_%s_num_points" % side] = np.array(p_in.shape[0])
+    (ns_in, nrm, ncm), ns_out = cap["node_ot"]
+    store.update(D_node_scores_in=ns_in[0].numpy(), D_node_row_masks=nrm[0].numpy(), D_node_col_masks=ncm[0].numpy(),
+                 D_node_log_scores=ns_out[0].numpy(), D_node_alpha=np.array(float(full.node_optimal_transport.alpha)))
+    (cm_in, _, _), (ci, cj, cs) = cap["coarse"]
+    assert torch.equal(cm_in, ns_out[0])
+    store.update(D_node_corr_i=ci.numpy().astype(np.int32), D_node_corr_j=cj.numpy().astype(np.int32), D_node_corr_scores=cs.numpy())
+    (ps_in, prm, pcm), ps_out = cap["patch_ot"]
+    assert torch.equal(ps_out, ms)                                             # what fine_matching received (stage B's input)
+    Dsel = S[:: N_SUBSET // D_N_PATCH][:D_N_PATCH]
+    store.update(D_patch_ids=Dsel.numpy(), D_patch_scores_in=ps_in[Dsel].numpy(), D_patch_row_masks=prm[Dsel].numpy(),
+                 D_patch_col_masks=pcm[Dsel].numpy(), D_patch_log_scores=ps_out[Dsel].numpy(),
+                 D_patch_alpha=np.array(float(full.optimal_transport.alpha)))
+    # how far the reference's OWN fp32 result is from the same module run in fp64 (the floor any fp32 implementation shares)
+    torch.set_default_dtype(torch.float64)
+    with torch.no_grad():
+        n64 = full.node_optimal_transport.double()(ns_in.double(), nrm, ncm)[0]
+        p64 = full.optimal_transport.double()(ps_in[Dsel].double(), prm[Dsel], pcm[Dsel])
+    torch.set_default_dtype(torch.float32)
+    full.node_optimal_transport.float()
+    full.optimal_transport.float()
+
+    def valid_mask(rm_, cm_):
+        v = torch.ones(rm_.shape[0], rm_.shape[1] + 1, cm_.shape[1] + 1, dtype=torch.bool)
+        v[:, :-1, :] &= rm_[:, :, None]
+        v[:, :, :-1] &= cm_[:, None, :]
+        return v
+
+    nv = valid_mask(nrm, ncm)[0]
+    pv = valid_mask(prm[Dsel], pcm[Dsel])
+    e_node = float((ns_out[0].double() - n64)[nv].abs().max())
+    e_patch = np.array([float((ps_out[Dsel][k].double() - p64[k])[pv[k]].abs().max()) for k in range(len(Dsel))])
+    rng_patch = np.array([float(ps_in[Dsel][k][prm[Dsel][k]][:, pcm[Dsel][k]].max() - ps_in[Dsel][k][prm[Dsel][k]][:, pcm[Dsel][k]].min()) for k in range(len(Dsel))])
+    store.update(D_node_log_scores_f64=n64.numpy(), D_node_ref_err_vs_f64=np.array(e_node), D_patch_ref_err_vs_f64=e_patch, D_patch_score_range=rng_patch,
+                 D_patch_log_scores_f64=p64.numpy().astype(np.float64))
+    print("D: reference fp32 vs fp64: node OT %.2e; patch OT per problem" % e_node, np.array2string(e_patch, precision=1), "score ranges", np.array2string(rng_patch, precision=0))
+    print("D: nodes", ns_in.shape, "node corr", ci.shape[0], "patch problems", tuple(ps_in.shape), "kept", len(Dsel),
+          "node score range %.3f..%.3f" % (float(ns_in.min()), float(ns_in.max())), "patch score range %.3f..%.3f" % (float(ps_in.min()), float(ps_in.max())))
     # ---- C: the same module on the well-conditioned synthetic case
     ref, src, rm, sm, logs, T_true = synthetic_lgr_case()
     tr, ts, trm, tsm, tl = (torch.from_numpy(x) for x in (ref, src, rm, sm, logs))

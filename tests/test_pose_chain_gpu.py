@@ -133,3 +133,112 @@ def test_local_global_registration_well_conditioned(gold, model):
     got = _run_lgr(model, ref, src, rm, sm, logs)
     _check_lgr("synthetic", got, gold, "C_", pin_T=True)
     assert np.abs(got[3] - T_true).max() < 1e-3
+
+
+# ---- D: the matching link between A and B on the reference's own tensors ----------------------------------------------------
+# Reference: ops/pointcloud_partition.py:60-107, sinkhorn/learnable_sinkhorn.py:20-66, geotransformer/superpoint_matching.py:91-187.
+
+def _valid(rm, cm):
+    v = np.ones((rm.shape[0], rm.shape[1] + 1, cm.shape[1] + 1), dtype=bool)
+    v[:, :-1, :] &= rm[:, :, None]
+    v[:, :, :-1] &= cm[:, None, :]
+    return v
+
+
+def test_point_to_node_partition_on_reference_nodes(gold):
+    """D1: stage-0 points of each demo scan + the reference's node centres -> node masks, (M, 128) knn indices and masks.
+    Integers are exact EXCEPT where the reference's own choice is an artefact of its fp32 distance formula: it evaluates
+    |n|^2 - 2 n.p + |p|^2 (pairwise_distance.py), whose rounding error at 20-60 m from the sensor (~ 4 eps (|n|^2 + |p|^2), up to
+    3e-3 m^2) exceeds the gap between many candidate pairs; the HIP kernel takes differences first and is exact to 1e-6.  Every
+    mismatch is therefore required to be such a near-tie in fp64 — two candidates whose exact squared distances differ by less than
+    that bound — and all of them are counted and printed."""
+    from lcrnet_amd import functional as F
+    eps = float(np.finfo(np.float32).eps)
+    total_slots = total_bad = 0
+    for side, scan in (("pos", "003854"), ("anc", "000958")):
+        pts = load_scan(scan)
+        nodes = gold["A_%s_points_c" % side]
+        N, M = len(pts), len(nodes)
+        assert N == int(gold["D_%s_num_points" % side])
+        p2n, nm, knn, km = F.point_to_node_partition(cu(pts), cu(nodes), 128)
+        p2n, nm, knn, km = p2n.cpu().numpy().astype(np.int64), nm.cpu().numpy(), knn.cpu().numpy(), km.cpu().numpy()
+        w_p2n = gold["D_%s_point_to_node" % side].astype(np.int64)
+        w_knn, w_km, w_nm = gold["D_%s_node_knn_indices" % side].astype(np.int64), gold["D_%s_node_knn_masks" % side], gold["D_%s_node_masks" % side]
+        p64, n64 = pts.astype(np.float64), nodes.astype(np.float64)
+        d2 = ((n64[:, None, :] - p64[None, :, :]) ** 2).sum(-1)                                   # (M, N) exact
+        bound = 4 * eps * ((n64 ** 2).sum(1)[:, None] + (p64 ** 2).sum(1)[None, :])              # rounding of the reference's formula
+        # point -> nearest node
+        bad = np.nonzero(p2n != w_p2n)[0]
+        for i in bad:
+            assert abs(d2[p2n[i], i] - d2[w_p2n[i], i]) <= bound[p2n[i], i] + bound[w_p2n[i], i], ("point", i, p2n[i], w_p2n[i])
+        moved = set(bad.tolist())                                                                 # points whose owner is a near-tie
+        assert np.array_equal(nm, w_nm) or len(moved) > 0
+        # per node: the (up to) 128 nearest of its own points, ascending
+        n_bad = 0
+        for m in range(M):
+            if np.array_equal(knn[m], w_knn[m]):
+                continue
+            for k in np.nonzero(knn[m] != w_knn[m])[0]:
+                a, b = int(knn[m, k]), int(w_knn[m, k])
+                n_bad += 1
+                if a in moved or b in moved:
+                    continue                                                                      # ownership itself was a near-tie
+                if a == N or b == N:                                                              # one side ran out of own points: only via a moved point
+                    own_got, own_want = set(np.nonzero(p2n == m)[0].tolist()), set(np.nonzero(w_p2n == m)[0].tolist())
+                    assert own_got != own_want, ("node", m, "slot", k, a, b)
+                    continue
+                assert abs(d2[m, a] - d2[m, b]) <= bound[m, a] + bound[m, b], ("node", m, "slot", k, a, b, d2[m, a], d2[m, b])
+        assert np.array_equal(km, knn != N) and np.array_equal(w_km, w_knn != N)
+        total_slots += M * 128
+        total_bad += n_bad
+        print("partition %s: %d points / %d nodes: %d owner near-ties, %d of %d knn slots differ (all fp64 near-ties of the reference's formula)"
+              % (side, N, M, len(bad), n_bad, M * 128))
+    assert total_bad <= 0.005 * total_slots
+
+
+def test_node_transport_and_coarse_matching_on_reference_scores(gold):
+    """D2: the reference's scaled node score matrix + masks -> log-Sinkhorn (100 iterations) -> dustbin top-1 matching.
+    Log scores within 1e-4 of the reference's on the valid entries (and no farther from an fp64 run of the reference module than
+    the reference's own fp32 result is); node correspondences exact, from the reference's scores and from ours."""
+    from lcrnet_amd import functional as F
+    raw, rm, cm = gold["D_node_scores_in"], gold["D_node_row_masks"], gold["D_node_col_masks"]
+    alpha = torch.tensor(float(gold["D_node_alpha"]), device="cuda")
+    got = F.log_optimal_transport(cu(raw)[None], cu(rm)[None], cu(cm)[None], alpha, scale=1.0, iters=100)
+    v = _valid(rm[None], cm[None])[0]
+    g = got[0].cpu().numpy()
+    e_ref = np.abs(g - gold["D_node_log_scores"])[v].max()
+    e_64 = np.abs(g.astype(np.float64) - gold["D_node_log_scores_f64"])[v].max()
+    floor = float(gold["D_node_ref_err_vs_f64"])
+    print("node transport (%d x %d, scores %.1f..%.1f): vs reference %.2e, vs fp64 %.2e (reference's own fp32 error %.2e)" %
+          (raw.shape[0], raw.shape[1], raw.min(), raw.max(), e_ref, e_64, floor))
+    assert e_ref < TOL
+    assert e_64 < max(TOL, 1.5 * floor)
+    for tag, logs in (("reference scores", cu(gold["D_node_log_scores"])[None]), ("own scores", got)):
+        bij, sc = F.top1_matching(logs)
+        assert np.array_equal(bij[:, 1].cpu().numpy(), gold["D_node_corr_i"]) and np.array_equal(bij[:, 2].cpu().numpy(), gold["D_node_corr_j"]), tag
+        e = np.abs(sc.cpu().numpy() - gold["D_node_corr_scores"]).max()
+        assert e < TOL * max(1.0, float(np.abs(gold["D_node_corr_scores"]).max())), (tag, e)
+    print("coarse matching: %d node correspondences exact" % len(gold["D_node_corr_i"]))
+
+
+def test_patch_transport_on_reference_scores(gold):
+    """D3: 20 of the reference's (128 x 128) patch score matrices (its scaled feature products, spread over up to 600 with the
+    seeded random weights) -> the 129 x 129 log scores.  Per problem: within 1e-4 of the reference where the reference's own fp32
+    result is that close to an fp64 run of its module; elsewhere no farther from fp64 than 1.5x the reference's own error."""
+    from lcrnet_amd import functional as F
+    raw, rm, cm = gold["D_patch_scores_in"], gold["D_patch_row_masks"], gold["D_patch_col_masks"]
+    alpha = torch.tensor(float(gold["D_patch_alpha"]), device="cuda")
+    got = F.log_optimal_transport(cu(raw), cu(rm), cu(cm), alpha, scale=1.0, iters=100).cpu().numpy()
+    v = _valid(rm, cm)
+    assert np.array_equal(gold["D_patch_log_scores"], gold["B_log_scores"][:: 2][: len(raw)])          # the matrices stage B consumes
+    worst = 0.0
+    for k in range(len(raw)):
+        e_ref = np.abs(got[k] - gold["D_patch_log_scores"][k])[v[k]].max()
+        e_64 = np.abs(got[k].astype(np.float64) - gold["D_patch_log_scores_f64"][k])[v[k]].max()
+        floor = float(gold["D_patch_ref_err_vs_f64"][k])
+        print("patch %2d: score range %6.1f  vs reference %.2e  vs fp64 %.2e  (reference vs fp64 %.2e)" % (k, gold["D_patch_score_range"][k], e_ref, e_64, floor))
+        assert e_64 < max(TOL, 1.5 * floor), k
+        if floor < 3e-5:
+            assert e_ref < TOL, k
+            worst = max(worst, e_ref)
+    print("patch transport: worst difference to the reference on the problems it resolves itself: %.2e" % worst)

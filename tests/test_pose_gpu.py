@@ -47,13 +47,32 @@ def test_point_to_node_partition():
     p2n, nm, knn, km = F.point_to_node_partition(pts.cuda(), nodes.cuda(), 128)
     assert (p2n.cpu().long() == wp2n).float().mean().item() > 0.999
     assert torch.equal(nm.cpu(), wnm)
-    assert (knn.cpu() == wknn).float().mean().item() > 0.998 and (km.cpu() == wkm).float().mean().item() > 0.999
+    assert (knn.cpu() == wknn).float().mean().item() > 0.998 and (km.cpu() == wkm).float().mean().item() > 0.999   # exact-up-to-fp64-near-ties is asserted on the reference's own nodes in test_pose_chain_gpu.py (stage D1)
+
+
+def _ot_errors(raw, rm, cm, alpha, scale):
+    """-> (valid mask, HIP result, fp32 torch oracle, fp64 torch oracle) of one LearnableLogOptimalTransport problem set."""
+    from lcrnet_amd import functional as F
+    B, M, N = raw.shape
+    want32 = torch_ref.log_optimal_transport(raw * scale, rm, cm, alpha, iters=100)
+    want64 = torch_ref.log_optimal_transport(raw.double() * scale, rm, cm, alpha.double(), iters=100)
+    got = F.log_optimal_transport(raw.cuda(), rm.cuda(), cm.cuda(), alpha.cuda(), scale=scale, iters=100).cpu()
+    valid = torch.ones(B, M + 1, N + 1, dtype=torch.bool)
+    valid[:, :M, :] &= rm[:, :, None]
+    valid[:, :, :N] &= cm[:, None, :]
+    return valid, got, want32, want64
+
+
+# (B, M, N) -> bound on |HIP - fp64 oracle| over the valid entries.  What fp32 allows depends on the spread of the scores (the
+# log-sum-exp of a row loses ~ eps * spread per iteration at worst); measured on MI355X: 3.4e-5 (planted +20 matches: spread 30) / 3.1e-6 / 1.1e-6,
+# the fp32 torch oracle's own distance to fp64 on the same problems being 4.0e-5 / 3.2e-6 / 1.2e-6.  The bounds leave a factor 2-3.
+SINKHORN_CASES = {(1, 350, 331): 7e-5, (37, 128, 128): 1e-5, (3, 5, 9): 4e-6}
 
 
 def test_log_sinkhorn_and_top1_matching():
     from lcrnet_amd import functional as F
     g = torch.Generator().manual_seed(2)
-    for (B, M, N) in [(1, 350, 331), (37, 128, 128), (3, 5, 9)]:
+    for (B, M, N), bound in SINKHORN_CASES.items():
         raw = torch.randn(B, M, N, generator=g) * 3
         if B == 1:                                          # planted matches so that some pairs beat the dustbins
             perm = torch.randperm(N, generator=g)[:200]
@@ -63,27 +82,33 @@ def test_log_sinkhorn_and_top1_matching():
         rm[:, 0] = True
         cm[:, 0] = True
         alpha = torch.tensor(0.7)
-        want = torch_ref.log_optimal_transport(raw * 0.5, rm, cm, alpha, iters=100)
-        got = F.log_optimal_transport(raw.cuda(), rm.cuda(), cm.cuda(), alpha.cuda(), scale=0.5, iters=100).cpu()
-        valid = torch.ones(B, M + 1, N + 1, dtype=torch.bool)
-        valid[:, :M, :] &= rm[:, :, None]
-        valid[:, :, :N] &= cm[:, None, :]
-        assert (got[valid] - want[valid]).abs().max().item() < 2e-3, (B, M, N)
+        valid, got, want32, want64 = _ot_errors(raw, rm, cm, alpha, 0.5)
+        e64 = (got.double() - want64)[valid].abs().max().item()
+        e32 = (got - want32)[valid].abs().max().item()
+        floor = (want32.double() - want64)[valid].abs().max().item()
+        print("sinkhorn %s: HIP vs fp64 %.2e, vs fp32 torch %.2e (fp32 torch vs fp64 %.2e)" % ((B, M, N), e64, e32, floor))
+        assert e64 < bound, (B, M, N, e64)
+        assert e32 < 1e-4, (B, M, N, e32)                  # north_star's tolerance against the fp32 restatement of the reference
         if B == 1:
-            wi, wj, ws = torch_ref.superpoint_matching_ot(want[0])
+            wi, wj, ws = torch_ref.superpoint_matching_ot(want32[0])
             bij, sc = F.top1_matching(got.cuda())
             assert set(zip(wi.tolist(), wj.tolist())) == set(zip(bij[:, 1].tolist(), bij[:, 2].tolist()))
             assert bij[:, 1].tolist() == wi.tolist()                       # row-major order
-            assert (sc.cpu() - ws).abs().max().item() < 1e-3 * ws.abs().max().item() + 1e-6
+            assert (sc.cpu() - ws).abs().max().item() < 1e-4 * ws.abs().max().item() + 1e-6
+
+
+# spread -> bound on |HIP - fp64| (scores spread over +-3*spread).  Measured: 2.7e-6 / 1.0e-4 / 5.5e-4 for the HIP kernel and
+# 2.8e-6 / 6.6e-5 / 7.4e-4 for the fp32 torch oracle: beyond a spread of ~30 NO fp32 implementation of the reference's iteration
+# reaches 1e-4, the reference's own included (tests/test_pose_chain_gpu.py measures that on its real score matrices).
+WIDE_CASES = {1.0: 1e-5, 12.0: 3e-4, 40.0: 1.5e-3}
 
 
 @pytest.mark.parametrize("spread", [1.0, 12.0, 40.0])
 def test_patch_sinkhorn_survives_wide_score_ranges(spread):
     """The patch-level problems (129 x 129 + dustbins, register-resident kernel) with scores spread over +-3*spread — the widest
     case puts most of exp(score) below fp32's smallest normal — masked rows / columns, a row far below everything else and a
-    column that dominates its rows: finite everywhere and equal to the fp32 log-domain oracle on the valid entries (the oracle
-    itself is within 3e-6 / 7e-5 / 7e-4 of an fp64 run on these three cases)."""
-    from lcrnet_amd import functional as F
+    column that dominates its rows: finite everywhere, within the per-spread bound of an fp64 run, and never more than 2x farther
+    from it than the fp32 torch oracle is."""
     g = torch.Generator().manual_seed(int(spread))
     B, M, N = 9, 129, 129
     raw = torch.randn(B, M, N, generator=g) * spread
@@ -93,14 +118,13 @@ def test_patch_sinkhorn_survives_wide_score_ranges(spread):
     cm = torch.rand(B, N, generator=g) > 0.2
     rm[:, 0] = cm[:, 0] = True
     alpha = torch.tensor(1.0)
-    want = torch_ref.log_optimal_transport(raw, rm, cm, alpha, iters=100)
-    got = F.log_optimal_transport(raw.cuda(), rm.cuda(), cm.cuda(), alpha.cuda(), scale=1.0, iters=100).cpu()
+    valid, got, want32, want64 = _ot_errors(raw, rm, cm, alpha, 1.0)
     assert torch.isfinite(got).all()
-    valid = torch.ones(B, M + 1, N + 1, dtype=torch.bool)
-    valid[:, :M, :] &= rm[:, :, None]
-    valid[:, :, :N] &= cm[:, None, :]
-    err = (got[valid] - want[valid]).abs()
-    assert (err <= 2e-3 + 2e-5 * want[valid].abs()).all(), float(err.max())     # the tolerance of the test above
+    e64 = (got.double() - want64)[valid].abs().max().item()
+    floor = (want32.double() - want64)[valid].abs().max().item()
+    print("patch sinkhorn spread %.0f: HIP vs fp64 %.2e (fp32 torch vs fp64 %.2e)" % (spread, e64, floor))
+    assert e64 < WIDE_CASES[spread], e64
+    assert e64 < 2.0 * floor + 1e-5, (e64, floor)
 
 
 def test_procrustes_and_lgr_pieces():
