@@ -109,6 +109,12 @@ class LearnableLogOptimalTransport(nn.Module):
 
 
 class LCRNet(nn.Module):
+    # The reference has three classes with this body: LCRNet (global descriptors + matching), LCRNet_Matching_infer (the same
+    # without the NetVLAD head) and LCRNet_Matching (the evaluation harness' variant: extra outputs, ground-truth labels).  The two
+    # others derive from this one (model_family/LCRNet_Matching*.py) and switch these:
+    global_head = True              # NetVLAD descriptors of both clouds (LCRNet.py:115-122, :296-297)
+    matching_extras = False         # node_matching_scores / node masks / matching_scores in the output (LCRNet_Matching.py:212-214, :274)
+
     def __init__(self, cfg=None):
         super().__init__()
         cfg = cfg or make_cfg()
@@ -126,7 +132,8 @@ class LCRNet(nn.Module):
         self.kpdecoder = KPDecoder(b["init_dim"], b["group_norm"])
         self.node_optimal_transport = LearnableLogOptimalTransport(cfg["model"]["num_sinkhorn_iterations"])
         self.optimal_transport = LearnableLogOptimalTransport(cfg["model"]["num_sinkhorn_iterations"])
-        self.netvlad = NetVLADLoupe2(feature_size=1024, cluster_size=64, output_dim=256, gating=True, add_norm=True, is_training=False)
+        if self.global_head:
+            self.netvlad = NetVLADLoupe2(feature_size=1024, cluster_size=64, output_dim=256, gating=True, add_norm=True, is_training=False)
 
     # ---- LocalGlobalRegistration (geotransformer/local_global_registration.py:134-246; k=1, mutual=False, dustbin) --------
     def _local_global_registration(self, ref_knn_points, src_knn_points, ref_masks, src_masks, log_scores):
@@ -191,25 +198,37 @@ class LCRNet(nn.Module):
         if P == 1:
             n0, n1 = lens_c
             pos_c, anc_c = feats_c[:n0].contiguous(), feats_c[n0:n0 + n1].contiguous()
-            e0, e1 = self.transformer(points_c[:n0].contiguous(), points_c[n0:n0 + n1].contiguous(), pos_c, anc_c)
+            e0, e1, t0, t1 = self.transformer(points_c[:n0].contiguous(), points_c[n0:n0 + n1].contiguous(), pos_c, anc_c, return_pos_emb=True)
             enhanced = torch.cat([e0, e1], 0)
+            emb = [(t0, t1)]
         else:
             # rows of all first clouds / all second clouds, stacked: every Linear and LayerNorm of the transformer runs once
             idx0 = torch.cat([torch.arange(off_c[2 * p], off_c[2 * p + 1]) for p in range(P)]).to(feats_c.device, non_blocking=True)
             idx1 = torch.cat([torch.arange(off_c[2 * p + 1], off_c[2 * p + 2]) for p in range(P)]).to(feats_c.device, non_blocking=True)
-            e0, e1 = self.transformer(points_c[idx0], points_c[idx1], feats_c[idx0], feats_c[idx1], pos_lens, anc_lens)
+            e0, e1, t0, t1 = self.transformer(points_c[idx0], points_c[idx1], feats_c[idx0], feats_c[idx1], pos_lens, anc_lens, return_pos_emb=True)
             enhanced = torch.empty((n_c, e0.shape[1]), dtype=e0.dtype, device=e0.device)
             enhanced[idx0] = e0
             enhanced[idx1] = e1
-        g = self.netvlad.describe(feats_c[:n_c], lens_c)            # pre-transformer features (LCRNet.py:296-297)
+            po, ao = [0], [0]
+            for p in range(P):
+                po.append(po[-1] + pos_lens[p])
+                ao.append(ao[-1] + anc_lens[p])
+            emb = [(t0[po[p]:po[p + 1]], t1[ao[p]:ao[p + 1]]) for p in range(P)]
+        g = self.netvlad.describe(feats_c[:n_c], lens_c) if self.global_head else None      # pre-transformer features (LCRNet.py:296-297)
         outs = []
         for p in range(P):
             a0, a1, a2 = off_c[2 * p], off_c[2 * p + 1], off_c[2 * p + 2]
-            outs.append({"pos_feature_global": g[2 * p:2 * p + 1], "anc_feature_global": g[2 * p + 1:2 * p + 2],
-                         "ori_pos_points_c": points_c[a0:a1], "ori_anc_points_c": points_c[a1:a2],
-                         "pos_feats_c_enhanced": enhanced[a0:a1], "anc_feats_c_enhanced": enhanced[a1:a2]})
+            o = {"ori_pos_points_c": points_c[a0:a1], "ori_anc_points_c": points_c[a1:a2],
+                 "pos_feats_c_enhanced": enhanced[a0:a1], "anc_feats_c_enhanced": enhanced[a1:a2],
+                 "pos_emb": emb[p][0][None], "anc_emb": emb[p][1][None]}
+            if g is not None:
+                o["pos_feature_global"], o["anc_feature_global"] = g[2 * p:2 * p + 1], g[2 * p + 1:2 * p + 2]
+            outs.append(o)
         if not pose:
             outs[0]["feats_list"] = feats_list
+            if not self.matching_extras:
+                for o in outs:
+                    o.pop("pos_emb"), o.pop("anc_emb")
             return outs
 
         # ---- KeypointDetection tail (LCRNet.py:152-159): once over the stack
@@ -240,6 +259,9 @@ class LCRNet(nn.Module):
             c = 2 * p
             outs[p].update({"shifted_pos_points_c": vd["shifted_points_c"][sl(off_c, c)], "shifted_anc_points_c": vd["shifted_points_c"][sl(off_c, c + 1)],
                             "length": vd["length"][c:c + 2], "feats_c": vd["feats_c"][off_m[c]:off_m[c + 2]]})
+            if not self.matching_extras:
+                for k in ("node_matching_scores", "pos_node_masks", "anc_node_masks", "pos_emb", "anc_emb"):
+                    outs[p].pop(k, None)
         return outs
 
     def _dense_matching_group(self, outs, P, pts_f, feats_f, off_f, vd, off_m):
@@ -305,7 +327,11 @@ class LCRNet(nn.Module):
                 "node_corr_scores": nscore[q], "pos_feats_f": feats_f[off_f[c]:off_f[c + 1]], "anc_feats_f": feats_f[off_f[c + 1]:off_f[c + 2]],
                 "pos_node_corr_knn_points": pkp[q], "anc_node_corr_knn_points": akp[q], "pos_node_corr_knn_masks": pkm[q],
                 "anc_node_corr_knn_masks": akm[q], "matching_scores": ms[q],
-                "pos_corr_points": rp, "anc_corr_points": sp, "corr_scores": sc, "estimated_transform": T})
+                "pos_corr_points": rp, "anc_corr_points": sp, "corr_scores": sc, "estimated_transform": T,
+                "node_matching_scores": ns[p, :m[c] + 1, :m[c + 1] + 1] if Mx == m[c] and Nx == m[c + 1] else
+                torch.cat([torch.cat([ns[p, :m[c], :m[c + 1]], ns[p, :m[c], Nx:Nx + 1]], 1),
+                           torch.cat([ns[p, Mx:Mx + 1, :m[c + 1]], ns[p, Mx:Mx + 1, Nx:Nx + 1]], 1)], 0),
+                "pos_node_masks": parts[c][0], "anc_node_masks": parts[c + 1][0]})
 
     def _dense_matching(self, out, pos_f, anc_f, pos_ff, anc_ff, pos_nodes, anc_nodes, pos_fc, anc_fc):
         K = self.num_points_in_patch
@@ -330,7 +356,8 @@ class LCRNet(nn.Module):
             "pos_node_corr_indices": pi, "anc_node_corr_indices": ai, "node_corr_scores": node_corr_scores,
             "pos_feats_f": pos_ff, "anc_feats_f": anc_ff, "pos_node_corr_knn_points": pkp, "anc_node_corr_knn_points": akp,
             "pos_node_corr_knn_masks": pkm, "anc_node_corr_knn_masks": akm, "matching_scores": ms,
-            "pos_corr_points": rp, "anc_corr_points": sp, "corr_scores": sc, "estimated_transform": T})
+            "pos_corr_points": rp, "anc_corr_points": sp, "corr_scores": sc, "estimated_transform": T,
+            "node_matching_scores": ns[0], "pos_node_masks": pos_nm, "anc_node_masks": anc_nm})
 
 
 def create_model(cfg=None):

@@ -106,9 +106,10 @@ class ThDRoFormer(nn.Module):
         self.transformer = RPEConditionalTransformer(["self", "cross"] * num_layers, hidden_dim, num_heads)
         self.out_proj = nn.Linear(hidden_dim, output_dim)
 
-    def forward(self, ref_points, src_points, ref_feats, src_feats, ref_lens=None, src_lens=None):
+    def forward(self, ref_points, src_points, ref_feats, src_feats, ref_lens=None, src_lens=None, return_pos_emb=False):
         """(N,3), (M,3), (N,C), (M,C)  [a leading batch dim of 1 as in the reference is accepted] -> (N,out), (M,out).
-        ref_lens / src_lens (host sequences, one entry per pair): the inputs are the stacks of P pairs' first / second clouds."""
+        ref_lens / src_lens (host sequences, one entry per pair): the inputs are the stacks of P pairs' first / second clouds.
+        return_pos_emb: also return the rotary angles theta of both clouds (thdroformer_linear.py:94-95)."""
         squeeze = ref_points.dim() == 3
         if squeeze:
             ref_points, src_points, ref_feats, src_feats = ref_points[0], src_points[0], ref_feats[0], src_feats[0]
@@ -118,4 +119,6 @@ class ThDRoFormer(nn.Module):
         f0, f1 = self.transformer(f0, f1, t0, t1, ref_lens, src_lens)
         f0 = F.linear(f0, self.out_proj.weight, self.out_proj.bias)
         f1 = F.linear(f1, self.out_proj.weight, self.out_proj.bias)
+        if return_pos_emb:
+            return (f0[None], f1[None], t0[None], t1[None]) if squeeze else (f0, f1, t0, t1)
         return (f0[None], f1[None]) if squeeze else (f0, f1)

@@ -48,3 +48,20 @@ def test_snapshot_roundtrip_like_base_tester(tmp_path):
     assert torch.equal(gd.state_dict()["encoder.encoder3_2.KPConv.kernel_points"], sd["encoder.encoder3_2.KPConv.kernel_points"])
     res2 = load_snapshot(full, str(path), strict=True)
     assert not res2.missing_keys and not res2.unexpected_keys
+
+
+def test_matching_model_layouts():
+    """The two registration entry points (model_family/LCRNet_Matching.py — test_loop_closure.py:13 — and LCRNet_Matching_infer.py —
+    infer_registration.py:11): both named LCRNet_Matching like the reference's, both with the reference class' key set = LCRNet's
+    minus the NetVLAD head; the full checkpoint loads into them with strict=False and exactly the netvlad.* keys unexpected."""
+    from lcrnet_amd.model_family import LCRNet, LCRNet_Matching, LCRNet_Matching_infer
+    from lcrnet_amd.weights import seeded_state_dict
+    man = _manifest()
+    full_sd = seeded_state_dict(LCRNet().state_dict(), 5)
+    for mod, key in ((LCRNet_Matching, "LCRNet_Matching"), (LCRNet_Matching_infer, "LCRNet_Matching_infer")):
+        m = mod.create_model()
+        assert type(m).__name__ == "LCRNet_Matching"
+        assert len(man[key]) == 354
+        _check(m, man[key])
+        res = m.load_state_dict(full_sd, strict=False)
+        assert not res.missing_keys and all(k.startswith("netvlad.") for k in res.unexpected_keys) and len(res.unexpected_keys) == 19
