@@ -107,6 +107,7 @@ typedef struct LcrRadiusQuery {
     int32_t*       out_idx32;  /* [nq_cap, limit] */
     const int32_t* q_order;    /* processing order or NULL */
 } LcrRadiusQuery;
+#define LCR_RADIUS_QUERY_MULTI_MAX 12   /* searches per lcr_radius_query_multi launch; longer lists: call it on slices */
 int lcr_radius_query_multi(const LcrRadiusQuery* list, int n, int B, void* stream);
 /* Same build that also writes the cell-sorted processing order (what lcr_support_grid_order returns) into order i32[ns_cap]. */
 int lcr_support_grid_build_ex(const float* s, const int64_t* slen, int B, int64_t ns_cap, float radius,

@@ -9,19 +9,23 @@ from .modules.kpconv import ConvBlock, ResidualBlock, StageContext
 
 
 def segment_min_rows(data_dict, stages=4):
-    """Rows of the shortest GroupNorm segment per stage, from HOST data only (None = unknown): the segments are the clouds of
-    'lengths_host' or equal-sized groups of consecutive clouds (the two clouds of a registration pair)."""
-    seg, host = data_dict.get("segment_lengths"), data_dict.get("lengths_host")
-    if seg is None or host is None:
+    """Rows of the shortest GroupNorm segment per stage, from HOST data only (None = unknown — the normalise-on-load GEMM, whose
+    64-row blocks may span at most two segments, is then not used).  Known exactly in two cases only: the caller states the rows of
+    every segment ('segment_rows_host': per stage a list of host ints — LCRNet.forward_pairs does, for its per-pair segments), or
+    the segments are the clouds themselves (as many segments as entries of 'lengths_host').  Any other grouping of clouds into
+    segments is NOT guessed."""
+    seg, host, stated = data_dict.get("segment_lengths"), data_dict.get("lengths_host"), data_dict.get("segment_rows_host")
+    if seg is None:
         return [None] * stages
     rows = []
     for i in range(stages):
-        n_seg, clouds = int(seg[i].numel()), [int(v) for v in host[i]]
-        if n_seg == 0 or len(clouds) % n_seg:
+        n_seg = int(seg[i].numel())
+        if stated is not None and len(stated[i]) == n_seg and n_seg > 0:
+            rows.append(min(int(v) for v in stated[i]))
+        elif host is not None and n_seg > 0 and len(host[i]) == n_seg:
+            rows.append(min(int(v) for v in host[i]))
+        else:
             rows.append(None)
-            continue
-        per = len(clouds) // n_seg
-        rows.append(min(sum(clouds[k:k + per]) for k in range(0, len(clouds), per)))
     return rows
 
 

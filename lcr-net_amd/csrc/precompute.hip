@@ -277,8 +277,11 @@ extern "C" int lcr_precompute_batch(const float* points0, const int64_t* lengths
     }
     r *= 2.f;
   }
-  if (n_search > 0) {
-    rc = TURN(lcr_radius_query_multi(searches, n_search, B, main));
+  // up to 3*S - 2 searches (S self + S-1 subsampling + S-1 upsampling = 22 at LCR_MAX_STAGES): one launch per slice of
+  // LCR_RADIUS_QUERY_MULTI_MAX — the reference's 4-stage collate (10 searches) is one launch
+  for (int o = 0; o < n_search; o += LCR_RADIUS_QUERY_MULTI_MAX) {
+    const int c = n_search - o < LCR_RADIUS_QUERY_MULTI_MAX ? n_search - o : LCR_RADIUS_QUERY_MULTI_MAX;
+    rc = TURN(lcr_radius_query_multi(searches + o, c, B, main));
     if (rc) return rc;
   }
   for (int i = 0; i < S && getenv("LCR_PRE_FORK"); ++i) {

@@ -525,7 +525,7 @@ __global__ __launch_bounds__(RS_WAVES * 64) void k_radius_query(RqSearch A, int 
 // All searches of a collate in ONE launch (int32 rows): every wavefront works through its share of search 0, then of search 1, ...
 // without a barrier in between, so the small coarse-stage searches — alone they sit on the ~10 us launch floor with a handful of
 // workgroups — ride in the tail of the large ones.
-constexpr int RQ_MAX_SEARCHES = 12;
+constexpr int RQ_MAX_SEARCHES = LCR_RADIUS_QUERY_MULTI_MAX;
 struct RqMulti {
   int      n, B;
   RqSearch s[RQ_MAX_SEARCHES];

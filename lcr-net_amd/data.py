@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .modules.ops import SupportGrid, grid_subsample, grid_subsample_device, radius_search
+from .modules.ops import SupportGrid, finish_deferred, grid_subsample, grid_subsample_device, radius_search, radius_search_deferred
 
 STATUS_KEY_OVERFLOW = 1
 STATUS_LEN_MISMATCH = 2
@@ -33,14 +33,20 @@ def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, 
         points_list.append(points)
         lengths_list.append(lengths)
         voxel_size *= 2
+    pending, slots = [], []                                  # the ten searches are issued back to back, read back ONCE
     for i in range(num_stages):
         cur_p, cur_l = points_list[i], lengths_list[i]
-        neighbors_list.append(radius_search(cur_p, cur_p, cur_l, cur_l, radius, neighbor_limits[i]))
+        pending.append(radius_search_deferred(cur_p, cur_p, cur_l, cur_l, radius, neighbor_limits[i]))
+        slots.append(neighbors_list)
         if i < num_stages - 1:
             sub_p, sub_l = points_list[i + 1], lengths_list[i + 1]
-            subsampling_list.append(radius_search(sub_p, cur_p, sub_l, cur_l, radius, neighbor_limits[i]))
-            upsampling_list.append(radius_search(cur_p, sub_p, cur_l, sub_l, radius * 2, neighbor_limits[i + 1]))
+            pending.append(radius_search_deferred(sub_p, cur_p, sub_l, cur_l, radius, neighbor_limits[i]))
+            slots.append(subsampling_list)
+            pending.append(radius_search_deferred(cur_p, sub_p, cur_l, sub_l, radius * 2, neighbor_limits[i + 1]))
+            slots.append(upsampling_list)
         radius *= 2
+    for lst, idx in zip(slots, finish_deferred(pending)):
+        lst.append(idx)
     return {"points": points_list, "lengths": lengths_list, "neighbors": neighbors_list,
             "subsampling": subsampling_list, "upsampling": upsampling_list}
 

@@ -70,8 +70,8 @@ class Vote_Encoder(nn.Module):
         centers = F.neighbor_mean(shifted, knn, pad)
         sub = radius_search(centers, points_c, length, lens_c, self.init_radius * 8, limits[-2], check=False)
         nb = radius_search(centers, centers, length, length, self.init_radius * 16, limits[-1], check=False)
-        if pairs > 1:
-            q_ctx, s_ctx = StageContext(length.view(pairs, 2).sum(1)), StageContext(lens_c.view(pairs, 2).sum(1))
+        if pairs > 1:                                                  # min_rows unknown on the host here (node counts live on the device):
+            q_ctx, s_ctx = StageContext(length.view(pairs, 2).sum(1)), StageContext(lens_c.view(pairs, 2).sum(1))   # plain GroupNorm pass
         else:
             q_ctx = s_ctx = StageContext(None)
         f = self.encoder6_1(feats, centers, points_c, sub, q_ctx, s_ctx)
@@ -188,6 +188,9 @@ class LCRNet(nn.Module):
         if P > 1 and "segment_lengths" not in data_dict:             # GroupNorm per pair at every stage
             dd = dict(data_dict)
             dd["segment_lengths"] = [l.view(P, 2).sum(1) for l in lens_dev]
+            host = data_dict.get("lengths_host")
+            if host is not None:                                     # rows of every pair segment, stated exactly (normalise-on-load gate)
+                dd["segment_rows_host"] = [[int(h[2 * p]) + int(h[2 * p + 1]) for p in range(P)] for h in host]
         feats_list = self.encoder(feats, dd)
         feats_c = feats_list[-1]
         off_c = [0]

@@ -27,11 +27,14 @@ class StageContext:
         self.order = order
         self.min_rows = min_rows        # host int: rows of the shortest segment when known (None with segments = unknown)
 
-    def norm_on_load(self, K, N):
-        """May ResidualBlock fold norm_conv + LeakyReLU into unary2's GEMM?  (segments of >= 64 rows, the light GEMM form)"""
+    def norm_on_load(self, K, N, M):
+        """May ResidualBlock fold norm_conv + LeakyReLU into unary2's GEMM?  (segments of >= 64 rows, the light GEMM form).  The
+        same rule as the native driver's (csrc/encoder.hip: min_rows >= 64, min_rows = the stack's rows when there is one segment),
+        so the two drivers take the same numeric path for every input."""
         if _NO_NORM_ON_LOAD or not F.gemm_anorm_ok(K, N):
             return False
-        return self.seg_len is None or (self.min_rows is not None and self.min_rows >= F.ANORM_MIN_SEG_ROWS)
+        rows = M if self.seg_len is None else self.min_rows
+        return rows is not None and rows >= F.ANORM_MIN_SEG_ROWS
 
 
 _NO_NORM_ON_LOAD = bool(os.environ.get("LCR_NO_NORM_ON_LOAD"))     # A/B switch
@@ -117,7 +120,7 @@ class ResidualBlock(nn.Module):
             x, pos = self.unary1(s_feats, s_ctx, want_pos=True)                       # Linear+GN+LeakyReLU, pos flags for the count
         x, stats = self.KPConv.forward_raw(x, q_points, s_points, neighbor_indices, s_pos=pos, seg_len=q_ctx.seg_len, groups=g,
                                            order=q_ctx.order)
-        if q_ctx.norm_on_load(x.shape[1], self.out_channels):
+        if q_ctx.norm_on_load(x.shape[1], self.out_channels, x.shape[0]):
             # norm_conv + LeakyReLU applied while unary2's GEMM stages its A tiles: no stand-alone GroupNorm pass over x
             y, ystats = F.gemm_anorm(x, stats, self.norm_conv.norm.weight, self.norm_conv.norm.bias, g, self.unary2.mlp.weight,
                                      bias=self.unary2.mlp.bias, seg_len=q_ctx.seg_len, groups=g)

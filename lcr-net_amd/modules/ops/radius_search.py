@@ -40,7 +40,7 @@ def _call(q_points, s_points, q_lengths, s_lengths, radius, limit, want64, want3
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     out64 = torch.empty((nq, limit), dtype=torch.int64, device=dev) if (want64 and limit > 0) else None
     out32 = torch.empty((nq, limit), dtype=torch.int32, device=dev) if (want32 and limit > 0) else None
-    cnt = torch.empty((nq,), dtype=torch.int32, device=dev) if want_cnt else None
+    cnt = torch.zeros((nq,), dtype=torch.int32, device=dev) if want_cnt else None      # rows beyond sum(q_lengths) are never written
     _lib.check(L.lcr_radius_search(_lib.ptr(q_points), _lib.ptr(s_points), _lib.ptr(q_lengths), _lib.ptr(s_lengths), B,
                                    nq, ns, float(radius), int(limit), _lib.ptr(out64), _lib.ptr(out32), _lib.ptr(cnt),
                                    _lib.ptr(status), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "lcr_radius_search")
@@ -63,6 +63,15 @@ def radius_search(q_points, s_points, q_lengths, s_lengths, radius, neighbor_lim
     ``neighbor_limit`` columns (the extra ones are pure padding).
     Rows are ascending in (d², index) and padded with M = s_points.shape[0]; the result is contiguous.
     """
+    pending = radius_search_deferred(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, dtype)
+    return finish_deferred([pending])[0] if check else pending[0]
+
+
+def radius_search_deferred(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, dtype=torch.int64):
+    """The launches of `radius_search` without its read-back: (indices [N, limit], counts, status word, limit).  `finish_deferred`
+    turns a list of these into the reference-shaped results with ONE host synchronisation for all of them (a collate runs ten
+    searches).  neighbor_limit <= 0 (full width) needs the widest neighbourhood first and therefore synchronises here; its count
+    pass is reused for the result."""
     _check(q_points, s_points, q_lengths, s_lengths)
     limit = int(neighbor_limit)
     want64 = dtype == torch.int64
@@ -70,17 +79,32 @@ def radius_search(q_points, s_points, q_lengths, s_lengths, radius, neighbor_lim
         cnt = radius_count(q_points, s_points, q_lengths, s_lengths, radius)
         limit = int(cnt.max().item()) if cnt.numel() else 0   # host sync: output width is data dependent
         if limit == 0:
-            return torch.empty((q_points.shape[0], 0), dtype=dtype, device=q_points.device)
-    out64, out32, cnt, status = _call(q_points, s_points, q_lengths, s_lengths, radius, limit, want64, not want64, check)
-    out = out64 if want64 else out32
-    if check:
-        mx = cnt.max().to(torch.int32).reshape(1) if cnt.numel() else torch.zeros(1, dtype=torch.int32, device=out.device)
-        st, width = torch.cat([status, mx]).tolist()             # one read-back: status word + widest neighbourhood
+            empty = torch.empty((q_points.shape[0], 0), dtype=dtype, device=q_points.device)
+            return empty, cnt, torch.zeros(1, dtype=torch.int32, device=q_points.device), 0
+        out64, out32, _, status = _call(q_points, s_points, q_lengths, s_lengths, radius, limit, want64, not want64, False)
+        return (out64 if want64 else out32), cnt, status, limit
+    out64, out32, cnt, status = _call(q_points, s_points, q_lengths, s_lengths, radius, limit, want64, not want64, True)
+    return (out64 if want64 else out32), cnt, status, limit
+
+
+def finish_deferred(pending):
+    """[(indices, counts, status, limit), ...] -> [indices cut to (N, min(limit, widest neighbourhood))], raising on a lengths /
+    rows mismatch like the reference op's TORCH_CHECKs.  One read-back for the whole list."""
+    if not pending:
+        return []
+    dev = pending[0][0].device
+    words = []
+    for out, cnt, status, limit in pending:
+        mx = cnt.max().to(torch.int32).reshape(1) if cnt.numel() else torch.zeros(1, dtype=torch.int32, device=dev)
+        words += [status.reshape(1), mx]
+    host = torch.cat(words).tolist()
+    res = []
+    for k, (out, cnt, status, limit) in enumerate(pending):
+        st, width = host[2 * k], host[2 * k + 1]
         if st != 0:
             raise RuntimeError("radius_search: lengths do not match the point tensors (status %d)" % st)
-        if width < limit:
-            out = out[:, :width].contiguous()
-    return out
+        res.append(out[:, :width].contiguous() if width < limit else out)
+    return res
 
 
 class SupportGrid:

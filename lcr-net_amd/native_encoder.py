@@ -89,7 +89,10 @@ def eligible(feats, data_dict):
     P, N, S = data_dict["points"], data_dict["neighbors"], data_dict["subsampling"]
     return (feats.is_cuda and feats.dtype == torch.float32 and feats.dim() == 2 and feats.shape[1] == 1 and len(P) == 4 and len(N) == 4
             and len(S) == 3 and all(t.dtype == torch.int32 and t.is_contiguous() for t in list(N) + list(S))
-            and all(t.dtype == torch.float32 and t.is_contiguous() for t in P))
+            and all(t.dtype == torch.float32 and t.is_contiguous() for t in P)
+            # the drop-in collate cuts every list to its own densest neighbourhood (like the reference); the native driver wants the
+            # self and subsampling lists of a stage equally wide — otherwise the module tree runs the pass
+            and all(int(S[i].shape[1]) == int(N[i].shape[1]) and int(S[i].shape[0]) == int(P[i + 1].shape[0]) for i in range(3)))
 
 
 def forward(enc, feats, data_dict):

@@ -174,9 +174,11 @@ class DescriptorPipeline:
         self.enc_streams = None      # set by enable_dual_encoder(): consecutive batches' encoders on alternating streams
 
     def close(self):
-        """Give the pipeline's native streams back (idempotent; see `release_streams`).  The pipeline cannot run afterwards."""
+        """Give the pipeline's native streams back (idempotent; see `release_streams`).  The pipeline cannot run afterwards
+        (`run` raises)."""
         release_streams(self._streams)
         self._streams, self.pre_streams, self.pre_stream, self.enc_streams = [], [], None, None
+        self._closed = True
 
     def __enter__(self):
         return self
@@ -233,6 +235,8 @@ class DescriptorPipeline:
         under `torch.cuda.stream(stream)`) then leaves the caller's hardware queue free of barrier packets: that queue is shared with
         one of the pipeline's four streams (5 streams, 4 hardware queues), and a wait-for-the-encoder parked in it stalls whatever
         else runs there."""
+        if getattr(self, "_closed", False):
+            raise RuntimeError("DescriptorPipeline is closed")      # its streams were given back: threaded mode would start no producer and wait forever
         if not self.overlap:
             for pts, lens in batches:
                 yield self.encode(self.preprocess(pts, lens))

@@ -83,6 +83,25 @@ def test_native_precompute_ragged_batches(sizes):
             assert x.shape == y.shape and torch.equal(x, y), key
 
 
+@pytest.mark.parametrize("stages", [5, 6])
+def test_native_precompute_more_searches_than_one_multi_launch(stages):
+    """num_stages 5 / 6 with upsampling = 13 / 16 searches, more than one lcr_radius_query_multi launch takes
+    (LCR_RADIUS_QUERY_MULTI_MAX = 12): the native call issues the list in slices and returns the op-by-op lists."""
+    from lcrnet_amd.data import precompute_batch
+    scans = [load_scan(n) for n in ["003854", "000958"]]
+    pts = torch.from_numpy(np.concatenate(scans)).cuda()
+    lens = torch.tensor([len(s) for s in scans], dtype=torch.int64, device="cuda")
+    limits = [30] * stages
+    a = precompute_batch(pts, lens, stages, 0.3, 1.275, limits, upsampling=True, native=False)
+    b = precompute_batch(pts, lens, stages, 0.3, 1.275, limits, upsampling=True, native=True)
+    torch.cuda.synchronize()
+    assert a["lengths_host"] == b["lengths_host"] and len(b["upsampling"]) == stages - 1
+    for key in ("points", "lengths", "neighbors", "subsampling", "upsampling"):
+        assert len(a[key]) == len(b[key])
+        for x, y in zip(a[key], b[key]):
+            assert x.shape == y.shape and torch.equal(x, y), key
+
+
 def test_raw_scan_mode_of_the_native_precompute():
     """Raw scans -> stage 0 -> everything in ONE native call == voxelize_raw_scans followed by precompute_batch; a capacity guess
     that is too small is detected on the device and the call repeats with the safe bound."""
