@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=5, help="the timed K-step block runs this many times back to back (each bracketed by "
+                    "barrier + synchronize); the line reports the MEDIAN block, ms_per_step_min / _max the spread")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-upsampling", action="store_true", help="skip the 3 decoder-only upsampling searches")
     ap.add_argument("--no-overlap", action="store_true", help="run pre-processing and encoder on one stream (no pipelining)")
@@ -151,6 +153,60 @@ def cpu_baseline(scans):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def _cpulist(text):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus += list(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def gpu_numa_node(index):
+    """NUMA node of GPU `index` from sysfs (PCI address from the device properties), or None."""
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        addr = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % addr).read())
+        return node if node >= 0 else None
+    except Exception:
+        return None
+
+
+def rank_cpus(local, n_local, single_device=False):
+    """The host cores of local rank `local` of `n_local`: the cores of its GPU's NUMA node, shared out among the ranks whose GPUs sit
+    on that node; without NUMA information an equal contiguous share of the cores this process may use.  Every rank runs ~6 busy
+    host threads (2 pre-processing issuers, 2 encoder issuers, the consumer, RCCL's proxy): they should neither migrate across
+    sockets nor pile onto one rank's cores."""
+    allowed = sorted(os.sched_getaffinity(0))
+    nodes = [None if single_device else gpu_numa_node(r) for r in range(n_local)]
+    me = nodes[local]
+    if me is not None:
+        try:
+            node_cpus = [c for c in _cpulist(open("/sys/devices/system/node/node%d/cpulist" % me).read()) if c in set(allowed)]
+            peers = [r for r in range(n_local) if nodes[r] == me]
+            k = peers.index(local)
+            share = len(node_cpus) // len(peers)
+            if share >= 1:
+                return node_cpus[k * share:(k + 1) * share], "numa node %d, share %d/%d" % (me, k + 1, len(peers))
+        except Exception:
+            pass
+    share = max(1, len(allowed) // n_local)
+    return allowed[(local * share) % len(allowed):][:share], "even split of %d cores" % len(allowed)
+
+
+def bind_rank(local, n_local, single_device=False):
+    """Pin this rank process (and the threads it starts later) to its cores and cap the math libraries' thread pools."""
+    cpus, how = rank_cpus(local, n_local, single_device)
+    try:
+        os.sched_setaffinity(0, cpus)
+    except Exception as e:                                             # containers may forbid it: not fatal
+        how = "not bound (%s)" % e
+    torch.set_num_threads(max(1, min(8, len(cpus))))                    # torch intra-op pool (host-side tensor ops are tiny here)
+    return len(cpus), how
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N rank processes (one per GPU) with the torchrun environment
     contract and wait for them; rank 0's JSON line goes to this process's stdout."""
@@ -167,10 +223,21 @@ def spawn_ranks(args):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        env.setdefault("OMP_NUM_THREADS", "8")                          # before the rank imports torch / numpy
+        env.setdefault("MKL_NUM_THREADS", "8")
+        # rank 0's JSON line is the only thing on stdout; the other ranks keep stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
-    for p in procs:
-        rc = p.wait() or rc
+    try:
+        for p in procs:
+            rc = p.wait(timeout=float(os.environ.get("LCR_BENCH_RANK_TIMEOUT", "3600"))) or rc
+    except subprocess.TimeoutExpired:
+        rc = 124
+    finally:
+        for p in procs:                                                 # a rank that died must not leave its peers in a barrier
+            if p.poll() is None:
+                p.kill()
     sys.exit(rc)
 
 
@@ -202,6 +269,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         single = bool(os.environ.get("LCR_BENCH_SINGLE_DEVICE"))          # dry run of the N>1 code path on a 1-GPU box
         backend = os.environ.get("LCR_BENCH_BACKEND", "gloo" if single else "nccl")   # "nccl" is RCCL on ROCm
+        n_local = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        bound = bind_rank(local, n_local, single)                       # both launch forms (torchrun / own spawn) pass through here
         if single:
             local = 0
         torch.cuda.set_device(local)
@@ -211,6 +280,7 @@ def main():
             dist.init_process_group(backend=backend)
     else:
         torch.cuda.set_device(0)
+        bound = (len(os.sched_getaffinity(0)), "single rank: not bound")
     dev = torch.device("cuda", torch.cuda.current_device())
 
     from lcrnet_amd import functional as F
@@ -269,29 +339,37 @@ def main():
                 nnz[(sp[i + 1], sp[i])] = int((dd0["subsampling"][i] < sp[i]).sum())
         del dd0
     stage_points = stage_points_all[0]
-    # ---- timed region: exactly K steps between barrier + synchronize
-    timer = F.KernelTimer({"kpconv_aggregate", "gemm", "radius_query"})
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    F.set_timer(timer)
-    t0 = time.perf_counter()
-    desc = run_steps(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    F.set_timer(None)
+    # ---- timed region: exactly K steps between barrier + synchronize — R such blocks back to back, the line reports the MEDIAN one
+    blocks = []
+    R = max(1, args.repeats)
+    for rep in range(R):
+        timer = F.KernelTimer({"kpconv_aggregate", "gemm", "radius_query"})
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        if not os.environ.get("LCR_BENCH_NO_KTIMER"):                  # A/B: what the per-launch events cost the timed region
+            F.set_timer(timer)
+        t0 = time.perf_counter()
+        desc = run_steps(args.steps)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt_r = time.perf_counter() - t0
+        F.set_timer(None)
+        if world > 1:
+            t = torch.tensor([dt_r], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_r = float(t.item())
+        blocks.append((dt_r, timer))
+    order_r = sorted(range(R), key=lambda i: blocks[i][0])
+    dt, timer = blocks[order_r[(R - 1) // 2]]                            # median block (lower median for even R)
+    dt_min, dt_max = blocks[order_r[0]][0], blocks[order_r[-1]][0]
     if os.environ.get("LCR_PIPE_STATS") and rank == 0:
         print("pipeline host threads:", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in pipe.stats.items()}, file=sys.stderr)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
     iso = iso_rs = None
-    summ = timer.summary() if rank == 0 else None     # read the timed region's log before anything else is logged
-    if rank == 0:
+    summ = timer.records() if rank == 0 else None     # read the timed region's log before anything else is logged
+    if rank == 0 and not os.environ.get("LCR_BENCH_NO_KTIMER"):
         # the same launches once more with nothing else on the GPU (one stream, outside the timed region): in the timed
         # region four streams share the CUs, so a launch's event-to-event duration includes time it spent waiting for them
         iso_timer = F.KernelTimer({"gemm", "radius_query"})
@@ -304,24 +382,34 @@ def main():
             pipe.encode(dd_iso)
         torch.cuda.synchronize()
         F.set_timer(None)
-        s_iso = iso_timer.summary()
+        s_iso = iso_timer.records()
         g = s_iso["gemm"]
-        iso = sum(2.0 * m[0] * m[1] * m[2] for _, m in g) / sum(t for t, _ in g) / 1e12
-        iso_rs = sum(t for t, _ in s_iso["radius_query"]) / 3.0
+        iso = sum(2.0 * m[0] * m[1] * m[2] for _, _, m in g) / sum((k if k is not None else b) for b, k, _ in g) / 1e12
+        iso_rs = sum((k if k is not None else b) for b, k, _ in s_iso["radius_query"]) / 3.0
+    if rank == 0 and os.environ.get("LCR_BENCH_NO_KTIMER"):            # A/B run without per-launch events: the headline only
+        print(json.dumps({"value": round(world * BATCH * args.steps / dt, 3), "ms_per_step": round(dt / args.steps * 1e3, 3),
+                          "ms_per_step_min": round(dt_min / args.steps * 1e3, 3), "ms_per_step_max": round(dt_max / args.steps * 1e3, 3), "ktimer": False}), flush=True)
+        rank = -1
     if rank == 0:
         assert torch.isfinite(desc).all() and abs(float(desc.norm(dim=1).mean()) - 1.0) < 1e-3
         # ---- roofline of the dominant kernel family, measured live with HIP events on the launch stream.
         # Dominant by time = lcr::k_gemm_f32 (all tile variants; profiles/): compute-bound on the fp32 matrix cores, so
         # "achieved" = algorithmic flops (2*M*N*K per launch) / launch time vs the 157.3 TFLOP/s dense fp32 MFMA peak.
-        gem, agg, rsq = summ["gemm"], summ["kpconv_aggregate"], summ["radius_query"]
+        # Two clocks per launch (lcr_ktimer_read2): the kernel's OWN begin-to-end time (hipExtLaunchKernel's start / stop events: what
+        # rocprofv3's kernel trace reports — `achieved` / `frac` below follow from profiles/*_kernel_summary.md) and the time between
+        # two events bracketing the launch on its stream (`*_event_bracketed`: includes the wait behind the other three streams).
+        kown = lambda recs: sum((k if k is not None else b) for b, k, _ in recs)
+        gem_r, agg_r, rsq_r = summ["gemm"], summ["kpconv_aggregate"], summ["radius_query"]
+        tk_gemm, tk_agg, tk_rs = kown(gem_r), kown(agg_r), kown(rsq_r)
+        gem, agg, rsq = [(b, m) for b, _, m in gem_r], [(b, m) for b, _, m in agg_r], [(b, m) for b, _, m in rsq_r]
         t_gemm, t_agg, t_rs = sum(t for t, _ in gem), sum(t for t, _ in agg), sum(t for t, _ in rsq)
         flops = sum(2.0 * m[0] * m[1] * m[2] for _, m in gem)
         # KPConv layer = aggregation + its (15C x Cout) contraction, against SURVEY §8d's a-4 bytes: indices + query/support xyz +
         # support features + OUTPUT features + weights (the materialised (M,15C) aggregate is NOT algorithmic traffic)
-        contr = [(t, m) for t, m in gem if m[2] % 15 == 0 and m[2] >= 480]
+        contr = [((k if k is not None else b), m) for b, k, m in gem_r if m[2] % 15 == 0 and m[2] >= 480]
         bytes_kp = sum(M * H * isz + (M + Ns) * 12 + Ns * C * 4 for _, (M, Ns, H, C, isz) in agg) + \
             sum(M * N * 4 + K * N * 4 for _, (M, N, K) in contr)
-        t_kp = t_agg + sum(t for t, _ in contr)
+        t_kp = tk_agg + sum(t for t, _ in contr)
         # the aggregation is MFMA work too (D[16 kernel points x C] += W[16 x 4] F[4 x C] per four neighbours): 2*15*nnz*C flops
         flops_agg = sum(2.0 * 15 * nnz.get((M, Ns), M * H) * C for _, (M, Ns, H, C, isz) in agg)
         n_search = 7 if args.no_upsampling else 10
@@ -334,27 +422,31 @@ def main():
             traffic_rs = (pmc.get("k_radius_query_multi") or pmc.get("k_radius_query") or {}).get("traffic_bytes")
             traffic_src = "profiles/pmc_traffic.json: separate rocprofv3 --pmc passes of this command (2*FETCH_SIZE + WRITE_SIZE per launch), not measured in this run"
         roof = {"bound": "mfma", "kernel": "lcr::k_gemm_f32 (fp32 MFMA, %d launches/step)" % (len(gem) // max(args.steps, 1)),
-                "achieved": round(flops / t_gemm / 1e12, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(flops / t_gemm / 1e12 / FP32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "achieved": round(flops / tk_gemm / 1e12, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(flops / tk_gemm / 1e12 / FP32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "clock": "kernel begin-to-end (hipExtLaunchKernel start/stop events) over the timed region, four streams sharing the CUs",
+                "avg_launch_us": round(tk_gemm / max(len(gem), 1) * 1e6, 2),
+                "achieved_event_bracketed": round(flops / t_gemm / 1e12, 2), "frac_event_bracketed": round(flops / t_gemm / 1e12 / FP32_PEAK_TFLOPS, 4),
+                "avg_launch_us_event_bracketed": round(t_gemm / max(len(gem), 1) * 1e6, 2),
                 "achieved_alone": round(iso, 2), "frac_alone": round(iso / FP32_PEAK_TFLOPS, 4),
-                "avg_launch_us": round(t_gemm / max(len(gem), 1) * 1e6, 2),
                 "gflop_per_launch": round(flops / max(len(gem), 1) / 1e9, 3),
                 "event_time_over_step_time": {"gemm": round(t_gemm / dt, 3), "kpconv_aggregate": round(t_agg / dt, 3), "radius_query": round(t_rs / dt, 3),
                                               "note": "sum of launch-to-completion event times / wall time; streams overlap, so the shares do not add up to 1"},
                 "neighbor": {"kernel": "lcr::k_radius_query[_multi] (%d searches in %d launch(es) per step)" % (n_search, max(1, round(len(rsq) / max(args.steps, 1)))),
                              "bound": "hbm",
                              "algorithmic_mb_per_step": round(bytes_rs / 1e6, 2),
-                             "achieved": round(bytes_rs * args.steps / t_rs / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(bytes_rs * args.steps / t_rs / 1e9 / HBM_PEAK_GBS, 4),
-                             "ms_per_step": round(t_rs / args.steps * 1e3, 4),
+                             "achieved": round(bytes_rs * args.steps / tk_rs / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(bytes_rs * args.steps / tk_rs / 1e9 / HBM_PEAK_GBS, 4),
+                             "ms_per_step": round(tk_rs / args.steps * 1e3, 4),
+                             "ms_per_step_event_bracketed": round(t_rs / args.steps * 1e3, 4),
                              "algorithmic_bytes_per_launch": round(bytes_rs * args.steps / max(len(rsq), 1)), "traffic": traffic_rs,
                              "achieved_alone": round(search_bytes(stage_points, not args.no_upsampling) / iso_rs / 1e9, 1),
                              "frac_alone": round(search_bytes(stage_points, not args.no_upsampling) / iso_rs / 1e9 / HBM_PEAK_GBS, 4),
                              "ms_per_step_alone": round(iso_rs * 1e3, 4)},
                 "aggregation": {"kernel": "lcr::k_kpconv_aggregate (fp32 MFMA 16x16x4, %d launches/step)" % (len(agg) // max(args.steps, 1)), "bound": "mfma",
-                                "achieved": round(flops_agg / t_agg / 1e12, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(flops_agg / t_agg / 1e12 / FP32_PEAK_TFLOPS, 4), "gflop_per_step": round(flops_agg / args.steps / 1e9, 2),
-                                "note": "2*15*nnz*C flops over the valid neighbours; event time inside the pipeline (other streams share the CUs)"},
+                                "achieved": round(flops_agg / tk_agg / 1e12, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(flops_agg / tk_agg / 1e12 / FP32_PEAK_TFLOPS, 4), "gflop_per_step": round(flops_agg / args.steps / 1e9, 2),
+                                "note": "2*15*nnz*C flops over the valid neighbours; kernel begin-to-end time inside the pipeline (other streams share the CUs)"},
                 "whole_step": {"gflop_per_step": round((flops + flops_agg) / args.steps / 1e9, 1), "what": "GEMMs + KPConv aggregation (fp32 MFMA work of a step)",
                                "tflops": round((flops + flops_agg) / dt / 1e12, 2),
                                "frac_of_fp32_mfma_peak": round((flops + flops_agg) / dt / 1e12 / FP32_PEAK_TFLOPS, 4)},
@@ -367,6 +459,8 @@ def main():
             "metric": "scans/s (120k-pt KITTI-shape scan -> 256-D descriptor)",
             "value": round(world * BATCH * args.steps / dt, 3), "unit": "scans/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "repeats": R, "ms_per_step_min": round(dt_min / args.steps * 1e3, 3), "ms_per_step_max": round(dt_max / args.steps * 1e3, 3),
+            "timing": "median of %d back-to-back blocks of %d steps, each bracketed by barrier + synchronize (max over ranks)" % (R, args.steps),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: batch of 8 synthetic 64-beam scans (~120k pts, 0.3 m voxel -> ~16k pts), "
                                    "voxelise + 3 subsamples + %d radius searches + KPConv encoder + NetVLAD, seeded random weights"
@@ -375,7 +469,8 @@ def main():
                        "stage_points_per_batch": stage_points, "distinct_input_batches": nb_in, "neighbor_limits": LIMITS,
                        "streams": "1" if args.no_overlap else ("pre-processing stream (own host thread, 2 batches ahead) + %d encoder stream(s)"
                                                                % (1 if (args.single_encoder or args.no_thread) else 2)),
-                       "parallelism": "scan-parallel x%d, all-gather of descriptors%s" % (world, (" (%s)" % backend) if backend else "")},
+                       "parallelism": "scan-parallel x%d, all-gather of descriptors%s" % (world, (" (%s)" % backend) if backend else ""),
+                       "host": "rank 0 on %d cores (%s)" % bound},
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:

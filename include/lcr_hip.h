@@ -39,6 +39,8 @@ const char* lcr_last_error(void);
  * the logged events and returns the number of records of `kind`. */
 void lcr_ktimer_enable(int on);
 int lcr_ktimer_read(int kind, int max_records, double* seconds, int64_t* meta);
+/* same, plus the kernel's own begin-to-end duration (what a profiler reports; < 0 where a launch site does not record it) */
+int lcr_ktimer_read2(int kind, int max_records, double* seconds, double* seconds_kernel, int64_t* meta);
 /* Diagnostic: one wavefront spinning for `microseconds` on `stream`.  The runtime deals streams to 4 hardware queues; two busy
  * streams on one queue serialise each other.  A short kernel on stream B behind a spin on stream A tells whether A and B share
  * a queue (lcr-net_amd/pipeline.py picks four streams on four queues this way). */

@@ -40,6 +40,7 @@ _SIGS = {
                                    c_int, c_vp, c_vp]),
     "lcr_ktimer_enable": (None, [c_int]),
     "lcr_ktimer_read": (c_int, [c_int, c_int, c_vp, c_vp]),
+    "lcr_ktimer_read2": (c_int, [c_int, c_int, c_vp, c_vp, c_vp]),
     "lcr_encoder_ws_bytes": (c_int, [c_vp, c_vp, c_int, c_size_p]),
     "lcr_encoder_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_size_t, c_vp]),
     "lcr_kpconv_aggregate": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_int, c_vp, c_float, c_vp, c_vp, c_vp, c_vp]),

@@ -1,6 +1,7 @@
 // common.h — shared host/device helpers for liblcr_hip.so (gfx950 only; wave = 64).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
@@ -208,7 +209,22 @@ struct KernelTimerScope {
   hipStream_t st;
   KernelTimerScope(int kind, hipStream_t stream, int64_t m0, int64_t m1, int64_t m2, int64_t m3 = 0, int64_t m4 = 0);
   ~KernelTimerScope();
+  // A second pair of events for the kernel's OWN begin / end timestamps (hipExtLaunchKernel's startEvent / stopEvent: what a
+  // profiler reports as the kernel's duration).  The bracketing pair above also contains the time the launch waited in its queue
+  // behind other streams' kernels; next to each other the two say how much of a launch's latency is the kernel.  False when
+  // timing is off.
+  bool kernel_events(hipEvent_t* a, hipEvent_t* b);
+  static KernelTimerScope*& current();      // innermost live scope of this host thread (nullptr outside instrumented entry points)
+  KernelTimerScope* outer;
 };
+// launch `kernel` so that an active timer scope also gets the kernel's own begin / end timestamps
+#define LCR_LAUNCH_TIMED(kernel, grid, block, shmem, stream, ...)                                            \
+  do {                                                                                                      \
+    hipEvent_t _ka, _kb;                                                                                    \
+    lcr::KernelTimerScope* _sc = lcr::KernelTimerScope::current();                                          \
+    if (_sc && _sc->kernel_events(&_ka, &_kb)) hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, _ka, _kb, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                               \
+  } while (0)
 
 // ---- device-wide exclusive scan of int32 (n known on the host as a capacity) ---------------------
 // out[i] = sum(in[0..i-1]); out may alias in; total (i64) written to *total if non-null.

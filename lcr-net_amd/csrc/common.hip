@@ -37,27 +37,40 @@ LaunchTurn::~LaunchTurn() {
 
 // ---- opt-in launch timing ---------------------------------------------------------------------------------------------
 struct KtRec {
-  hipEvent_t a, b;
+  hipEvent_t a, b;        // bracket the launch on its stream
+  hipEvent_t ka, kb;      // the kernel's own begin / end (hipExtLaunchKernel), valid when has_k
+  bool       has_k;
   int        kind;
   int64_t    meta[5];
 };
+struct KtEvents {
+  hipEvent_t a, b, ka, kb;
+};
 static std::mutex g_kt_mu;
 static std::vector<KtRec> g_kt_log;
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_kt_pool;
+static std::vector<KtEvents> g_kt_pool;
 static std::atomic<int> g_kt_on{0};
 
+KernelTimerScope*& KernelTimerScope::current() {
+  static thread_local KernelTimerScope* cur = nullptr;
+  return cur;
+}
 KernelTimerScope::KernelTimerScope(int kind, hipStream_t stream, int64_t m0, int64_t m1, int64_t m2, int64_t m3, int64_t m4) : slot(-1), st(stream) {
+  outer = current();
+  current() = this;
   if (!g_kt_on.load(std::memory_order_relaxed)) return;
   std::lock_guard<std::mutex> lk(g_kt_mu);
   KtRec r;
   if (!g_kt_pool.empty()) {
-    r.a = g_kt_pool.back().first;
-    r.b = g_kt_pool.back().second;
+    r.a = g_kt_pool.back().a, r.b = g_kt_pool.back().b, r.ka = g_kt_pool.back().ka, r.kb = g_kt_pool.back().kb;
     g_kt_pool.pop_back();
   } else {
     hipEventCreate(&r.a);
     hipEventCreate(&r.b);
+    hipEventCreate(&r.ka);
+    hipEventCreate(&r.kb);
   }
+  r.has_k = false;
   r.kind = kind;
   r.meta[0] = m0, r.meta[1] = m1, r.meta[2] = m2, r.meta[3] = m3, r.meta[4] = m4;
   hipEventRecord(r.a, st);
@@ -65,9 +78,18 @@ KernelTimerScope::KernelTimerScope(int kind, hipStream_t stream, int64_t m0, int
   g_kt_log.push_back(r);
 }
 KernelTimerScope::~KernelTimerScope() {
+  current() = outer;
   if (slot < 0) return;
   std::lock_guard<std::mutex> lk(g_kt_mu);
   if (slot < static_cast<int>(g_kt_log.size())) hipEventRecord(g_kt_log[slot].b, st);
+}
+bool KernelTimerScope::kernel_events(hipEvent_t* a, hipEvent_t* b) {
+  if (slot < 0) return false;
+  std::lock_guard<std::mutex> lk(g_kt_mu);
+  if (slot >= static_cast<int>(g_kt_log.size())) return false;
+  g_kt_log[slot].has_k = true;
+  *a = g_kt_log[slot].ka, *b = g_kt_log[slot].kb;
+  return true;
 }
 
 // ---- scan: tile = 256 threads x 16 items ----------------------------------------------------------
@@ -280,7 +302,7 @@ extern "C" int lcr_debug_spin(int microseconds, void* stream) {
 extern "C" void lcr_ktimer_enable(int on) {
   std::lock_guard<std::mutex> lk(lcr::g_kt_mu);
   if (on) {
-    for (auto& r : lcr::g_kt_log) lcr::g_kt_pool.push_back({r.a, r.b});
+    for (auto& r : lcr::g_kt_log) lcr::g_kt_pool.push_back({r.a, r.b, r.ka, r.kb});
     lcr::g_kt_log.clear();
   }
   lcr::g_kt_on.store(on ? 1 : 0);
@@ -298,6 +320,30 @@ extern "C" int lcr_ktimer_read(int kind, int max_records, double* seconds, int64
       float ms = 0.f;
       hipEventElapsedTime(&ms, r.a, r.b);
       if (seconds) seconds[n] = static_cast<double>(ms) * 1e-3;
+      if (meta)
+        for (int k = 0; k < 5; ++k) meta[static_cast<size_t>(n) * 5 + k] = r.meta[k];
+    }
+    ++n;
+  }
+  return n;
+}
+// The same records with the kernel's own duration next to the bracketed one (seconds_kernel[i] < 0 where the launch site does
+// not provide it).
+extern "C" int lcr_ktimer_read2(int kind, int max_records, double* seconds, double* seconds_kernel, int64_t* meta /* [max_records,5] */) {
+  std::lock_guard<std::mutex> lk(lcr::g_kt_mu);
+  int n = 0;
+  for (auto& r : lcr::g_kt_log) {
+    if (r.kind != kind) continue;
+    if (n < max_records) {
+      hipEventSynchronize(r.b);
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, r.a, r.b);
+      if (seconds) seconds[n] = static_cast<double>(ms) * 1e-3;
+      if (seconds_kernel) {
+        seconds_kernel[n] = -1.0;
+        if (r.has_k && hipEventSynchronize(r.kb) == hipSuccess && hipEventElapsedTime(&ms, r.ka, r.kb) == hipSuccess)
+          seconds_kernel[n] = static_cast<double>(ms) * 1e-3;
+      }
       if (meta)
         for (int k = 0; k < 5; ++k) meta[static_cast<size_t>(n) * 5 + k] = r.meta[k];
     }

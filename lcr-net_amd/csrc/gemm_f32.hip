@@ -811,10 +811,10 @@ static int launch_gemm(const float* A, const float* B, float* C, int64_t M, int 
   const int mt8 = (div_up(M, BM) + 7) / 8 * 8;
   dim3 grid(mt8 * div_up(N, BN), 1, bt.count ? bt.count : 1);     // see the XCD-aware tile order in the kernel
   dim3 block(GM_T);
-  if (!transA && !transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, false, false, VEC, SHORT>), grid, block, 0, st, A, B, C, M, N, K, ep, bt, ANorm{});
-  else if (!transA && transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, false, true, VEC, SHORT>), grid, block, 0, st, A, B, C, M, N, K, ep, bt, ANorm{});
-  else if (transA && !transB) hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, true, false, VEC, SHORT>), grid, block, 0, st, A, B, C, M, N, K, ep, bt, ANorm{});
-  else hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, true, true, VEC, SHORT>), grid, block, 0, st, A, B, C, M, N, K, ep, bt, ANorm{});
+  if (!transA && !transB) LCR_LAUNCH_TIMED((k_gemm_f32<BM, BN, WM, WN, false, false, VEC, SHORT>), grid, block, 0, st, A, B, C, M, N, K, ep, bt, ANorm{});
+  else if (!transA && transB) LCR_LAUNCH_TIMED((k_gemm_f32<BM, BN, WM, WN, false, true, VEC, SHORT>), grid, block, 0, st, A, B, C, M, N, K, ep, bt, ANorm{});
+  else if (transA && !transB) LCR_LAUNCH_TIMED((k_gemm_f32<BM, BN, WM, WN, true, false, VEC, SHORT>), grid, block, 0, st, A, B, C, M, N, K, ep, bt, ANorm{});
+  else LCR_LAUNCH_TIMED((k_gemm_f32<BM, BN, WM, WN, true, true, VEC, SHORT>), grid, block, 0, st, A, B, C, M, N, K, ep, bt, ANorm{});
   return check_launch("lcr_gemm_f32");
 }
 
@@ -877,7 +877,7 @@ static int launch_gemm_sk(const float* A, const float* B, float* C, int64_t M, i
     sk.arrived = sc.arrived;
     sk.U = U;
   }
-  hipLaunchKernelGGL((k_gemm_f32_sk<64, 64, 2, 2>), dim3(8 * U), dim3(GM_T), 0, st, A, B, C, M, N, K, ep, sk);
+  LCR_LAUNCH_TIMED((k_gemm_f32_sk<64, 64, 2, 2>), dim3(8 * U), dim3(GM_T), 0, st, A, B, C, M, N, K, ep, sk);
   return check_launch("lcr_gemm_f32");
 }
 
@@ -919,7 +919,7 @@ extern "C" int lcr_gemm_f32_anorm(const float* A, const float* B, float* C, int6
   GemmEpilogue ep{bias, nullptr, seg_len, S, groups, stats};
   ANorm an{a_stats, a_gamma, a_beta, a_groups, a_eps, a_slope};
   const int mt8 = (div_up(M, 64) + 7) / 8 * 8;
-  hipLaunchKernelGGL((k_gemm_f32<64, 64, 2, 2, false, true, true, true, true>), dim3(mt8 * div_up(N, 64)), dim3(GM_T), 0, st, A, B, C, M,
+  LCR_LAUNCH_TIMED((k_gemm_f32<64, 64, 2, 2, false, true, true, true, true>), dim3(mt8 * div_up(N, 64)), dim3(GM_T), 0, st, A, B, C, M,
                      N, K, ep, GemmBatch{}, an);
   return check_launch("lcr_gemm_f32_anorm");
 }

@@ -643,10 +643,10 @@ static int launch_aggregate(const float* s_feats, const uint8_t* s_pos, const fl
                             int64_t Ns, int H, int C, const KPoints& kp, float sigma, float* A, float* nn, const int32_t* order, hipStream_t st) {
   dim3 grid(grid_for_xcd(M, KP_WAVES)), block(KP_WAVES * 64);
   switch (C) {
-    case 32: hipLaunchKernelGGL((k_kpconv_aggregate_vec<IdxT, 32>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
-    case 64: hipLaunchKernelGGL((k_kpconv_aggregate_vec<IdxT, 64>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
-    case 128: hipLaunchKernelGGL((k_kpconv_aggregate_vec<IdxT, 128>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
-    case 256: hipLaunchKernelGGL((k_kpconv_aggregate_vec<IdxT, 256>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
+    case 32: LCR_LAUNCH_TIMED((k_kpconv_aggregate_vec<IdxT, 32>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
+    case 64: LCR_LAUNCH_TIMED((k_kpconv_aggregate_vec<IdxT, 64>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
+    case 128: LCR_LAUNCH_TIMED((k_kpconv_aggregate_vec<IdxT, 128>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
+    case 256: LCR_LAUNCH_TIMED((k_kpconv_aggregate_vec<IdxT, 256>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
     default: set_error("lcr_kpconv_aggregate: C must be 32, 64, 128 or 256 (got %d)", C); return LCR_EARG;
   }
   return check_launch("lcr_kpconv_aggregate");

@@ -660,9 +660,9 @@ extern "C" int lcr_radius_query_ordered(const float* q, const int64_t* qlen, int
   KernelTimerScope timed(KT_RADIUS, st, nq_cap, ns_cap, limit, out_idx64 ? 8 : 4, B);
   const int nblk = (min(div_up(nq_cap, RS_WAVES * A.qb), getenv("LCR_RS_NBLK") ? atoi(getenv("LCR_RS_NBLK")) : rq_n_cu() * rq_wg_per_cu()) + 7) / 8 * 8;
   const dim3 grid(nblk);
-  if (out_idx64 && out_idx32) hipLaunchKernelGGL((k_radius_query<true, true>), grid, block, 0, st, A, B);
-  else if (out_idx64) hipLaunchKernelGGL((k_radius_query<true, false>), grid, block, 0, st, A, B);
-  else hipLaunchKernelGGL((k_radius_query<false, true>), grid, block, 0, st, A, B);
+  if (out_idx64 && out_idx32) LCR_LAUNCH_TIMED((k_radius_query<true, true>), grid, block, 0, st, A, B);
+  else if (out_idx64) LCR_LAUNCH_TIMED((k_radius_query<true, false>), grid, block, 0, st, A, B);
+  else LCR_LAUNCH_TIMED((k_radius_query<false, true>), grid, block, 0, st, A, B);
   return check_launch("lcr_radius_query");
 }
 
@@ -697,7 +697,7 @@ extern "C" int lcr_radius_query_multi(const LcrRadiusQuery* list, int n, int B, 
   KernelTimerScope timed(KT_RADIUS, st, nq_sum, 0, 0, 4, B);
   const int64_t cap = static_cast<int64_t>(rq_n_cu()) * rq_wg_per_cu();
   const int nblk = static_cast<int>(((turns < cap ? turns : cap) + 7) / 8 * 8);
-  hipLaunchKernelGGL(k_radius_query_multi, dim3(nblk), dim3(RS_WAVES * 64), 0, st, m);
+  LCR_LAUNCH_TIMED(k_radius_query_multi, dim3(nblk), dim3(RS_WAVES * 64), 0, st, m);
   return check_launch("lcr_radius_query_multi");
 }
 

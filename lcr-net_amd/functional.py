@@ -23,17 +23,25 @@ class KernelTimer:
         self._cache = None
 
     def summary(self):
+        """name -> [(seconds between the events bracketing the launch on its stream, meta)]"""
+        return {k: [(b, m) for b, _, m in v] for k, v in self.records().items()}
+
+    def records(self):
+        """name -> [(bracketed seconds, the kernel's own begin-to-end seconds or None, meta)].  The bracketed time contains whatever
+        the launch waited for in its queue (other streams' kernels holding the CUs); the kernel's own time is what a profiler's kernel
+        trace reports."""
         if self._cache is None:
             out = {}
             L = _lib.lib()
             for name in self.names:
                 kind = self.KINDS[name]
-                n = L.lcr_ktimer_read(kind, 0, None, None)
+                n = L.lcr_ktimer_read2(kind, 0, None, None, None)
                 sec = (ctypes.c_double * max(n, 1))()
+                ksec = (ctypes.c_double * max(n, 1))()
                 meta = (ctypes.c_int64 * (5 * max(n, 1)))()
-                L.lcr_ktimer_read(kind, n, ctypes.cast(sec, ctypes.c_void_p), ctypes.cast(meta, ctypes.c_void_p))
+                L.lcr_ktimer_read2(kind, n, ctypes.cast(sec, ctypes.c_void_p), ctypes.cast(ksec, ctypes.c_void_p), ctypes.cast(meta, ctypes.c_void_p))
                 width = 3 if name == "gemm" else 5            # radius_query: (nq_cap, ns_cap, limit, index bytes, B); attention: (sum Nq*Nk, P, heads, head_dim, 0)
-                out[name] = [(sec[i], tuple(int(meta[5 * i + k]) for k in range(width))) for i in range(n)]
+                out[name] = [(sec[i], ksec[i] if ksec[i] >= 0 else None, tuple(int(meta[5 * i + k]) for k in range(width))) for i in range(n)]
             self._cache = out
         return self._cache
 

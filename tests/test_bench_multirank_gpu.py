@@ -1,0 +1,26 @@
+"""GPU: the N-rank code path of bench.py on ONE device (LCR_BENCH_SINGLE_DEVICE=1, gloo: RCCL refuses two ranks on one GPU): rank
+processes started by bench.py itself, bound to their core ranges, rendezvous on 127.0.0.1, all-gather of the descriptors inside the
+timed region, one JSON line from rank 0 with n_gpus = 2.  (the reference's multi-process entry is
+utils/engine/base_tester.py:88.)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_on_one_device():
+    env = dict(os.environ, LCR_BENCH_SINGLE_DEVICE="1", LCR_BENCH_RANK_TIMEOUT="600")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # only rank 0 writes to stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["repeats"] == 2 and line["scaling"] == "weak"
+    assert line["value"] > 0 and line["ms_per_step_min"] <= line["ms_per_step"] <= line["ms_per_step_max"]
+    assert "gloo" in line["config"]["parallelism"]
