@@ -615,6 +615,219 @@ __global__ __launch_bounds__(GM_T, SHORT ? 6 : 2) void k_gemm_f32(const float* _
   gemm_epilogue<BM, BN, WM, WN, NT>(acc, C, M, N, m0, n0, m_tile, ep, bias_v, blk_first, blk_seg_start, blk_seg_end, wm, wn, lane);
 }
 
+// ---- K-deep form: LDS-direct loads three tiles ahead, fragments of step t+1 fetched under the MFMAs of step t -----------------
+// For C = A[M,K] · B[N,K]^T with K % 32 == 0 and K beyond the light form (the KPConv contractions with pre-transposed weights,
+// the unary Linears of stages 3-4).  What the register-staged kernel above loses per K-step is (a) the LDS latency of the
+// fragment reads it issues right after its barrier, in front of the first MFMA, and (b) ~40 VALU / LDS-store instructions that
+// move a tile from registers to LDS.  Here
+//   * tiles go from global memory straight into LDS (global_load_lds_dwordx4: the wavefront's 64 x 16 B land in 1 KB of
+//     consecutive LDS, no staging registers, no ds_write, no zero-select); the LDS image of a tile is row-major, 128 B per row,
+//     with the eight 16-B chunks of row r XOR-ed by (r >> 1) & 7 — applied on the SOURCE side (which chunk a lane fetches) and on
+//     the fragment read, so a ds_read_b128 of 16 different rows touches 16 different bank groups;
+//   * a ring of three LDS stages: the loads of tile t+3 are issued during step t and have two full steps (~2 x 1024 cycles of
+//     MFMA) to land.  They are issued from inline assembly and retired with COUNTED waits (s_waitcnt vmcnt(loads of one tile):
+//     the next tile stays in flight across the barrier) — the compiler orders every LDS read behind ALL outstanding LDS-direct
+//     loads it knows of (vmcnt(0)), which with one step of cover measured slower than the register-staged kernel whenever a CU
+//     holds more than one workgroup;
+//   * the MFMA operand fragments of step t+1 are read from LDS during the MFMAs of step t (two fragment register sets), so a
+//     step starts with its operands in registers;
+//   * one barrier per step, after the step's first MFMA: it closes tile t+1 (every wavefront has waited for its own share) and
+//     frees stage t % 3 — whose fragments are in registers by then — for tile t+3.
+// Same K pairing and summation order as k_gemm_f32's single-accumulator tiles: results are bit-identical to its 64x64 tile.
+template <int N_OUTSTANDING>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_OUTSTANDING) : "memory");
+}
+// one wavefront-wide 1-KB LDS-direct load: lane i's 16 B at base + off[i] land at lds_dst + 16 i (M0 = the wave-uniform LDS
+// address; written in the same statement that uses it, saved and restored around it: the compiler owns M0).  Scalar base + 32-bit
+// lane offset: the K-step advance is one scalar add for all loads.
+__device__ __forceinline__ void glds16(const float* base, unsigned off, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(off), "s"(base), "s"(lds_dst)
+               : "memory");
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(GM_T, 3) void k_gemm_f32_deep(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                            int64_t M, int N, int K, GemmEpilogue ep) {
+  static_assert(WM * WN == 4 && BM == 32 * WM && BN == 32 * WN, "one 32x32 accumulator per wavefront");
+  constexpr int LA = BM / 32, LB = BN / 32, LPW = LA + LB;   // 1-KB load instructions per wavefront and tile (8 rows each)
+  constexpr int STAGE_A = BM * 128, STAGE = (BM + BN) * 128;  // bytes
+  constexpr int NS = 3;
+  __shared__ __attribute__((aligned(1024))) char lds[NS * STAGE];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = w / WN, wn = w % WN;
+  const int ntn = (N + BN - 1) / BN;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;    // XCD-aware tile order, as in k_gemm_f32
+  const int64_t m_tile = static_cast<int64_t>(slot / ntn) * 8 + xcd;
+  const int64_t m0 = m_tile * BM;
+  const int n0 = (slot % ntn) * BN;
+  if (m0 >= M) return;
+  const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds));   // LDS byte address (low 32 bits of the generic pointer)
+
+  // source byte offset of this lane for each of its load instructions: LDS slot (row, physical chunk pc) <- global chunk pc ^ ((row >> 1) & 7)
+  unsigned oa[LA], ob[LB];                                     // the launcher guarantees M*K*4 and N*K*4 < 2^32
+#pragma unroll
+  for (int j = 0; j < LA; ++j) {
+    const int row = (w * LA + j) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    int64_t gr = m0 + row;
+    gr = gr < M ? gr : M - 1;                                // duplicate rows only feed outputs that are never stored
+    oa[j] = static_cast<unsigned>((gr * K + c * 4) * 4);
+  }
+#pragma unroll
+  for (int j = 0; j < LB; ++j) {
+    const int row = (w * LB + j) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    int gr = n0 + row;
+    gr = gr < N ? gr : N - 1;
+    ob[j] = static_cast<unsigned>((static_cast<int64_t>(gr) * K + c * 4) * 4);
+  }
+  const unsigned dst_a = lds_base + w * LA * 1024, dst_b = lds_base + STAGE_A + w * LB * 1024;
+  const float* Ak = A;                                         // scalar bases, advanced one K-step per tile issued
+  const float* Bk = B;
+  auto issue_one = [&](int stage, int j) {                     // j-th load instruction of the tile going to `stage` (A first, then B)
+    if (j < LA) glds16(Ak, oa[j], dst_a + stage * STAGE + j * 1024);
+    else glds16(Bk, ob[j - LA], dst_b + stage * STAGE + (j - LA) * 1024);
+  };
+  auto advance = [&] {                                         // after ALL load instructions of a tile
+    Ak += GM_BK;
+    Bk += GM_BK;
+  };
+  auto issue = [&](int stage) {
+#pragma unroll
+    for (int j = 0; j < LPW; ++j) issue_one(stage, j);
+    advance();
+  };
+
+  // fragment addresses: lane (l & 31) owns row wm*32 + (l & 31) of A (wn*32 + .. of B), half l >> 5 the k range [16 half, 16 half + 16)
+  const int half = lane >> 5;
+  const int ra = wm * 32 + (lane & 31), rb = wn * 32 + (lane & 31);
+  int offa[4], offb[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    offa[q] = ra * 128 + (((4 * half + q) ^ ((ra >> 1) & 7)) << 4);
+    offb[q] = STAGE_A + rb * 128 + (((4 * half + q) ^ ((rb >> 1) & 7)) << 4);
+  }
+  float4 fa[4], fb[4];                                         // the current step's fragments (k = 16 half + 4 q .. + 3 in fa[q])
+  floatx16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int nk = K / GM_BK;
+
+  issue(0);
+  if (nk > 1) issue(1);
+  if (nk > 2) issue(2);
+  // epilogue operands under the first tile's latency
+  float bias_v[1];
+  {
+    const int col = n0 + wn * 32 + (lane & 31);
+    bias_v[0] = (ep.bias && col < N) ? ep.bias[col] : 0.f;
+  }
+  int blk_first = 0;
+  int64_t blk_seg_start = 0, blk_seg_end = 0;
+  if (ep.stats != nullptr) {
+    blk_seg_end = ep.seg_len[0];
+    while (blk_first + 1 < ep.S && m0 >= blk_seg_end) {
+      ++blk_first;
+      blk_seg_start = blk_seg_end;
+      blk_seg_end += ep.seg_len[blk_first];
+    }
+  }
+  if (nk > 2) wait_vmcnt<2 * LPW>();                           // tile 0 has landed (tiles 1 and 2 may still be in flight)
+  else if (nk > 1) wait_vmcnt<LPW>();
+  else wait_vmcnt<0>();
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    fa[q] = *reinterpret_cast<const float4*>(lds + offa[q]);
+    fb[q] = *reinterpret_cast<const float4*>(lds + offb[q]);
+  }
+
+  auto mfma = [&](float a, float b) { acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0); };
+  auto mfma4 = [&](const float4& a, const float4& b) {
+    mfma(a.x, b.x);
+    mfma(a.y, b.y);
+    mfma(a.z, b.z);
+    mfma(a.w, b.w);
+  };
+  auto pin = [] { __builtin_amdgcn_sched_barrier(0); };
+  // step t computes tile t (its fragments are in fa / fb; its LDS stage is ST = t % 3), fetches the fragments of tile t+1 and
+  // issues the loads of tile t+3.  FULL: tiles t+1 .. t+3 exist — no branches, the three steps of a ring turn are one basic block.
+  // The 8 fragment reads and the LPW loads are dealt out one or two per MFMA (a 64-cycle MFMA hides ~10 issue slots; in one clump
+  // behind the barrier they were ~40 instructions during which this wavefront fed the matrix pipe nothing), every position pinned:
+  // left alone, the scheduler sinks the reads to their first use in the NEXT step and hoists the barrier above this step's MFMAs.
+  auto step = [&](auto st_c, auto full_c, int t) {
+    constexpr int ST = decltype(st_c)::value;
+    constexpr bool FULL = decltype(full_c)::value;
+    constexpr int NXT = (ST + 1) % NS;
+    float4 na[4], nb[4];
+    mfma4(fa[0], fb[0]);
+    const bool more = FULL || t + 1 < nk;                     // block-uniform
+    const bool load = FULL || t + 3 < nk;
+    pin();
+    if (more) {
+      if (FULL || t + 2 < nk) wait_vmcnt<LPW>();              // this wavefront's share of tile t+1 has landed; tile t+2 stays in flight
+      else wait_vmcnt<0>();
+      __syncthreads();                                        // ... and everybody else's; every wavefront holds its stage-ST fragments
+    }
+    const float a1[4] = {fa[1].x, fa[1].y, fa[1].z, fa[1].w}, b1[4] = {fb[1].x, fb[1].y, fb[1].z, fb[1].w};
+    const float a2[4] = {fa[2].x, fa[2].y, fa[2].z, fa[2].w}, b2[4] = {fb[2].x, fb[2].y, fb[2].z, fb[2].w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (more) {
+        na[q] = *reinterpret_cast<const float4*>(lds + NXT * STAGE + offa[q]);
+        nb[q] = *reinterpret_cast<const float4*>(lds + NXT * STAGE + offb[q]);
+      }
+      pin();
+      mfma(a1[q], b1[q]);
+      pin();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (more && load) {                                     // tile t+3 -> the stage this step's fragments came from
+#pragma unroll
+        for (int j = q; j < LPW; j += 4) issue_one(ST, j);
+      }
+      pin();
+      mfma(a2[q], b2[q]);
+      pin();
+    }
+    if (more && load) advance();
+    mfma4(fa[3], fb[3]);
+    if (more) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) fa[q] = na[q], fb[q] = nb[q];
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  int t = 0;
+  for (; t + 6 <= nk; t += 3) {                                // every step of this turn has three successors
+    step(I0{}, std::true_type{}, t);
+    step(I1{}, std::true_type{}, t + 1);
+    step(I2{}, std::true_type{}, t + 2);
+  }
+  for (; t < nk; t += 3) {
+    step(I0{}, std::false_type{}, t);
+    if (t + 1 < nk) step(I1{}, std::false_type{}, t + 1);
+    if (t + 2 < nk) step(I2{}, std::false_type{}, t + 2);
+  }
+
+  floatx16 accs[1] = {acc};
+  gemm_epilogue<BM, BN, WM, WN, 1>(accs, C, M, N, m0, n0, m_tile, ep, bias_v, blk_first, blk_seg_start, blk_seg_end, wm, wn, lane);
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_gemm_deep(const float* A, const float* B, float* C, int64_t M, int N, int K, const GemmEpilogue& ep, hipStream_t st) {
+  const int mt8 = (div_up(M, BM) + 7) / 8 * 8;
+  LCR_LAUNCH_TIMED((k_gemm_f32_deep<BM, BN, WM, WN>), dim3(mt8 * div_up(N, BN)), dim3(GM_T), 0, st, A, B, C, M, N, K, ep);
+  return check_launch("lcr_gemm_f32");
+}
+
 // ---- stream-K form of the K-deep contractions ---------------------------------------------------------------------------
 // With one tile per workgroup, 408 / 596 / 806 tiles of 64x64 on 256 CUs (<= 3 resident workgroups each) leave some CUs with one
 // tile more than others: the deepest KPConv contractions lose ~20 % to that quantisation.  Here the grid is a fixed number of
@@ -890,6 +1103,9 @@ static int g_force_tile = 0;
 extern "C" void lcr_gemm_debug_force_tile(int t) { g_force_tile = t; }
 // tuning / test hook: -1 = LCR_GEMM_STREAMK (default 1 = heuristic), 0 = never, 2 = whenever the stream-K kernel is legal
 static int g_force_streamk = -1;
+// tuning / test hook: -1 = LCR_GEMM_DEEP (default on), 0 = never, 1 = wherever legal
+static int g_force_deep = -1;
+extern "C" void lcr_gemm_debug_deep(int mode) { g_force_deep = mode; }
 extern "C" void lcr_gemm_debug_streamk(int mode) { g_force_streamk = mode; }
 
 static int gemm_impl(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB, const float* bias,
@@ -974,6 +1190,13 @@ static int gemm_impl(const float* A, const float* B, float* C, int64_t M, int N,
   if (!no_short && K <= short_k && !transA) {
     if (N <= 32) return launch_gemm<128, 32, 4, 1, true, true>(A, B, C, M, N, K, transA, transB, ep, st);
     return launch_gemm<64, 64, 2, 2, true, true>(A, B, C, M, N, K, transA, transB, ep, st);
+  }
+  // K-deep problems with both operands k-contiguous: LDS-direct loads + cross-step fragment prefetch (LCR_GEMM_DEEP=0: off)
+  static const int deep_env = getenv("LCR_GEMM_DEEP") ? atoi(getenv("LCR_GEMM_DEEP")) : 1;
+  const int deep_mode = g_force_deep >= 0 ? g_force_deep : deep_env;
+  if (deep_mode && !transA && transB && K % GM_BK == 0 && !g_force_tile && M * K < (int64_t(1) << 30) && static_cast<int64_t>(N) * K < (int64_t(1) << 30)) {
+    if (N <= 32) return launch_gemm_deep<128, 32, 4, 1>(A, B, C, M, N, K, ep, st);
+    return launch_gemm_deep<64, 64, 2, 2>(A, B, C, M, N, K, ep, st);
   }
   if (N <= 32) return launch_gemm<128, 32, 4, 1, true>(A, B, C, M, N, K, transA, transB, ep, st);
   // Stream-K is opt-in: measured +3 / +5 / +7 % on the three deepest KPConv contractions alone (93.6 vs 96, 121 vs 128, 153 vs
