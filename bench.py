@@ -342,13 +342,17 @@ def main():
     # ---- timed region: exactly K steps between barrier + synchronize — R such blocks back to back, the line reports the MEDIAN one
     blocks = []
     R = max(1, args.repeats)
+    # per-launch clocks on every SAMPLE-th launch of a kind only: a timed launch is a profiled dispatch (4 event records, timestamped
+    # completion signal, system-scope release at kernel end); with every launch timed the pipeline ran 7 % slower (2 409 vs 2 577
+    # scans/s).  9 is coprime with the 35 GEMMs / 10 aggregations of a step, so every shape is sampled equally often.
+    SAMPLE = max(1, int(os.environ.get("LCR_BENCH_KTIMER_SAMPLE", "9")))
     for rep in range(R):
         timer = F.KernelTimer({"kpconv_aggregate", "gemm", "radius_query"})
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         if not os.environ.get("LCR_BENCH_NO_KTIMER"):                  # A/B: what the per-launch events cost the timed region
-            F.set_timer(timer)
+            F.set_timer(timer, SAMPLE)
         t0 = time.perf_counter()
         desc = run_steps(args.steps)
         torch.cuda.synchronize()
@@ -413,6 +417,7 @@ def main():
         # the aggregation is MFMA work too (D[16 kernel points x C] += W[16 x 4] F[4 x C] per four neighbours): 2*15*nnz*C flops
         flops_agg = sum(2.0 * 15 * nnz.get((M, Ns), M * H) * C for _, (M, Ns, H, C, isz) in agg)
         n_search = 7 if args.no_upsampling else 10
+        rs_launch = tk_rs / max(len(rsq), 1)                                         # one launch per step (all searches of a batch)
         uses = [len(range(k, args.steps, nb_in)) for k in range(nb_in)]              # how often the timed region fed each batch
         bytes_rs = sum(u * search_bytes(sp, not args.no_upsampling) for u, sp in zip(uses, stage_points_all)) / max(args.steps, 1)
         traffic, traffic_src, traffic_rs = None, None, None
@@ -421,40 +426,44 @@ def main():
             traffic = pmc.get("k_gemm_f32", {}).get("traffic_bytes")
             traffic_rs = (pmc.get("k_radius_query_multi") or pmc.get("k_radius_query") or {}).get("traffic_bytes")
             traffic_src = "profiles/pmc_traffic.json: separate rocprofv3 --pmc passes of this command (2*FETCH_SIZE + WRITE_SIZE per launch), not measured in this run"
-        roof = {"bound": "mfma", "kernel": "lcr::k_gemm_f32 (fp32 MFMA, %d launches/step)" % (len(gem) // max(args.steps, 1)),
+        per_step = lambda recs: round(len(recs) * SAMPLE / max(args.steps, 1))
+        roof = {"bound": "mfma", "kernel": "lcr::k_gemm_f32 / k_gemm_f32_deep (fp32 MFMA, %d launches/step)" % per_step(gem),
                 "achieved": round(flops / tk_gemm / 1e12, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(flops / tk_gemm / 1e12 / FP32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "clock": "kernel begin-to-end (hipExtLaunchKernel start/stop events) over the timed region, four streams sharing the CUs",
+                "clock": "kernel begin-to-end (hipExtLaunchKernel start/stop events) of every %d-th launch over the timed region, four streams sharing the CUs" % SAMPLE,
+                "launches_timed": len(gem),
                 "avg_launch_us": round(tk_gemm / max(len(gem), 1) * 1e6, 2),
                 "achieved_event_bracketed": round(flops / t_gemm / 1e12, 2), "frac_event_bracketed": round(flops / t_gemm / 1e12 / FP32_PEAK_TFLOPS, 4),
                 "avg_launch_us_event_bracketed": round(t_gemm / max(len(gem), 1) * 1e6, 2),
                 "achieved_alone": round(iso, 2), "frac_alone": round(iso / FP32_PEAK_TFLOPS, 4),
                 "gflop_per_launch": round(flops / max(len(gem), 1) / 1e9, 3),
-                "event_time_over_step_time": {"gemm": round(t_gemm / dt, 3), "kpconv_aggregate": round(t_agg / dt, 3), "radius_query": round(t_rs / dt, 3),
-                                              "note": "sum of launch-to-completion event times / wall time; streams overlap, so the shares do not add up to 1"},
-                "neighbor": {"kernel": "lcr::k_radius_query[_multi] (%d searches in %d launch(es) per step)" % (n_search, max(1, round(len(rsq) / max(args.steps, 1)))),
+                "gflop_per_step": round(flops * SAMPLE / max(args.steps, 1) / 1e9, 1),
+                "kernel_time_over_step_time": {"gemm": round(tk_gemm * SAMPLE / dt, 3), "kpconv_aggregate": round(tk_agg * SAMPLE / dt, 3),
+                                               "radius_query": round(tk_rs * SAMPLE / dt, 3),
+                                               "note": "sum of kernel begin-to-end times (sampled, scaled) / wall time; streams overlap, so the shares do not add up to 1"},
+                "neighbor": {"kernel": "lcr::k_radius_query[_multi] (%d searches in %d launch(es) per step)" % (n_search, max(1, per_step(rsq))),
                              "bound": "hbm",
                              "algorithmic_mb_per_step": round(bytes_rs / 1e6, 2),
-                             "achieved": round(bytes_rs * args.steps / tk_rs / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(bytes_rs * args.steps / tk_rs / 1e9 / HBM_PEAK_GBS, 4),
-                             "ms_per_step": round(tk_rs / args.steps * 1e3, 4),
-                             "ms_per_step_event_bracketed": round(t_rs / args.steps * 1e3, 4),
-                             "algorithmic_bytes_per_launch": round(bytes_rs * args.steps / max(len(rsq), 1)), "traffic": traffic_rs,
+                             "achieved": round(bytes_rs / rs_launch / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(bytes_rs / rs_launch / 1e9 / HBM_PEAK_GBS, 4),
+                             "ms_per_step": round(rs_launch * 1e3, 4),
+                             "ms_per_step_event_bracketed": round(t_rs / max(len(rsq), 1) * 1e3, 4),
+                             "algorithmic_bytes_per_launch": round(bytes_rs), "traffic": traffic_rs,
                              "achieved_alone": round(search_bytes(stage_points, not args.no_upsampling) / iso_rs / 1e9, 1),
                              "frac_alone": round(search_bytes(stage_points, not args.no_upsampling) / iso_rs / 1e9 / HBM_PEAK_GBS, 4),
                              "ms_per_step_alone": round(iso_rs * 1e3, 4)},
-                "aggregation": {"kernel": "lcr::k_kpconv_aggregate (fp32 MFMA 16x16x4, %d launches/step)" % (len(agg) // max(args.steps, 1)), "bound": "mfma",
+                "aggregation": {"kernel": "lcr::k_kpconv_aggregate (fp32 MFMA 16x16x4, %d launches/step)" % per_step(agg), "bound": "mfma",
                                 "achieved": round(flops_agg / tk_agg / 1e12, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(flops_agg / tk_agg / 1e12 / FP32_PEAK_TFLOPS, 4), "gflop_per_step": round(flops_agg / args.steps / 1e9, 2),
+                                "frac": round(flops_agg / tk_agg / 1e12 / FP32_PEAK_TFLOPS, 4), "gflop_per_step": round(flops_agg * SAMPLE / args.steps / 1e9, 2),
                                 "note": "2*15*nnz*C flops over the valid neighbours; kernel begin-to-end time inside the pipeline (other streams share the CUs)"},
-                "whole_step": {"gflop_per_step": round((flops + flops_agg) / args.steps / 1e9, 1), "what": "GEMMs + KPConv aggregation (fp32 MFMA work of a step)",
-                               "tflops": round((flops + flops_agg) / dt / 1e12, 2),
-                               "frac_of_fp32_mfma_peak": round((flops + flops_agg) / dt / 1e12 / FP32_PEAK_TFLOPS, 4)},
+                "whole_step": {"gflop_per_step": round((flops + flops_agg) * SAMPLE / args.steps / 1e9, 1), "what": "GEMMs + KPConv aggregation (fp32 MFMA work of a step; sampled launches, scaled)",
+                               "tflops": round((flops + flops_agg) * SAMPLE / dt / 1e12, 2),
+                               "frac_of_fp32_mfma_peak": round((flops + flops_agg) * SAMPLE / dt / 1e12 / FP32_PEAK_TFLOPS, 4)},
                 "secondary": {"kernel": "KPConv layers: lcr::k_kpconv_aggregate + its (15C x Cout) contraction", "bound": "hbm",
                               "achieved": round(bytes_kp / t_kp / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(bytes_kp / t_kp / 1e9 / HBM_PEAK_GBS, 4),
-                              "algorithmic_mb_per_step": round(bytes_kp / args.steps / 1e6, 1),
-                              "ms_per_step": round(t_kp / args.steps * 1e3, 3)}}
+                              "algorithmic_mb_per_step": round(bytes_kp * SAMPLE / args.steps / 1e6, 1),
+                              "ms_per_step": round(t_kp * SAMPLE / args.steps * 1e3, 3)}}
         line = {
             "metric": "scans/s (120k-pt KITTI-shape scan -> 256-D descriptor)",
             "value": round(world * BATCH * args.steps / dt, 3), "unit": "scans/s", "n_gpus": world, "steps": args.steps,

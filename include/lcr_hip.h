@@ -38,6 +38,7 @@ const char* lcr_last_error(void);
  * also when they are called from lcr_encoder_forward.  lcr_ktimer_enable(1) clears the log; lcr_ktimer_read synchronises on
  * the logged events and returns the number of records of `kind`. */
 void lcr_ktimer_enable(int on);
+void lcr_ktimer_sample(int every);   /* time every n-th instrumented launch of a kind only (default 1 = all) */
 int lcr_ktimer_read(int kind, int max_records, double* seconds, int64_t* meta);
 /* same, plus the kernel's own begin-to-end duration (what a profiler reports; < 0 where a launch site does not record it) */
 int lcr_ktimer_read2(int kind, int max_records, double* seconds, double* seconds_kernel, int64_t* meta);
@@ -243,6 +244,7 @@ typedef struct LcrBlockW {     /* ResidualBlock (modules.py:148-225) */
   float sigma;
   const float* kernel_points_host;
   const float *kp_w, *kp_b;    /* KPConv weights [15, cout/4, cout/4], bias [cout/4] */
+  const float* kp_wt;          /* optional: the same weights as [cout/4, 15 * cout/4] (k-contiguous rows: the K-deep GEMM form); NULL = not provided */
   const float *normconv_w, *normconv_b;
   LcrUnaryW unary1, unary2, shortcut;
 } LcrBlockW;

@@ -39,6 +39,7 @@ _SIGS = {
     "lcr_gemm_f32_anorm": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_float, c_float, c_vp, c_int,
                                    c_int, c_vp, c_vp]),
     "lcr_ktimer_enable": (None, [c_int]),
+    "lcr_ktimer_sample": (None, [c_int]),
     "lcr_ktimer_read": (c_int, [c_int, c_int, c_vp, c_vp]),
     "lcr_ktimer_read2": (c_int, [c_int, c_int, c_vp, c_vp, c_vp]),
     "lcr_encoder_ws_bytes": (c_int, [c_vp, c_vp, c_int, c_size_p]),

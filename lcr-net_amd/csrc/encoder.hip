@@ -105,7 +105,9 @@ static int residual_block(const LcrBlockW& b, const float* s_feats, const StageI
       return rc;
   } else {
     if ((rc = TURN(lcr_kpconv_aggregate(x, pos, q.pts, sup.pts, idx, 0, M, Ns, H, mid, b.kernel_points_host, b.sigma, A, nn, q.order, s)))) return rc;
-    if ((rc = TURN(lcr_gemm_f32(A, b.kp_w, kpo, M, mid, 15 * mid, 0, 0, b.kp_b, nn, q.seg, sp.S, g, stc, s)))) return rc;
+    // weights pre-transposed by the caller ([mid, 15 mid]): both operands k-contiguous -> the K-deep GEMM form
+    if ((rc = TURN(b.kp_wt ? lcr_gemm_f32(A, b.kp_wt, kpo, M, mid, 15 * mid, 0, 1, b.kp_b, nn, q.seg, sp.S, g, stc, s)
+                           : lcr_gemm_f32(A, b.kp_w, kpo, M, mid, 15 * mid, 0, 0, b.kp_b, nn, q.seg, sp.S, g, stc, s)))) return rc;
   }
   // 3. + 4. norm_conv + LeakyReLU + unary2 (normalised in step 7).  With segments of >= 64 rows and the light GEMM form, the
   // normalisation happens while unary2's GEMM stages its A tiles (lcr_gemm_f32_anorm) — same rule as ResidualBlock.forward.

@@ -1187,17 +1187,21 @@ static int gemm_impl(const float* A, const float* B, float* C, int64_t M, int N,
   const int64_t b128 = (M + 127) / 128, nb128 = (N + 127) / 128;
   static const bool no_short = getenv("LCR_GEMM_NO_SHORT") != nullptr;   // A/B switch while the light form is being evaluated
   static const int short_k = getenv("LCR_GEMM_SHORT_K") ? atoi(getenv("LCR_GEMM_SHORT_K")) : 256;
+  // K-deep form (LDS-direct loads + cross-step fragment prefetch) wherever both operands are k-contiguous and K is a multiple of the
+  // K-step (LCR_GEMM_DEEP=0: off; 1: K beyond the light form; 2: every such K)
+  static const int deep_env = getenv("LCR_GEMM_DEEP") ? atoi(getenv("LCR_GEMM_DEEP")) : 1;
+  const int deep_mode = g_force_deep >= 0 ? g_force_deep : deep_env;
+  const bool deep_ok = !transA && transB && K % GM_BK == 0 && !g_force_tile && M * K < (int64_t(1) << 30) && static_cast<int64_t>(N) * K < (int64_t(1) << 30);
+  auto deep = [&] {
+    if (N <= 32) return launch_gemm_deep<128, 32, 4, 1>(A, B, C, M, N, K, ep, st);
+    return launch_gemm_deep<64, 64, 2, 2>(A, B, C, M, N, K, ep, st);
+  };
+  if (deep_mode == 2 && deep_ok) return deep();
   if (!no_short && K <= short_k && !transA) {
     if (N <= 32) return launch_gemm<128, 32, 4, 1, true, true>(A, B, C, M, N, K, transA, transB, ep, st);
     return launch_gemm<64, 64, 2, 2, true, true>(A, B, C, M, N, K, transA, transB, ep, st);
   }
-  // K-deep problems with both operands k-contiguous: LDS-direct loads + cross-step fragment prefetch (LCR_GEMM_DEEP=0: off)
-  static const int deep_env = getenv("LCR_GEMM_DEEP") ? atoi(getenv("LCR_GEMM_DEEP")) : 1;
-  const int deep_mode = g_force_deep >= 0 ? g_force_deep : deep_env;
-  if (deep_mode && !transA && transB && K % GM_BK == 0 && !g_force_tile && M * K < (int64_t(1) << 30) && static_cast<int64_t>(N) * K < (int64_t(1) << 30)) {
-    if (N <= 32) return launch_gemm_deep<128, 32, 4, 1>(A, B, C, M, N, K, ep, st);
-    return launch_gemm_deep<64, 64, 2, 2>(A, B, C, M, N, K, ep, st);
-  }
+  if (deep_mode && deep_ok) return deep();
   if (N <= 32) return launch_gemm<128, 32, 4, 1, true>(A, B, C, M, N, K, transA, transB, ep, st);
   // Stream-K is opt-in: measured +3 / +5 / +7 % on the three deepest KPConv contractions alone (93.6 vs 96, 121 vs 128, 153 vs
   // 164 us) — far from the 20 % a CU-count model predicts, because one or two workgroups per CU already reach 40 / 60 % of the

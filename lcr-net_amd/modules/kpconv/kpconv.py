@@ -39,6 +39,17 @@ class KPConv(nn.Module):
         # result in the checkpoint; real values therefore always come from load_state_dict.  Default: un-rotated disposition.
         self.register_buffer("kernel_points", torch.from_numpy(base_kernel_points() * radius).float())
         self._kp_cache = None
+        self._wt_cache = None
+
+    def weights_t(self):
+        """The (15 Cin, Cout) contraction matrix transposed to [Cout, 15 Cin] (rows contiguous along k), cached until the weights
+        change: with both operands k-contiguous the contraction takes the K-deep GEMM form (LDS-direct loads, 16-B fragment reads
+        for both operands).  Same products, same summation order: the result does not change."""
+        w = self.weights
+        key = (w.data_ptr(), w._version, w.device)
+        if self._wt_cache is None or self._wt_cache[0] != key:
+            self._wt_cache = (key, w.detach().reshape(self.kernel_size * self.in_channels, self.out_channels).t().contiguous())
+        return self._wt_cache[1]
 
     def kernel_points_host(self):
         kp = self.kernel_points
@@ -63,8 +74,7 @@ class KPConv(nn.Module):
             return F.kpconv_fused(s_feats, s_pos, q_points, s_points, neighbor_indices, kp, self.sigma, self.weights, self.bias,
                                   seg_len=seg_len, groups=groups, order=order)
         A, nn_cnt = F.kpconv_aggregate(s_feats, s_pos, q_points, s_points, neighbor_indices, kp, self.sigma, order=order)
-        W = self.weights.view(self.kernel_size * self.in_channels, self.out_channels)
-        return F.gemm(A, W, bias=self.bias, rowdiv=nn_cnt, seg_len=seg_len, groups=groups)
+        return F.gemm(A, self.weights_t(), trans_b=True, bias=self.bias, rowdiv=nn_cnt, seg_len=seg_len, groups=groups)
 
     def forward(self, s_feats, q_points, s_points, neighbor_indices):
         return self.forward_raw(s_feats, q_points, s_points, neighbor_indices)[0]

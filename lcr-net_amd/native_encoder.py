@@ -22,7 +22,7 @@ class UnaryW(ctypes.Structure):
 
 class BlockW(ctypes.Structure):
     _fields_ = [("cin", ctypes.c_int), ("cout", ctypes.c_int), ("strided", ctypes.c_int), ("sigma", ctypes.c_float),
-                ("kernel_points_host", _fp), ("kp_w", _fp), ("kp_b", _fp), ("normconv_w", _fp), ("normconv_b", _fp),
+                ("kernel_points_host", _fp), ("kp_w", _fp), ("kp_b", _fp), ("kp_wt", _fp), ("normconv_w", _fp), ("normconv_b", _fp),
                 ("unary1", UnaryW), ("unary2", UnaryW), ("shortcut", UnaryW)]
 
 
@@ -60,6 +60,9 @@ class EncoderTable:
             blk.cin, blk.cout, blk.strided, blk.sigma = int(b.in_channels), int(b.out_channels), int(bool(b.strided)), float(b.KPConv.sigma)
             blk.kernel_points_host = self._kp(b.KPConv)
             blk.kp_w, blk.kp_b = _p(b.KPConv.weights), _p(b.KPConv.bias)
+            wt = b.KPConv.weights_t()                     # [mid, 15 mid] copy (cached by the module, rebuilt with the weights)
+            self.keep.append(wt)
+            blk.kp_wt = _p(wt)
             blk.normconv_w, blk.normconv_b = _p(b.norm_conv.norm.weight), _p(b.norm_conv.norm.bias)
             blk.unary1, blk.unary2, blk.shortcut = _unary(b.unary1), _unary(b.unary2), _unary(b.unary_shortcut)
         self.w = w

@@ -13,6 +13,12 @@ SHAPES = [("1_2 kpconv", 127812, 32, 480, 1), ("2_1 kpconv", 51547, 32, 480, 1),
           ("3_2 kpconv", 19061, 128, 1920, 1), ("4_1 kpconv", 6479, 128, 1920, 1), ("4_2 kpconv", 6479, 256, 3840, 1),
           ("3_x unary", 19061, 128, 512, 0), ("3_2 short", 19061, 512, 256, 0), ("4_x unary1", 6479, 256, 1024, 0), ("4_2 short", 6479, 1024, 512, 0),
           ("4_2 unary1", 6479, 256, 512, 0), ("netvlad", 6479, 64, 1024, 0), ("square", 8192, 1024, 1024, 0), ("ragged", 5000, 96, 352, 1)]
+if "--short" in sys.argv:
+    SHAPES = [("1_2 unary1", 127812, 32, 64, 0), ("1_2 unary2", 127812, 128, 32, 0), ("1_2 short", 127812, 128, 64, 0), ("2_1 unary1", 127812, 32, 128, 0),
+              ("2_1 unary2", 51547, 128, 32, 0), ("2_2 unary1", 51547, 64, 128, 0), ("2_2 unary2", 51547, 256, 64, 0), ("2_2 short", 51547, 256, 128, 0),
+              ("2_3 unary1", 51547, 64, 256, 0), ("3_1 unary2", 19061, 256, 64, 0), ("3_2 unary1", 19061, 128, 256, 0), ("3_2 unary2", 19061, 512, 128, 0),
+              ("4_1 unary2", 6479, 512, 128, 0), ("4_2 unary2", 6479, 1024, 256, 0), ("tiny", 700, 256, 64, 0)]
+DEEP_MODE = 2 if "--short" in sys.argv else 1
 
 
 def main():
@@ -30,7 +36,7 @@ def main():
         kw = dict(trans_b=True, bias=bias, rowdiv=div, seg_len=seg if g else None, groups=g)
         lib.lcr_gemm_debug_deep(0)
         c0, s0 = F.gemm(a, b, **kw)
-        lib.lcr_gemm_debug_deep(1)
+        lib.lcr_gemm_debug_deep(DEEP_MODE)
         c1, s1 = F.gemm(a, b, **kw)
         torch.cuda.synchronize()
         same = torch.equal(c0, c1)
@@ -46,7 +52,7 @@ def main():
     times = {(t[0], m): [] for t in tensors for m in (0, 1)}
     for rnd in range(5):
         for mode in (0, 1):
-            lib.lcr_gemm_debug_deep(mode)
+            lib.lcr_gemm_debug_deep(DEEP_MODE if mode else 0)
             timer = F.KernelTimer({"gemm"})
             F.set_timer(timer)
             for tag, M, N, K, a, b, kw in tensors:
