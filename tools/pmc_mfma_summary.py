@@ -15,7 +15,7 @@ import sys
 
 def fam(k):
     k = k.replace("lcr::", "").replace("void ", "")
-    for f in ("k_gemm_f32<64, 64, 2, 2, false, false", "k_gemm_f32<64, 64, 2, 2, false, true", "k_gemm_f32<128, 32", "k_gemm_f32<128, 128",
+    for f in ("k_gemm_f32_deep<64, 64", "k_gemm_f32_deep<128, 32", "k_gemm_f32<64, 64, 2, 2, false, true, true, true, true", "k_gemm_f32<64, 64, 2, 2, false, false", "k_gemm_f32<64, 64, 2, 2, false, true", "k_gemm_f32<128, 32", "k_gemm_f32<128, 128",
               "k_kpconv_aggregate_vec<int, 32", "k_kpconv_aggregate_vec<int, 64", "k_kpconv_aggregate_vec<int, 128",
               "k_kpconv_aggregate_vec<int, 256", "k_gn_apply", "k_maxpool", "k_kpconv_cin1", "k_attention", "k_radius_query"):
         if f in k:
