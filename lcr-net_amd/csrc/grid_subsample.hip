@@ -385,11 +385,35 @@ __device__ __forceinline__ int hm_bucket(uint64_t key, uint64_t nb64, double inv
 // swaps t and bk).  The arrays may live in LDS (small phases) or in global memory; the code is the same.
 // E = int32_t (arrays in global memory, any size) or uint16_t (LDS phases: every value — bucket id, list position, count — is
 // below the phase's bucket count <= 5087); gmin / cnt stay 32-bit, they are the targets of LDS atomics.
-template <int HU, typename E>
-__device__ __forceinline__ void hm_phase(const uint64_t* __restrict__ key, E* __restrict__ t, E* __restrict__ bk,
-                                         E* __restrict__ memt, E* __restrict__ arrv, E* __restrict__ at,
-                                         int32_t* __restrict__ gmin, int32_t* __restrict__ cnt, E* __restrict__ start, int lo,
+// Arrays and their access pattern: key, t, bk, arrv are walked element by element (streamed); gmin, cnt (atomic targets), start, at
+// and memt are hit at data-dependent addresses — ~11 of them per element and phase, which one CU issues ~30x faster to LDS than to
+// L2/HBM.  Hence three placements of the same code: everything in LDS (phases <= 5087 buckets, all arrays 16-bit but the two atomic
+// targets), the SCATTERED arrays in LDS and the streamed ones in global memory (the 10273-bucket phase: 16-bit start / at / memt next
+// to 32-bit gmin / cnt = 14 B per bucket, 144 KB; the 20753-bucket phase of clouds up to ~17.6 k voxels: gmin 32-bit, cnt as packed
+// 16-bit halves that turn into `start` in place, at 16-bit, memt left in global memory), or everything in global memory (any size).
+// CNT16: cnt is a uint16_t array updated through 32-bit atomics on the word that holds it (counts stay below 2^16: a bucket holds
+// at most `hi` <= 65535 elements there) and `start` ALIASES it (pass B reads cnt[i] and writes start[i] from the same thread).
+template <bool CNT16>
+struct HmCnt {
+  using type = int32_t;
+};
+template <>
+struct HmCnt<true> {
+  using type = uint16_t;
+};
+__device__ __forceinline__ int hm_cnt_fetch_inc(int32_t* cnt, int i) { return atomicAdd(&cnt[i], 1); }
+__device__ __forceinline__ int hm_cnt_fetch_inc(uint16_t* cnt, int i) {
+  uint32_t* w = reinterpret_cast<uint32_t*>(cnt + (i & ~1));
+  const uint32_t old = atomicAdd(w, (i & 1) ? 0x10000u : 1u);
+  return static_cast<int>((old >> (16 * (i & 1))) & 0xffffu);
+}
+
+template <int HU, typename ET, typename EM, typename EA, typename ES, bool CNT16 = false>
+__device__ __forceinline__ void hm_phase(const uint64_t* __restrict__ key, ET* __restrict__ t, ET* __restrict__ bk,
+                                         EM* __restrict__ memt, ET* __restrict__ arrv, EA* __restrict__ at,
+                                         int32_t* __restrict__ gmin, typename HmCnt<CNT16>::type* cnt, ES* start, int lo,
                                          int hi, int nb, uint64_t nb64, int* lds) {
+  using E = ET;
   const int tid = threadIdx.x;
   const double inv_nb = 1.0 / static_cast<double>(nb64);
   // only buckets that can be hit matter, but all nb are scanned for the member offsets; nb <= 2.25 n + 64
@@ -418,7 +442,7 @@ __device__ __forceinline__ void hm_phase(const uint64_t* __restrict__ key, E* __
       if (e < hi) {
         bb[k] = hm_bucket(kk[k], nb64, inv_nb);
         atomicMin(&gmin[bb[k]], tt[k]);
-        arr[k] = atomicAdd(&cnt[bb[k]], 1);
+        arr[k] = hm_cnt_fetch_inc(cnt, bb[k]);
       }
     }
 #pragma unroll
@@ -448,14 +472,14 @@ __device__ __forceinline__ void hm_phase(const uint64_t* __restrict__ key, E* __
     for (int k = 0; k < HU; ++k) {
       const int i = i0 + k * HM_T;
       if (i < nb) {
-        if (c[k] > 0) at[g[k]] = static_cast<E>(c[k]);
-        start[i] = static_cast<E>(c[k]);
+        if (c[k] > 0) at[g[k]] = static_cast<EA>(c[k]);
+        start[i] = static_cast<ES>(c[k]);
       }
     }
   }
   __syncthreads();
-  hm_scan_inplace<true, E>(at, hi, lds);     // at[tt] = number of elements in groups created AFTER time tt
-  hm_scan_inplace<false, E>(start, nb, lds);  // member-list offsets per bucket
+  hm_scan_inplace<true, EA>(at, hi, lds);     // at[tt] = number of elements in groups created AFTER time tt
+  hm_scan_inplace<false, ES>(start, nb, lds);  // member-list offsets per bucket
   // pass C: member lists (timestamps), and per bucket the list position of its group (replaces gmin)
   for (int e0 = tid; e0 < hi; e0 += HU * HM_T) {
     int bb[HU], tt[HU], ar[HU], s0[HU];
@@ -476,7 +500,7 @@ __device__ __forceinline__ void hm_phase(const uint64_t* __restrict__ key, E* __
 #pragma unroll
     for (int k = 0; k < HU; ++k) {
       const int e = e0 + k * HM_T;
-      if (e < hi) memt[s0[k] + ar[k]] = static_cast<E>(tt[k]);
+      if (e < hi) memt[s0[k] + ar[k]] = static_cast<EM>(tt[k]);
     }
   }
   for (int i0 = tid; i0 < nb; i0 += HU * HM_T) {
@@ -569,7 +593,9 @@ __device__ __forceinline__ void hm_emit(const E* __restrict__ pos, const int32_t
 // phase of every stage ran out of global memory.)
 constexpr int HM_LDS_PHASES = 9;
 constexpr int HM_LC = 5087 + 9;         // entries per LDS array (c_sched[HM_LDS_PHASES - 1], padded to a multiple of 8)
-constexpr size_t HM_LDS_BYTES = static_cast<size_t>(HM_LC) * (2 * sizeof(int32_t) + 6 * sizeof(uint16_t) + sizeof(uint64_t));
+constexpr size_t HM_LDS_SMALL = static_cast<size_t>(HM_LC) * (2 * sizeof(int32_t) + 6 * sizeof(uint16_t) + sizeof(uint64_t));   // all arrays of the small phases
+constexpr size_t HM_LDS_BYTES = 160 * 1024 - 1024;   // the whole CU's LDS but the static part: the 10273- / 20753-bucket phases keep their scattered arrays there
+static_assert(HM_LDS_SMALL <= HM_LDS_BYTES, "LDS phases do not fit");
 
 __global__ __launch_bounds__(HM_T) void k_gs_hashorder(const GsHeader* __restrict__ h, const uint64_t* __restrict__ ins_key,
                                                        const int32_t* __restrict__ ins_seg, const float* __restrict__ bary,
@@ -604,7 +630,7 @@ __global__ __launch_bounds__(HM_T) void k_gs_hashorder(const GsHeader* __restric
     for (; p < HM_LDS_PHASES; ++p) {
       const int nb = static_cast<int>(c_sched[p]);
       const int hi = min(n, nb);
-      hm_phase<4, uint16_t>(lkey, lt, lbk, lmem, larr, lat, lgmin, lcnt, lstart, lo, hi, nb, static_cast<uint64_t>(nb), lds);
+      hm_phase<4, uint16_t, uint16_t, uint16_t, uint16_t>(lkey, lt, lbk, lmem, larr, lat, lgmin, lcnt, lstart, lo, hi, nb, static_cast<uint64_t>(nb), lds);
       uint16_t* sw = lt;                         // the new positions become the next phase's timestamps
       lt = lbk;
       lbk = sw;
@@ -635,7 +661,25 @@ __global__ __launch_bounds__(HM_T) void k_gs_hashorder(const GsHeader* __restric
     const int64_t nb64 = c_sched[p];
     const int hi = static_cast<int>(min(static_cast<int64_t>(n), nb64));
     const int nb = static_cast<int>(min(nb64, static_cast<int64_t>(2147483647)));
-    hm_phase<4, int32_t>(key, t, bk, memt, arrv, at, gmin, cnt, start, lo, hi, nb, static_cast<uint64_t>(nb64), lds);
+    // placement of the SCATTERED arrays (see hm_phase): all five in LDS, or gmin + packed cnt/start + at in LDS, or none
+    const size_t nbe = static_cast<size_t>(nb + 2) & ~size_t(1), hie = static_cast<size_t>(hi + 2) & ~size_t(1);   // even entry counts: 4-B aligned arrays
+    const size_t need_all = nbe * (4 + 4 + 2) + hie * (2 + 2);
+    const size_t need_part = nbe * (4 + 2) + hie * 2;
+    if (nb64 < 65536 && need_all <= HM_LDS_BYTES) {
+      int32_t* lgmin = reinterpret_cast<int32_t*>(hm_dyn);
+      int32_t* lcnt = lgmin + nbe;
+      uint16_t* lstart = reinterpret_cast<uint16_t*>(lcnt + nbe);
+      uint16_t* lat = lstart + nbe;
+      uint16_t* lmem = lat + hie;
+      hm_phase<4, int32_t, uint16_t, uint16_t, uint16_t>(key, t, bk, lmem, arrv, lat, lgmin, lcnt, lstart, lo, hi, nb, static_cast<uint64_t>(nb64), lds);
+    } else if (nb64 < 65536 && need_part <= HM_LDS_BYTES) {
+      int32_t* lgmin = reinterpret_cast<int32_t*>(hm_dyn);
+      uint16_t* lcnt = reinterpret_cast<uint16_t*>(lgmin + nbe);     // becomes `start` in place
+      uint16_t* lat = lcnt + nbe;
+      hm_phase<4, int32_t, int32_t, uint16_t, uint16_t, true>(key, t, bk, memt, arrv, lat, lgmin, lcnt, lcnt, lo, hi, nb, static_cast<uint64_t>(nb64), lds);
+    } else {
+      hm_phase<4, int32_t, int32_t, int32_t, int32_t>(key, t, bk, memt, arrv, at, gmin, cnt, start, lo, hi, nb, static_cast<uint64_t>(nb64), lds);
+    }
     int32_t* sw = t;
     t = bk;
     bk = sw;
