@@ -418,6 +418,8 @@ def main():
         flops_agg = sum(2.0 * 15 * nnz.get((M, Ns), M * H) * C for _, (M, Ns, H, C, isz) in agg)
         n_search = 7 if args.no_upsampling else 10
         rs_launch = tk_rs / max(len(rsq), 1)                                         # one launch per step (all searches of a batch)
+        sp0 = stage_points
+        n_queries = 2 * sp0[0] + 3 * sp0[1] + 3 * sp0[2] + 2 * sp0[3] if not args.no_upsampling else sp0[0] + 2 * sp0[1] + 2 * sp0[2] + 2 * sp0[3]
         uses = [len(range(k, args.steps, nb_in)) for k in range(nb_in)]              # how often the timed region fed each batch
         bytes_rs = sum(u * search_bytes(sp, not args.no_upsampling) for u, sp in zip(uses, stage_points_all)) / max(args.steps, 1)
         traffic, traffic_src, traffic_rs = None, None, None
@@ -451,7 +453,13 @@ def main():
                              "algorithmic_bytes_per_launch": round(bytes_rs), "traffic": traffic_rs,
                              "achieved_alone": round(search_bytes(stage_points, not args.no_upsampling) / iso_rs / 1e9, 1),
                              "frac_alone": round(search_bytes(stage_points, not args.no_upsampling) / iso_rs / 1e9 / HBM_PEAK_GBS, 4),
-                             "ms_per_step_alone": round(iso_rs * 1e3, 4)},
+                             "ms_per_step_alone": round(iso_rs * 1e3, 4),
+                             # the search is bound by VALU ISSUE, not by HBM: rocprofv3 --pmc (profiles/r02_radius_pmc.md, unchanged kernel)
+                             # counts 354 VALU wavefront-instructions per query at 4 cycles each on a SIMD, i.e. 354 cycles per query and CU
+                             "instruction_floor": {"valu_cycles_per_query_per_cu": 354, "queries_per_step": int(n_queries),
+                                                   "ms_per_step": round(n_queries * 354 / 256 / 2.4e9 * 1e3, 4),
+                                                   "alone_over_floor": round(iso_rs / (n_queries * 354 / 256 / 2.4e9), 3),
+                                                   "source": "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU per query, profiles/r02_radius_pmc.md; 256 CUs at 2.4 GHz"}},
                 "aggregation": {"kernel": "lcr::k_kpconv_aggregate (fp32 MFMA 16x16x4, %d launches/step)" % per_step(agg), "bound": "mfma",
                                 "achieved": round(flops_agg / tk_agg / 1e12, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(flops_agg / tk_agg / 1e12 / FP32_PEAK_TFLOPS, 4), "gflop_per_step": round(flops_agg * SAMPLE / args.steps / 1e9, 2),

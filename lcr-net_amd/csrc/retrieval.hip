@@ -7,13 +7,18 @@
 // faiss is an un-vendored dependency (no version pinned): its IndexFlat L2 metric is the plain squared
 // Euclidean distance; only the order inside exact-distance ties is unspecified — here ties are broken by ascending index.
 //
-// MI355X design: the (Q x C) inner products come from lcr_gemm_f32 (fp32 MFMA, TB=1: Q·D^T), so the per-query faiss
-// rebuild loop (O(C^2) adds, minutes on the CPU) becomes one dense contraction; this file turns products into masked
-// distances and selects the k smallest per row:
-//   k_l2_mask  : d2[i][j] = |q_i|^2 + |d_j|^2 - 2 q_i·d_j, clamped at 0, +inf outside the window j < i - exclude;
-//   k_row_topk : one workgroup per query; the row (<= 160 KB / 4 = 40 K columns per pass, longer rows are chunked with
-//                a carried candidate list) is staged in LDS, the k-th smallest key is found with an 8-bit radix select
-//                over (d2 bits << 32 | j), and the <= k survivors are ordered by an all-pairs rank (k = 50).
+// MI355X design: the inner products come from lcr_gemm_f32 (fp32 MFMA, TB=1: Q·D^T), so the per-query faiss rebuild loop
+// (O(C^2) adds, minutes on the CPU) becomes dense contractions — over blocks of RT_ROWS query rows, each against only the
+// database columns its LAST row may see (j < i - exclude: the causal window halves the work and the product buffer is one block,
+// not Q x C).  k_row_topk then selects per row, one workgroup per query, in ONE pass over the row's products:
+//   * d2 = |q_i|^2 + |d_j|^2 - 2 q_i·d_j (clamped at 0) is formed on the fly — no masked-distance matrix is written;
+//   * the first TK_FIRST columns are staged in LDS and their k-th smallest key (d2 bits << 32 | j) found with an 8-bit radix
+//     select; that key is the admission threshold for the rest of the row, which is only STREAMED: a column is kept iff its key
+//     beats the threshold (on average k * (C / TK_FIRST - 1) of them), admitted keys collect in an LDS list that is re-selected
+//     (tightening the threshold) only when it could overflow, and once at the end;
+//   * the <= k survivors are ordered by an all-pairs rank.
+// (Round 2 materialised the masked Q x C distances and radix-selected every 16 K-column chunk of every row: 16.4 ms for the
+// 23 201-frame corpus of KITTI 00-10; this form: see profiles/r03_retrieval_bench.json.)
 #include <algorithm>
 #include <cmath>
 
@@ -22,8 +27,11 @@
 namespace lcr {
 
 constexpr int TK_T = 512;        // threads per top-k workgroup
-constexpr int TK_CHUNK = 16384;  // columns staged in LDS per pass (keys are 8 B)
+constexpr int TK_FIRST = 2048;   // columns staged for the first selection
+constexpr int TK_CAND = 4096;    // admitted keys collected before a re-selection
+constexpr int TK_STEP = 2048;    // columns streamed between two overflow checks (TK_CAND - TK_STEP - TK_KMAX keys always fit)
 constexpr int TK_KMAX = 128;     // largest k supported
+constexpr int RT_ROWS = 2048;    // query rows per product block
 
 __global__ __launch_bounds__(256) void k_row_sqnorm(const float* __restrict__ x, int64_t N, int D, float* __restrict__ out) {
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
@@ -38,89 +46,106 @@ __global__ __launch_bounds__(256) void k_row_sqnorm(const float* __restrict__ x,
   }
 }
 
-// in place: dots[i][j] -> masked squared distance.  Query row i is global frame q0 + i; database column j is frame j.
-__global__ __launch_bounds__(256) void k_l2_mask(float* __restrict__ dots, const float* __restrict__ qn, const float* __restrict__ dn, int64_t Q,
-                                                 int64_t C, int64_t q0, int exclude) {
-  const int64_t total = Q * C;
-  for (int64_t t = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; t < total; t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-    const int64_t i = t / C, j = t - i * C;
-    const float d2 = fmaxf(qn[i] + dn[j] - 2.f * dots[t], 0.f);
-    dots[t] = (j < q0 + i - exclude) ? d2 : INFINITY;
-  }
-}
-
 __device__ __forceinline__ uint64_t make_key(float d2, uint32_t j) { return (static_cast<uint64_t>(__float_as_uint(d2)) << 32) | j; }
 
-// k smallest (d2, j) of every row, ascending; rows with fewer than k finite entries are padded with (-1, +inf).
-__global__ __launch_bounds__(TK_T) void k_row_topk(const float* __restrict__ d2, int64_t C, int k, int32_t* __restrict__ out_idx,
+// Block-wide: the k-th smallest of keys[0..n) (unique keys, n > k) by an MSB-first 8-bit radix select.
+__device__ uint64_t tk_select(const uint64_t* keys, int n, int k, int* s_hist, uint64_t* s_prefix, int* s_need) {
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    *s_prefix = 0ull;
+    *s_need = k;
+  }
+  __syncthreads();
+  for (int pass = 7; pass >= 0; --pass) {
+    for (int i = tid; i < 256; i += TK_T) s_hist[i] = 0;
+    __syncthreads();
+    const uint64_t prefix = *s_prefix;
+    const uint64_t himask = pass == 7 ? 0ull : (~0ull << (8 * (pass + 1)));
+    for (int i = tid; i < n; i += TK_T) {
+      const uint64_t key = keys[i];
+      if ((key & himask) == prefix) atomicAdd(&s_hist[(key >> (8 * pass)) & 255], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int need = *s_need, b = 0;
+      for (; b < 256; ++b) {
+        if (s_hist[b] >= need) break;
+        need -= s_hist[b];
+      }
+      *s_need = need;
+      *s_prefix = prefix | (static_cast<uint64_t>(b) << (8 * pass));
+    }
+    __syncthreads();
+  }
+  return *s_prefix;
+}
+
+// k smallest (d2, j) of every row of a product block, ascending; rows with fewer than k admissible columns are padded with
+// (-1, +inf).  Row r of the block is global frame g = frame0 + r and sees columns j < min(ncols, g - exclude); dots[r][j] = q_g·d_j.
+__global__ __launch_bounds__(TK_T) void k_row_topk(const float* __restrict__ dots, int64_t ld, const float* __restrict__ qn, const float* __restrict__ dn,
+                                                   int64_t frame0, int exclude, int64_t ncols, int k, int32_t* __restrict__ out_idx,
                                                    float* __restrict__ out_d2) {
-  __shared__ uint64_t s_key[TK_CHUNK + TK_KMAX];   // chunk keys, followed by the carried best-k of earlier chunks
+  __shared__ uint64_t s_key[TK_CAND];      // first: the staged columns; then: [0, k) the best so far, [k, ..) admitted keys
   __shared__ uint64_t s_best[TK_KMAX];
   __shared__ int s_hist[256];
   __shared__ int s_cnt;
   __shared__ uint64_t s_prefix;
   __shared__ int s_need;
   const int64_t row = blockIdx.x;
-  const float* r = d2 + row * C;
+  const float* r = dots + row * ld;
   const int tid = threadIdx.x;
-  int nbest = 0;
-  const uint64_t INF_KEY = make_key(INFINITY, 0);   // every finite distance sorts below this
-  for (int64_t c0 = 0; c0 < C; c0 += TK_CHUNK) {
-    const int nc = static_cast<int>(std::min<int64_t>(TK_CHUNK, C - c0));
-    for (int i = tid; i < nc; i += TK_T) s_key[i] = make_key(r[c0 + i], static_cast<uint32_t>(c0 + i));
-    for (int i = tid; i < nbest; i += TK_T) s_key[nc + i] = s_best[i];
-    const int n = nc + nbest;
-    __syncthreads();
-    // radix select (MSB first) of the k-th smallest key among the n staged keys
-    if (tid == 0) {
-      s_prefix = 0ull;
-      s_need = k;
-    }
-    __syncthreads();
+  const int64_t lim = max(static_cast<int64_t>(0), min(ncols, frame0 + row - exclude));
+  const float qq = qn[row];
+  auto key_of = [&](int64_t j) { return make_key(fmaxf(qq + dn[j] - 2.f * r[j], 0.f), static_cast<uint32_t>(j)); };
+  // ---- first selection
+  const int n1 = static_cast<int>(min(lim, static_cast<int64_t>(TK_FIRST)));
+  for (int i = tid; i < n1; i += TK_T) s_key[i] = key_of(i);
+  __syncthreads();
+  int nbest = n1;                          // keys held in s_key[0, nbest)
+  uint64_t thr = ~0ull;                    // admission threshold: keys <= thr may still be among the k smallest
+  auto reselect = [&](int n) {             // keep the min(n, k) smallest of s_key[0, n) in s_key[0, nbest); block-uniform
     if (n > k) {
-      for (int pass = 7; pass >= 0; --pass) {
-        for (int i = tid; i < 256; i += TK_T) s_hist[i] = 0;
-        __syncthreads();
-        const uint64_t prefix = s_prefix;
-        const uint64_t himask = pass == 7 ? 0ull : (~0ull << (8 * (pass + 1)));
-        for (int i = tid; i < n; i += TK_T) {
-          const uint64_t key = s_key[i];
-          if ((key & himask) == prefix) atomicAdd(&s_hist[(key >> (8 * pass)) & 255], 1);
-        }
-        __syncthreads();
-        if (tid == 0) {
-          int need = s_need, b = 0;
-          for (; b < 256; ++b) {
-            if (s_hist[b] >= need) break;
-            need -= s_hist[b];
-          }
-          s_need = need;
-          s_prefix = prefix | (static_cast<uint64_t>(b) << (8 * pass));
-        }
-        __syncthreads();
+      thr = tk_select(s_key, n, k, s_hist, &s_prefix, &s_need);
+      // keys <= thr (exactly k: keys are unique) move to the front, through a side buffer (no key is overwritten before it is read)
+      if (tid == 0) s_cnt = 0;
+      __syncthreads();
+      for (int i = tid; i < n; i += TK_T) {
+        const uint64_t key = s_key[i];
+        if (key <= thr) s_best[atomicAdd(&s_cnt, 1)] = key;
       }
-    } else if (tid == 0) {
-      s_prefix = ~0ull;   // keep everything
+      __syncthreads();
+      for (int i = tid; i < k; i += TK_T) s_key[i] = s_best[i];
+      __syncthreads();
+      nbest = k;
+    } else {
+      nbest = n;
+    }
+  };
+  reselect(n1);
+  // ---- stream the rest of the row: admit what beats the threshold
+  if (tid == 0) s_cnt = nbest;
+  __syncthreads();
+  for (int64_t c0 = n1; c0 < lim; c0 += TK_STEP) {
+    const int64_t c1 = min(lim, c0 + TK_STEP);
+    for (int64_t j = c0 + tid; j < c1; j += TK_T) {
+      const uint64_t key = key_of(j);
+      if (key <= thr) s_key[atomicAdd(&s_cnt, 1)] = key;
     }
     __syncthreads();
-    // keys are unique (the column index is part of the key): exactly min(n, k) keys are <= the k-th key
-    const uint64_t kth = s_prefix;
-    if (tid == 0) s_cnt = 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += TK_T) {
-      const uint64_t key = s_key[i];
-      if (key <= kth && key < INF_KEY) s_best[atomicAdd(&s_cnt, 1)] = key;
+    const int n = s_cnt;                   // block-uniform
+    if (n + TK_STEP > TK_CAND || c1 >= lim) {
+      __syncthreads();
+      reselect(n);
+      if (tid == 0) s_cnt = nbest;
+      __syncthreads();
     }
-    __syncthreads();
-    nbest = s_cnt;
-    __syncthreads();
   }
-  // order the survivors (all-pairs rank, keys unique)
+  // ---- order the survivors (all-pairs rank, keys unique)
   for (int e = tid; e < k; e += TK_T) {
     if (e < nbest) {
-      const uint64_t key = s_best[e];
+      const uint64_t key = s_key[e];
       int rank = 0;
-      for (int j = 0; j < nbest; ++j) rank += s_best[j] < key;
+      for (int j = 0; j < nbest; ++j) rank += s_key[j] < key;
       out_idx[row * k + rank] = static_cast<int32_t>(static_cast<uint32_t>(key));
       out_d2[row * k + rank] = __uint_as_float(static_cast<uint32_t>(key >> 32));
     } else {
@@ -140,7 +165,7 @@ extern "C" int lcr_gemm_f32(const float* A, const float* B, float* C, int64_t M,
 extern "C" int lcr_retrieval_ws_bytes(int64_t Q, int64_t C, size_t* bytes) {
   if (!bytes || Q < 0 || C < 0) return LCR_EARG;
   Carver c(nullptr, ~size_t(0));
-  c.take<float>(static_cast<size_t>(std::max<int64_t>(Q * C, 1)));
+  c.take<float>(static_cast<size_t>(std::max<int64_t>(std::min<int64_t>(Q, RT_ROWS) * C, 1)));   // one block of products
   c.take<float>(static_cast<size_t>(std::max<int64_t>(Q, 1)));
   c.take<float>(static_cast<size_t>(std::max<int64_t>(C, 1)));
   *bytes = c.off;
@@ -166,16 +191,22 @@ extern "C" int lcr_retrieval_topk(const float* queries, int64_t Q, int64_t q0, c
   }
   if (Q == 0) return LCR_OK;
   Carver c(ws, ws_bytes);
-  float* d2 = c.take<float>(static_cast<size_t>(Q * C));
+  float* dots = c.take<float>(static_cast<size_t>(std::min<int64_t>(Q, RT_ROWS) * C));
   float* qn = c.take<float>(static_cast<size_t>(Q));
   float* dn = c.take<float>(static_cast<size_t>(C));
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(k_row_sqnorm, dim3(static_cast<int>(std::min<int64_t>((Q + 3) / 4, 4096))), dim3(256), 0, st, queries, Q, D, qn);
   hipLaunchKernelGGL(k_row_sqnorm, dim3(static_cast<int>(std::min<int64_t>((C + 3) / 4, 4096))), dim3(256), 0, st, database, C, D, dn);
-  int rc = lcr_gemm_f32(queries, database, d2, Q, static_cast<int>(C), D, 0, 1, nullptr, nullptr, nullptr, 0, 0, nullptr, stream);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_l2_mask, dim3(static_cast<int>(std::min<int64_t>((Q * C + 255) / 256, 8192))), dim3(256), 0, st, d2, qn, dn, Q, C, q0,
-                     exclude);
-  hipLaunchKernelGGL(k_row_topk, dim3(static_cast<int>(Q)), dim3(TK_T), 0, st, d2, C, k, out_idx, out_d2);
+  for (int64_t r0 = 0; r0 < Q; r0 += RT_ROWS) {
+    const int64_t rows = std::min<int64_t>(RT_ROWS, Q - r0);
+    // columns the block's last row may see (the window is causal: earlier rows see fewer; every row masks by its own bound)
+    const int64_t nb = std::max<int64_t>(0, std::min<int64_t>(C, q0 + r0 + rows - 1 - exclude));
+    if (nb > 0) {
+      int rc = lcr_gemm_f32(queries + r0 * D, database, dots, rows, static_cast<int>(nb), D, 0, 1, nullptr, nullptr, nullptr, 0, 0, nullptr, stream);
+      if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_row_topk, dim3(static_cast<int>(rows)), dim3(TK_T), 0, st, dots, nb, qn + r0, dn, q0 + r0, exclude, nb, k, out_idx + r0 * k,
+                       out_d2 + r0 * k);
+  }
   return check_launch("lcr_retrieval_topk");
 }
