@@ -76,7 +76,8 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate_vec(const fl
   constexpr int NL = C / (16 * V);           // vector loads per lane per 4-neighbour step
   constexpr int D = NL == 1 ? 4 : 2;         // steps in flight (register ring)
   typedef typename VecOf<V>::type VecT;
-  __shared__ __attribute__((aligned(16))) float4 s_rel[KP_WAVES][KP_HMAX + 8];   // (dx, dy, dz, bits(index)) per valid neighbour
+  constexpr int PAD = 4 * D + 4;             // list entries the register ring may read beyond the last neighbour
+  __shared__ __attribute__((aligned(16))) float4 s_rel[KP_WAVES][KP_HMAX + PAD];   // (dx, dy, dz, bits(index)) per valid neighbour
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
   const int sub = lane >> 4, col = lane & 15;
   const float inv_sigma = 1.f / sigma;
@@ -88,7 +89,6 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate_vec(const fl
       ky = kp.p[k][1];
       kz = kp.p[k][2];
     }
-  const bool real_k = col < KP_K;
   const XcdBand band = xcd_band(M, w, KP_WAVES);
   for (int64_t t = band.begin; t < band.end; t += band.stride) {
     const int64_t m = order ? order[t] : t;
@@ -109,6 +109,11 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate_vec(const fl
       n += __popcll(mk);
       cnt += __popcll(__ballot(positive));      // scalar popcount of a lane mask instead of a six-step cross-lane sum
     }
+    // The list is padded with far-away neighbours (relative position 1e6: linear influence exactly 0 for every kernel point; feature
+    // row 0, multiplied by that 0): the steps then need neither an index clamp nor an in-range mask — 6 of ~19 VALU instructions per
+    // 4-neighbour step in a kernel that is VALU-issue-bound for C <= 64.  (Lane column 15 is no kernel point: its influence is
+    // garbage, accumulates into row 15 of D and is never stored.)
+    if (lane < PAD) s_rel[w][n + lane] = make_float4(1e6f, 1e6f, 1e6f, __uint_as_float(0u));
     wave_lds_sync();
 
     floatx4 acc[NL][V];
@@ -120,21 +125,19 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate_vec(const fl
     float4 p[D];
     VecT f[D][NL];
     auto fetch = [&](int s, float4& pp, VecT (&ff)[NL]) {
-      const int h = 4 * s + sub;
-      pp = s_rel[w][h < n ? h : n - 1];
+      pp = s_rel[w][4 * s + sub];
       const float* r = s_feats + static_cast<int64_t>(__float_as_uint(pp.w)) * C + V * col;
 #pragma unroll
       for (int q = 0; q < NL; ++q) ff[q] = *reinterpret_cast<const VecT*>(r + q * 16 * V);
     };
-    // Branch-free steady state: steps are rounded up to a multiple of D and every fetch is issued unconditionally with its
-    // neighbour index clamped (a duplicate of the last row: a cache hit whose influence is masked to zero).  One basic block per
+    // Branch-free steady state: steps are rounded up to a multiple of D and every fetch is issued unconditionally (beyond the
+    // list's end it reads padding: row 0, a cache hit, with influence 0).  One basic block per
     // trip keeps the s_waitcnt counts exact, so the D-step register ring really runs D steps ahead; with conditional fetches
     // the compiler waited for vmcnt(0) — the load it had just issued — before every MFMA group.
     if (n > 0) {
       auto compute = [&](int s, const float4& pp, const VecT (&ff)[NL]) {
         const float ex = pp.x - kx, ey = pp.y - ky, ez = pp.z - kz;
-        float wv = fmaxf(1.f - __builtin_amdgcn_sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * inv_sigma, 0.f);
-        wv = (real_k && 4 * s + sub < n) ? wv : 0.f;
+        const float wv = fmaxf(1.f - __builtin_amdgcn_sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * inv_sigma, 0.f);
 #pragma unroll
         for (int q = 0; q < NL; ++q)
 #pragma unroll

@@ -39,8 +39,22 @@ def grid_subsample_device(points, lengths, voxel_size, key_bits_hint=0):
     return out, out_len, status
 
 
+MAX_CLOUDS = 64      # clouds per native call (GS_MAX_B in csrc/grid_subsample.hip); longer stacks are processed in groups
+
+
 def grid_subsample(points, lengths, voxel_size):
     """Grid subsampling in stack mode (GPU).  Returns (s_points (M,3), s_lengths (B,)) like the reference."""
+    if lengths.numel() > MAX_CLOUDS:                          # clouds are independent: groups of MAX_CLOUDS, results concatenated
+        lens, parts, plens, o = lengths.tolist(), [], [], 0
+        for g in range(0, len(lens), MAX_CLOUDS):
+            n_g = sum(lens[g:g + MAX_CLOUDS])
+            p, l = grid_subsample(points[o:o + n_g], lengths[g:g + MAX_CLOUDS].contiguous(), voxel_size)
+            parts.append(p)
+            plens.append(l)
+            o += n_g
+        if o != points.shape[0]:
+            raise RuntimeError("lcr_grid_subsample: lengths do not match the point tensor")
+        return torch.cat(parts), torch.cat(plens)
     out, out_len, status = grid_subsample_device(points, lengths, voxel_size)
     m = int(out_len.sum().item())   # host sync: the output shape is data dependent
     st = int(status.item())

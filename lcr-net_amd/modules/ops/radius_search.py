@@ -27,11 +27,16 @@ def _check(q_points, s_points, q_lengths, s_lengths):
         raise RuntimeError("q_lengths and s_lengths must have the same batch size")
 
 
+MAX_CLOUDS = 64      # clouds per native call (GRID_MAX_B in csrc/radius_search.hip); longer stacks are processed in groups
+
+
 def _call(q_points, s_points, q_lengths, s_lengths, radius, limit, want64, want32, want_cnt):
     dev = q_points.device
     q_lengths = q_lengths.to(dev, non_blocking=True)
     s_lengths = s_lengths.to(dev, non_blocking=True)
     B = q_lengths.numel()
+    if B > MAX_CLOUDS:
+        return _call_grouped(q_points, s_points, q_lengths, s_lengths, radius, limit, want64, want32, want_cnt)
     nq, ns = q_points.shape[0], s_points.shape[0]
     L = _lib.lib()
     nbytes = ctypes.c_size_t(0)
@@ -45,6 +50,31 @@ def _call(q_points, s_points, q_lengths, s_lengths, radius, limit, want64, want3
                                    nq, ns, float(radius), int(limit), _lib.ptr(out64), _lib.ptr(out32), _lib.ptr(cnt),
                                    _lib.ptr(status), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "lcr_radius_search")
     return out64, out32, cnt, status
+
+
+def _call_grouped(q_points, s_points, q_lengths, s_lengths, radius, limit, want64, want32, want_cnt):
+    """Stacks of more than MAX_CLOUDS clouds: clouds are independent, so the stack is cut into groups of MAX_CLOUDS (one host read
+    of the lengths), each group searched on its own rows, and the group-local indices moved to the stack's numbering (a group's pad
+    value — its own support count — becomes the stack's)."""
+    ql, sl = q_lengths.tolist(), s_lengths.tolist()
+    ns_total = s_points.shape[0]
+    outs64, outs32, cnts, status = [], [], [], torch.zeros(1, dtype=torch.int32, device=q_points.device)
+    qo = so = 0
+    for g in range(0, len(ql), MAX_CLOUDS):
+        nq_g, ns_g = sum(ql[g:g + MAX_CLOUDS]), sum(sl[g:g + MAX_CLOUDS])
+        o64, o32, c, st = _call(q_points[qo:qo + nq_g], s_points[so:so + ns_g], q_lengths[g:g + MAX_CLOUDS].contiguous(),
+                                s_lengths[g:g + MAX_CLOUDS].contiguous(), radius, limit, want64, want32, want_cnt)
+        for o, lst in ((o64, outs64), (o32, outs32)):
+            if o is not None:
+                lst.append(torch.where(o == ns_g, torch.full_like(o, ns_total), o + so))
+        if c is not None:
+            cnts.append(c)
+        status = status | st
+        qo, so = qo + nq_g, so + ns_g
+    if qo != q_points.shape[0] or so != ns_total:
+        status = status | 1                                   # lengths do not add up to the rows (LCR_STATUS_LEN_MISMATCH)
+    cat = lambda lst: torch.cat(lst) if lst else None
+    return cat(outs64), cat(outs32), cat(cnts), status
 
 
 def radius_count(q_points, s_points, q_lengths, s_lengths, radius):

@@ -179,8 +179,8 @@ def test_sixty_four_clouds_and_the_limit_beyond():
     want = oracle_ops.radius_search(xyz, xyz, lens, lens, 1.5, 16, ref_width=True)
     got = radius_search(dev(xyz), dev(xyz), dev(lens), dev(lens), 1.5, 16)
     assert np.array_equal(got.cpu().numpy(), want)
-    with pytest.raises(RuntimeError):
-        grid_subsample(dev(xyz), dev(np.concatenate([lens, [0]])), 1.0)        # 65 clouds
+    got_p, got_l = grid_subsample(dev(xyz), dev(np.concatenate([lens, [0]])), 1.0)        # 65 clouds: two native calls (round 3)
+    assert np.array_equal(got_l.cpu().numpy(), np.concatenate([want_l, [0]])) and np.array_equal(got_p.cpu().numpy().view(np.uint32), want_p.view(np.uint32))
 
 
 @pytest.mark.parametrize("seed", range(4))
@@ -330,3 +330,22 @@ def test_radius_search_fuzz_against_the_oracle(seed):
     assert np.array_equal(got.cpu().numpy().astype(np.int64), want), "neighbour rows"
     if seed % 3 == 1 and len(s) > 700:
         assert cnt.max() > 512                               # the storage-free fallback ran
+
+
+def test_more_than_64_clouds_per_call():
+    """The native calls take up to 64 clouds; the drop-in ops cut longer stacks into groups (clouds are independent) and return
+    what one call over the whole stack would: 150 small clouds through grid_subsample and radius_search vs the oracle."""
+    from lcrnet_amd.modules.ops import grid_subsample, radius_search
+    rng = np.random.default_rng(11)
+    scan = load_scan("003528")
+    sizes = [int(x) for x in rng.integers(30, 400, 150)]
+    clouds = [scan[rng.choice(len(scan), n, replace=False)] for n in sizes]
+    pts = np.concatenate(clouds).astype(np.float32)
+    lens = np.array(sizes, dtype=np.int64)
+    sp, sl = grid_subsample(torch.from_numpy(pts).cuda(), torch.from_numpy(lens).cuda(), 0.6)
+    wp, wl = oracle_ops.grid_subsample(pts, lens, 0.6)
+    assert sl.cpu().tolist() == wl.tolist() and np.array_equal(sp.cpu().numpy().view(np.uint32), wp.view(np.uint32))
+    idx = radius_search(sp, torch.from_numpy(pts).cuda(), sl, torch.from_numpy(lens).cuda(), 1.275, 40)
+    want = oracle_ops.radius_search(wp, pts, wl, lens, 1.275, 40)
+    want = want[:, :idx.shape[1]]
+    assert np.array_equal(idx.cpu().numpy(), want)
