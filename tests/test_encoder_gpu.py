@@ -371,3 +371,41 @@ def test_normalise_on_load_single_short_segment():
     torch.cuda.synchronize()
     assert (got - want).abs().max().item() < 2e-5 * want.abs().max().item()
     assert torch.allclose(wstats.sum(0), gstats.sum(0), rtol=1e-5, atol=1e-5 * wstats.sum(0).abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,K,rowdiv", [(6479, 256, 3840, True), (19061, 128, 1920, True), (5000, 96, 352, True), (777, 64, 288, False),
+                                          (130, 200, 512, False), (64, 64, 320, False), (127812, 32, 480, True), (3000, 24, 960, False)])
+def test_k_deep_gemm_form(M, N, K, rowdiv):
+    """The K-deep GEMM form (LDS-direct loads three tiles ahead, cross-step fragment prefetch: k_gemm_f32_deep) against the
+    register-staged kernel on the same operands — output and GroupNorm sums: bit-identical for the 64x64 tile (same K pairing, same
+    summation order), fp32-rounding-identical for N <= 32 (the old 128x32 tile alternates two accumulators) — and against an fp64
+    product.  Ragged M / N (clamped duplicate rows), K = 9..120 steps, segment boundaries inside tiles."""
+    import ctypes
+    from lcrnet_amd import _lib, functional as F
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).cuda()
+    b = torch.randn(N, K, generator=g).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    div = (torch.rand(M, generator=g) + 1).cuda() if rowdiv else None
+    groups = 32 if N % 32 == 0 and ((N // 32) & (N // 32 - 1)) == 0 else 0
+    seg = torch.tensor([M // 3, M // 3 + 5, M - 2 * (M // 3) - 5], dtype=torch.int64, device="cuda") if groups else None
+    kw = dict(trans_b=True, bias=bias, rowdiv=div, seg_len=seg, groups=groups)
+    try:
+        lib.lcr_gemm_debug_deep(0)
+        c0, s0 = F.gemm(a, b, **kw)
+        lib.lcr_gemm_debug_deep(1)
+        c1, s1 = F.gemm(a, b, **kw)
+    finally:
+        lib.lcr_gemm_debug_deep(-1)
+    ref = a.double() @ b.double().t()
+    if div is not None:
+        ref = ref / div.double()[:, None]
+    ref = ref + bias.double()
+    assert ((c1.double() - ref).abs().max() / ref.abs().max()).item() < 5e-6
+    if N > 32:
+        assert torch.equal(c0, c1)
+        if groups:
+            assert torch.equal(s0.sum(0), s1.sum(0)) or ((s0.sum(0) - s1.sum(0)).abs() / s0.sum(0).abs().clamp_min(1e-30)).max().item() < 1e-12
+    else:
+        assert (c0 - c1).abs().max().item() < 1e-3 * ref.abs().max().item()
