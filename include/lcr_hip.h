@@ -39,6 +39,7 @@ const char* lcr_last_error(void);
  * the logged events and returns the number of records of `kind`. */
 void lcr_ktimer_enable(int on);
 void lcr_ktimer_sample(int every);   /* time every n-th instrumented launch of a kind only (default 1 = all) */
+void lcr_ktimer_kinds(unsigned mask); /* time only the kinds whose bit is set (gemm 0, aggregate 1, radius 2, attention 3, fused 4; default all) */
 int lcr_ktimer_read(int kind, int max_records, double* seconds, int64_t* meta);
 /* same, plus the kernel's own begin-to-end duration (what a profiler reports; < 0 where a launch site does not record it) */
 int lcr_ktimer_read2(int kind, int max_records, double* seconds, double* seconds_kernel, int64_t* meta);
@@ -355,6 +356,16 @@ int lcr_procrustes_batched(const float* src, const float* ref, const float* w, c
 /* counts[p] = #{ |ref - T_p src| < radius } (-1 if the hypothesis came from < min_count correspondences); best = first argmax */
 int lcr_inlier_count(const float* T, int P, const float* src, const float* ref, int n, float radius, const int32_t* start,
                      int min_count, int32_t* counts, int32_t* best, void* stream);
+/* local_to_global_registration (geotransformer/local_global_registration.py:134-201) for S pairs in one launch sequence:
+ * correspondences stacked pair-major; hypothesis h = weighted Procrustes of rows [hyp_start[h], hyp_start[h+1]) (one per patch
+ * correspondence); pair s owns hypotheses [seg_hyp_start[s], seg_hyp_start[s+1]).  Per pair: inlier counts of its hypotheses over
+ * its own rows (chunks below min_count rows never win), first argmax, then `steps` re-weighted refits; a pair without a valid
+ * hypothesis starts from the fit over all its rows.  T_out f32[S,4,4]; optional hyp_out f32[H,4,4], counts_out i32[H], best_out
+ * i32[S] (-1: fallback).  No host synchronisation. */
+int lcr_lgr_ws_bytes(int64_t n, int H, int S, size_t* bytes);
+int lcr_local_global_registration(const float* src, const float* ref, const float* score, int64_t n, const int32_t* hyp_start, int H,
+                                  const int32_t* seg_hyp_start, int S, float radius, int min_count, int steps, float* T_out,
+                                  float* hyp_out, int32_t* counts_out, int32_t* best_out, void* ws, size_t ws_bytes, void* stream);
 /* w_out = score * [ |ref - T src| < radius ], T = T_all[sel ? *sel : 0]  (recompute_correspondence_scores, LGR :127-132) */
 int lcr_inlier_weights(const float* T_all, const int32_t* sel, const float* src, const float* ref, const float* score, int n,
                        float radius, float* w_out, void* stream);

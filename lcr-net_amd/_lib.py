@@ -40,6 +40,7 @@ _SIGS = {
                                    c_int, c_vp, c_vp]),
     "lcr_ktimer_enable": (None, [c_int]),
     "lcr_ktimer_sample": (None, [c_int]),
+    "lcr_ktimer_kinds": (None, [ctypes.c_uint]),
     "lcr_ktimer_read": (c_int, [c_int, c_int, c_vp, c_vp]),
     "lcr_ktimer_read2": (c_int, [c_int, c_int, c_vp, c_vp, c_vp]),
     "lcr_encoder_ws_bytes": (c_int, [c_vp, c_vp, c_int, c_size_p]),
@@ -77,6 +78,9 @@ _SIGS = {
     "lcr_procrustes_batched": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_float, c_vp, c_vp]),
     "lcr_inlier_count": (c_int, [c_vp, c_int, c_vp, c_vp, c_int, c_float, c_vp, c_int, c_vp, c_vp, c_vp]),
     "lcr_inlier_weights": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_float, c_vp, c_vp]),
+    "lcr_lgr_ws_bytes": (c_int, [c_i64, c_int, c_int, c_size_p]),
+    "lcr_local_global_registration": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_int, c_float, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                              ctypes.c_size_t, c_vp]),
     "lcr_netvlad_ws_bytes": (c_int, [c_i64, c_int, c_size_p]),
     "lcr_netvlad_forward": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
 }

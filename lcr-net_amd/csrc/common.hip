@@ -51,6 +51,7 @@ static std::vector<KtRec> g_kt_log;
 static std::vector<KtEvents> g_kt_pool;
 static std::atomic<int> g_kt_on{0};
 static std::atomic<int> g_kt_sample{1};          // every n-th instrumented launch of a kind is timed
+static std::atomic<unsigned> g_kt_kinds{~0u};    // bit k: launches of kind k are timed
 static std::atomic<unsigned> g_kt_seen[8];
 
 KernelTimerScope*& KernelTimerScope::current() {
@@ -60,7 +61,7 @@ KernelTimerScope*& KernelTimerScope::current() {
 KernelTimerScope::KernelTimerScope(int kind, hipStream_t stream, int64_t m0, int64_t m1, int64_t m2, int64_t m3, int64_t m4) : slot(-1), st(stream) {
   outer = current();
   current() = this;
-  if (!g_kt_on.load(std::memory_order_relaxed)) return;
+  if (!g_kt_on.load(std::memory_order_relaxed) || !((g_kt_kinds.load(std::memory_order_relaxed) >> (kind & 31)) & 1u)) return;
   const int every = g_kt_sample.load(std::memory_order_relaxed);
   if (every > 1 && g_kt_seen[kind & 7].fetch_add(1, std::memory_order_relaxed) % static_cast<unsigned>(every) != 0) return;
   std::lock_guard<std::mutex> lk(g_kt_mu);
@@ -308,6 +309,8 @@ extern "C" int lcr_debug_spin(int microseconds, void* stream) {
 // pipeline ran 7 % slower; sampled 1 in 9 the cost disappears in the noise, and since 9 is coprime with the 35 GEMMs / 10
 // aggregations of a step every shape is sampled equally often.
 extern "C" void lcr_ktimer_sample(int every) { lcr::g_kt_sample.store(every < 1 ? 1 : every); }
+// Time only the kinds whose bit is set (KT_GEMM = bit 0, ...): a tool that wants the attention launches does not pay for the others.
+extern "C" void lcr_ktimer_kinds(unsigned mask) { lcr::g_kt_kinds.store(mask); }
 extern "C" void lcr_ktimer_enable(int on) {
   std::lock_guard<std::mutex> lk(lcr::g_kt_mu);
   if (on) {

@@ -828,6 +828,82 @@ __global__ void k_argmax_i32(const int32_t* __restrict__ v, int n, int32_t* __re
   }
 }
 
+// ---- local-to-global registration of S pairs in one launch sequence --------------------------------------------------------
+// Correspondences of all pairs are stacked pair-major (inside a pair: patch-major, as top-1 matching emits them); hypothesis h is the
+// weighted Procrustes fit of chunk [hyp_start[h], hyp_start[h+1]); pair s owns hypotheses [seg_hyp_start[s], seg_hyp_start[s+1]) and
+// the rows they cover.  The same arithmetic as the single-pair kernels above, with every "over all correspondences" restricted to
+// the hypothesis's own pair.
+__global__ void k_lgr_seg_rows(const int32_t* __restrict__ hyp_start, const int32_t* __restrict__ seg_hyp_start, int S, int32_t* __restrict__ seg_row_start) {
+  for (int s = threadIdx.x; s <= S; s += blockDim.x) seg_row_start[s] = hyp_start[seg_hyp_start[s]];
+}
+
+__global__ __launch_bounds__(256) void k_inlier_count_seg(const float* __restrict__ T, const float* __restrict__ src, const float* __restrict__ ref,
+                                                          float radius, const int32_t* __restrict__ hyp_start, const int32_t* __restrict__ seg_hyp_start,
+                                                          const int32_t* __restrict__ seg_row_start, int S, int min_count, int32_t* __restrict__ counts) {
+  __shared__ int s_c, s_lo, s_hi;
+  const int h = blockIdx.x;
+  if (hyp_start[h + 1] - hyp_start[h] < min_count) {       // hypothesis from too few correspondences: never the best
+    if (threadIdx.x == 0) counts[h] = -1;
+    return;
+  }
+  if (threadIdx.x == 0) {
+    int sg = 0;
+    while (sg + 1 < S && h >= seg_hyp_start[sg + 1]) ++sg;
+    s_lo = seg_row_start[sg];
+    s_hi = seg_row_start[sg + 1];
+    s_c = 0;
+  }
+  __syncthreads();
+  const float* t = T + 16 * h;
+  int c = 0;
+  for (int i = s_lo + threadIdx.x; i < s_hi; i += 256) {
+    const float x = src[3 * i], y = src[3 * i + 1], z = src[3 * i + 2];
+    const float dx = ref[3 * i] - (t[0] * x + t[1] * y + t[2] * z + t[3]);
+    const float dy = ref[3 * i + 1] - (t[4] * x + t[5] * y + t[6] * z + t[7]);
+    const float dz = ref[3 * i + 2] - (t[8] * x + t[9] * y + t[10] * z + t[11]);
+    c += sqrtf(dx * dx + dy * dy + dz * dz) < radius ? 1 : 0;
+  }
+  atomicAdd(&s_c, c);
+  __syncthreads();
+  if (threadIdx.x == 0) counts[h] = s_c;
+}
+
+// per pair: the first hypothesis with the most inliers (torch.argmax order), or — when no chunk of the pair reached min_count
+// correspondences (local_global_registration.py:186-190) — the fit over all of the pair's correspondences
+__global__ void k_lgr_select(const float* __restrict__ hyp, const int32_t* __restrict__ counts, const int32_t* __restrict__ seg_hyp_start,
+                             const float* __restrict__ T_all_rows, float* __restrict__ T_sel, int32_t* __restrict__ best_out) {
+  const int s = blockIdx.x;
+  __shared__ int s_best;
+  if (threadIdx.x == 0) {
+    int best = -1, bc = -1;
+    for (int h = seg_hyp_start[s]; h < seg_hyp_start[s + 1]; ++h)
+      if (counts[h] > bc) {
+        bc = counts[h];
+        best = h;
+      }
+    s_best = bc >= 0 ? best : -1;
+    if (best_out) best_out[s] = s_best;
+  }
+  __syncthreads();
+  const float* from = s_best >= 0 ? hyp + 16 * s_best : T_all_rows + 16 * s;
+  if (threadIdx.x < 16) T_sel[16 * s + threadIdx.x] = from[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_inlier_weights_seg(const float* __restrict__ T_seg, const int32_t* __restrict__ seg_row_start, int S,
+                                                            const float* __restrict__ src, const float* __restrict__ ref,
+                                                            const float* __restrict__ score, int n, float radius, float* __restrict__ w_out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int sg = 0;
+    while (sg + 1 < S && i >= seg_row_start[sg + 1]) ++sg;
+    const float* t = T_seg + 16 * sg;
+    const float x = src[3 * i], y = src[3 * i + 1], z = src[3 * i + 2];
+    const float dx = ref[3 * i] - (t[0] * x + t[1] * y + t[2] * z + t[3]);
+    const float dy = ref[3 * i + 1] - (t[4] * x + t[5] * y + t[6] * z + t[7]);
+    const float dz = ref[3 * i + 2] - (t[8] * x + t[9] * y + t[10] * z + t[11]);
+    w_out[i] = sqrtf(dx * dx + dy * dy + dz * dz) < radius ? score[i] : 0.f;
+  }
+}
+
 }  // namespace lcr
 
 using namespace lcr;
@@ -1026,4 +1102,53 @@ extern "C" int lcr_inlier_weights(const float* T_all, const int32_t* sel, const 
   if (n == 0) return LCR_OK;
   hipLaunchKernelGGL(k_inlier_weights, dim3(blocks_for(n)), dim3(256), 0, ST(stream), T_all, sel, src, ref, score, n, radius, w_out);
   return check_launch("lcr_inlier_weights");
+}
+
+// LocalGlobalRegistration.local_to_global_registration (geotransformer/local_global_registration.py:134-201) for S pairs at once:
+// per-chunk hypotheses -> per-hypothesis inlier counts over the hypothesis's own pair -> best hypothesis per pair -> `steps`
+// re-weighted refits.  ~2*steps + 5 launches whatever S is, no host synchronisation.  ws: lcr_lgr_ws_bytes(n, H, S).
+extern "C" int lcr_lgr_ws_bytes(int64_t n, int H, int S, size_t* bytes) {
+  if (!bytes || n < 0 || H < 1 || S < 1) return LCR_EARG;
+  Carver c(nullptr, ~size_t(0));
+  c.take<float>(static_cast<size_t>(H) * 16);      // hypotheses
+  c.take<int32_t>(H);                              // inlier counts
+  c.take<int32_t>(S + 1);                          // first row of every pair
+  c.take<float>(static_cast<size_t>(S) * 16);      // fit over all rows of a pair
+  c.take<float>(static_cast<size_t>(S) * 16);      // current transform of a pair
+  c.take<float>(static_cast<size_t>(n > 0 ? n : 1));   // current weights
+  *bytes = c.off;
+  return LCR_OK;
+}
+extern "C" int lcr_local_global_registration(const float* src, const float* ref, const float* score, int64_t n, const int32_t* hyp_start, int H,
+                                             const int32_t* seg_hyp_start, int S, float radius, int min_count, int steps, float* T_out /*[S,4,4]*/,
+                                             float* hyp_out /*[H,4,4] or NULL*/, int32_t* counts_out /*[H] or NULL*/, int32_t* best_out /*[S] or NULL*/,
+                                             void* ws, size_t ws_bytes, void* stream) {
+  if (!src || !ref || !score || !hyp_start || !seg_hyp_start || !T_out || !ws || n < 1 || H < 1 || S < 1 || steps < 1 || n > 2147483647) {
+    set_error("lcr_local_global_registration: bad argument");
+    return LCR_EARG;
+  }
+  size_t need = 0;
+  lcr_lgr_ws_bytes(n, H, S, &need);
+  if (need > ws_bytes) return LCR_ESPACE;
+  Carver c(ws, ws_bytes);
+  float* hyp = c.take<float>(static_cast<size_t>(H) * 16);
+  int32_t* counts = c.take<int32_t>(H);
+  int32_t* seg_rows = c.take<int32_t>(S + 1);
+  float* T_rows = c.take<float>(static_cast<size_t>(S) * 16);
+  float* T_cur = c.take<float>(static_cast<size_t>(S) * 16);
+  float* cur = c.take<float>(static_cast<size_t>(n));
+  hipStream_t st = ST(stream);
+  const int ni = static_cast<int>(n);
+  hipLaunchKernelGGL(k_lgr_seg_rows, dim3(1), dim3(64), 0, st, hyp_start, seg_hyp_start, S, seg_rows);
+  hipLaunchKernelGGL(k_procrustes, dim3(H), dim3(64), 0, st, src, ref, score, hyp_start, 1e-5f, hyp);
+  hipLaunchKernelGGL(k_procrustes, dim3(S), dim3(64), 0, st, src, ref, score, seg_rows, 1e-5f, T_rows);
+  hipLaunchKernelGGL(k_inlier_count_seg, dim3(H), dim3(256), 0, st, hyp, src, ref, radius, hyp_start, seg_hyp_start, seg_rows, S, min_count, counts);
+  hipLaunchKernelGGL(k_lgr_select, dim3(S), dim3(64), 0, st, hyp, counts, seg_hyp_start, T_rows, T_cur, best_out);
+  for (int it = 0; it < steps; ++it) {
+    hipLaunchKernelGGL(k_inlier_weights_seg, dim3(blocks_for(n)), dim3(256), 0, st, T_cur, seg_rows, S, src, ref, score, ni, radius, cur);
+    hipLaunchKernelGGL(k_procrustes, dim3(S), dim3(64), 0, st, src, ref, cur, seg_rows, 1e-5f, it + 1 == steps ? T_out : T_cur);
+  }
+  if (hyp_out) hipMemcpyAsync(hyp_out, hyp, sizeof(float) * 16 * H, hipMemcpyDeviceToDevice, st);
+  if (counts_out) hipMemcpyAsync(counts_out, counts, sizeof(int32_t) * H, hipMemcpyDeviceToDevice, st);
+  return check_launch("lcr_local_global_registration");
 }

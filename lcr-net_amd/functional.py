@@ -50,6 +50,10 @@ def set_timer(timer, sample_every=1):
     """sample_every = n: only every n-th instrumented launch of each kind is timed (a timed launch is a profiled dispatch; with all
     of them timed the bench pipeline runs 7 % slower)."""
     _lib.lib().lcr_ktimer_sample(int(sample_every))
+    mask = 0
+    for name in (timer.names if timer is not None else ()):
+        mask |= 1 << KernelTimer.KINDS[name]
+    _lib.lib().lcr_ktimer_kinds(mask if timer is not None else 0xffffffff)     # only the kinds the timer asked for are clocked
     _lib.lib().lcr_ktimer_enable(1 if timer is not None else 0)
 
 
@@ -460,6 +464,26 @@ def inlier_count(T, src, ref, radius, start=None, min_count=0):
     _lib.check(_L().lcr_inlier_count(_lib.ptr(T), P, _lib.ptr(src), _lib.ptr(ref), src.shape[0], float(radius), _lib.ptr(start), int(min_count),
                                      _lib.ptr(counts), _lib.ptr(best), _sp(T)), "lcr_inlier_count")
     return counts, best
+
+
+def local_global_registration(src, ref, score, hyp_start, seg_hyp_start, radius, min_count, steps, want_details=False):
+    """local_to_global_registration (local_global_registration.py:134-201) for S pairs in one native call: correspondences stacked
+    pair-major, hyp_start int32 [H+1] (one chunk per patch correspondence), seg_hyp_start int32 [S+1] (the chunks of every pair)
+    -> T [S,4,4] (and, with want_details, the hypotheses [H,4,4], their inlier counts [H] and the winner per pair [S])."""
+    dev = src.device
+    n, H, S = src.shape[0], hyp_start.numel() - 1, seg_hyp_start.numel() - 1
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(_L().lcr_lgr_ws_bytes(n, H, S, ctypes.byref(nbytes)), "lcr_lgr_ws_bytes")
+    ws = _lib.workspace(nbytes.value, dev)
+    T = torch.empty((S, 4, 4), dtype=torch.float32, device=dev)
+    hyp = torch.empty((H, 4, 4), dtype=torch.float32, device=dev) if want_details else None
+    counts = torch.empty((H,), dtype=torch.int32, device=dev) if want_details else None
+    best = torch.empty((S,), dtype=torch.int32, device=dev) if want_details else None
+    _lib.check(_L().lcr_local_global_registration(_lib.ptr(src.contiguous()), _lib.ptr(ref.contiguous()), _lib.ptr(score.contiguous()), n,
+                                                  _lib.ptr(hyp_start.contiguous()), H, _lib.ptr(seg_hyp_start.contiguous()), S, float(radius), int(min_count),
+                                                  int(steps), _lib.ptr(T), _lib.ptr(hyp), _lib.ptr(counts), _lib.ptr(best), _lib.ptr(ws), ws.numel(), _sp(src)),
+               "lcr_local_global_registration")
+    return (T, hyp, counts, best) if want_details else T
 
 
 def inlier_weights(T_all, sel, src, ref, score, radius):

@@ -136,27 +136,31 @@ class LCRNet(nn.Module):
             self.netvlad = NetVLADLoupe2(feature_size=1024, cluster_size=64, output_dim=256, gating=True, add_norm=True, is_training=False)
 
     # ---- LocalGlobalRegistration (geotransformer/local_global_registration.py:134-246; k=1, mutual=False, dustbin) --------
-    def _local_global_registration(self, ref_knn_points, src_knn_points, ref_masks, src_masks, log_scores):
-        P, K = ref_masks.shape
+    def _local_global_registration_group(self, ref_knn_points, src_knn_points, ref_masks, src_masks, log_scores, patch_off):
+        """The registration tail of S pairs at once.  Patch correspondences of all pairs are stacked (pair s owns patches
+        [patch_off[s], patch_off[s+1])): ONE dustbin top-1 matching over all patches, the matched points gathered once, and the
+        hypothesis / inlier-count / refit sequence as one native call whose launches do not depend on S (`lcr_local_global_registration`:
+        hypotheses only compete inside their own pair).  -> list of (ref_corr_points, src_corr_points, corr_scores, T) per pair.
+        One host read-back of the per-pair correspondence counts (output shapes) on top of top-1 matching's own."""
+        Pn, K = ref_masks.shape
+        S = len(patch_off) - 1
         bij, sc = F.top1_matching(log_scores, ref_masks, src_masks)
         if bij.shape[0] == 0:
             raise RuntimeError("no dense correspondences (the reference fails here as well)")
         b, i, j = bij[:, 0].long(), bij[:, 1].long(), bij[:, 2].long()
         rp = F.gather_rows(ref_knn_points.reshape(-1, 3), b * K + i)
         sp = F.gather_rows(src_knn_points.reshape(-1, 3), b * K + j)
-        start = torch.zeros(P + 1, dtype=torch.int32, device=rp.device)
-        start[1:] = torch.cumsum(torch.bincount(b, minlength=P), 0).int()          # rows are patch-major: chunk p = [start[p], start[p+1])
-        hyp = F.procrustes(sp, rp, sc, start)                                         # one hypothesis per patch correspondence
-        counts, best = F.inlier_count(hyp, sp, rp, self.acceptance_radius, start, self.correspondence_threshold)
-        if bool((counts >= 0).any()):
-            cur = F.inlier_weights(hyp, best, sp, rp, sc, self.acceptance_radius)
-        else:                                                                          # degenerate: all correspondences at once (:186-190)
-            cur = F.inlier_weights(F.procrustes(sp, rp, sc), None, sp, rp, sc, self.acceptance_radius)
-        T = F.procrustes(sp, rp, cur)
-        for _ in range(self.num_refinement_steps - 1):
-            cur = F.inlier_weights(T, None, sp, rp, sc, self.acceptance_radius)
-            T = F.procrustes(sp, rp, cur)
-        return rp, sp, sc, T[0]
+        start = torch.zeros(Pn + 1, dtype=torch.int32, device=rp.device)
+        start[1:] = torch.cumsum(torch.bincount(b, minlength=Pn), 0).int()           # rows are patch-major: chunk p = [start[p], start[p+1])
+        seg = torch.tensor(list(patch_off), dtype=torch.int32, device=rp.device)
+        rows = start[seg.long()].tolist()                                             # host sync: first correspondence row of every pair
+        if any(rows[s + 1] == rows[s] for s in range(S)):
+            raise RuntimeError("no dense correspondences (the reference fails here as well)")
+        T = F.local_global_registration(sp, rp, sc, start, seg, self.acceptance_radius, self.correspondence_threshold, self.num_refinement_steps)
+        return [(rp[rows[s]:rows[s + 1]], sp[rows[s]:rows[s + 1]], sc[rows[s]:rows[s + 1]], T[s]) for s in range(S)]
+
+    def _local_global_registration(self, ref_knn_points, src_knn_points, ref_masks, src_masks, log_scores):
+        return self._local_global_registration_group(ref_knn_points, src_knn_points, ref_masks, src_masks, log_scores, [0, ref_masks.shape[0]])[0]
 
     def forward(self, data_dict, pose=True):
         """Pair stack [pos(ref), anc(src)] (data.py:110-113) -> the reference's output_dict (LCRNet.py:274-321).  GroupNorm
@@ -316,10 +320,11 @@ class LCRNet(nn.Module):
         pkf, akf = F.gather_rows(feats_f, pk_g), F.gather_rows(feats_f, ak_g)
         ms = F.log_optimal_transport(F.bmm_nt(pkf, akf), pkm, akm, self.optimal_transport.alpha,
                                      scale=1.0 / feats_f.shape[1] ** 0.5, iters=self.optimal_transport.num_iterations)
+        lgr = self._local_global_registration_group(pkp, akp, pkm, akm, ms, q_off)      # all pairs: one matching, one registration sequence
         for p in range(P):
             q = slice(q_off[p], q_off[p + 1])
             c = 2 * p
-            rp, sp, sc, T = self._local_global_registration(pkp[q], akp[q], pkm[q], akm[q], ms[q])
+            rp, sp, sc, T = lgr[p]
             pi, ai = node_idx[p]
             outs[p].update({
                 "pos_points_c": vd["points_c"][off_m[c]:off_m[c + 1]], "anc_points_c": vd["points_c"][off_m[c + 1]:off_m[c + 2]],
