@@ -650,7 +650,7 @@ __device__ __forceinline__ void glds16(const float* base, unsigned off, unsigned
 }
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(GM_T, 3) void k_gemm_f32_deep(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+__global__ __launch_bounds__(GM_T, (BM == 64 ? 3 : 2)) void k_gemm_f32_deep(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                                             int64_t M, int N, int K, GemmEpilogue ep) {
   static_assert(WM * WN == 4 && BM == 32 * WM && BN == 32 * WN, "one 32x32 accumulator per wavefront");
   constexpr int LA = BM / 32, LB = BN / 32, LPW = LA + LB;   // 1-KB load instructions per wavefront and tile (8 rows each)
