@@ -8,7 +8,8 @@
 //                  adjacent channel pair; the SAME theta rotates q and k), one pass, sincosf once per pair;
 //   k_attention  : flash-style fused QK^T / softmax / PV on the fp32 matrix cores — the only dense QK^T·V on the path, so
 //                  this is where MFMA is spent (v_mfma_f32_32x32x2_f32; fp32 inputs are required for the 1e-4 tolerance).
-//                  One wavefront per (head, 32-query tile).  Scores are computed TRANSPOSED (S^T = K·Q^T) so that a lane
+//                  One workgroup of four wavefronts per (head, 32-query tile), the key blocks dealt round-robin to the wavefronts and
+//                  the partial softmax states merged through LDS (round 3: 72 -> 26 us per launch for one pair).  Scores are computed TRANSPOSED (S^T = K·Q^T) so that a lane
 //                  owns one query column: its running max / sum / rescale are per-lane scalars, the 32 keys of a tile sit
 //                  in the lane's 16 accumulator registers + its partner lane's (lane ^ 32), and P feeds the second MFMA
 //                  (O^T = V^T·P^T) straight from registers with one cross-half swap per step — no LDS round trip for P,
@@ -84,15 +85,23 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ src, int64_t
 }
 
 // one (head, 32-query tile) of one attention problem: q [Nq, H*32], k/v [Nk, H*32] -> out [Nq, H*32]; 64 threads
+// Key split: the AT_SPLIT wavefronts of a workgroup share the query tile and take the 32-key blocks w, w + AT_SPLIT, ... each with its
+// own running (max, sum, O^T); the partial states are merged through LDS at the end (O = sum_w O_w e^{m_w - m} / sum_w l_w e^{m_w - m}).
+// One wavefront per tile walked all ~26 key blocks of a cloud one after the other, every block a dependent chain (S^T MFMAs -> softmax
+// -> P·V MFMAs), and a pair's layer was 108 wavefronts on 1 024 SIMDs: the launch took as long as that one chain (68-90 us).
+constexpr int AT_SPLIT = 4;
+struct AttnMerge {
+  float m[AT_SPLIT][32], l[AT_SPLIT][32];
+  float o[AT_SPLIT][16][64];
+};
 __device__ __forceinline__ void attention_tile(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                int64_t Nq, int64_t Nk, int heads, float scale, float* __restrict__ out, int64_t q0, int head,
-                                               float* s_q, float* s_k, float* s_v) {
+                                               float* s_q, float* s_k, float* s_v, AttnMerge* mg) {
   const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
+  const int wsp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // this wavefront's share of the key blocks
   const int ld = heads * AT_D;
-  load_tile(q, Nq, q0, ld, head * AT_D, s_q);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (wsp == 0) load_tile(q, Nq, q0, ld, head * AT_D, s_q);
+  __syncthreads();
   // B operand of S^T = K·Q^T: B[kd][j=query] = Q[query][kd]; hoisted: 16 values per lane
   float qf[16];
 #pragma unroll
@@ -104,9 +113,12 @@ __device__ __forceinline__ void attention_tile(const float* __restrict__ q, cons
   float m = -INFINITY, l = 0.f;
 
   float4 kreg[4], vreg[4];
-  tile_to_regs(k, Nk, 0, ld, head * AT_D, kreg);
-  tile_to_regs(v, Nk, 0, ld, head * AT_D, vreg);
-  for (int64_t k0 = 0; k0 < Nk; k0 += 32) {
+  const int64_t kb0 = 32 * static_cast<int64_t>(wsp), kstep = 32 * AT_SPLIT;
+  if (kb0 < Nk) {
+    tile_to_regs(k, Nk, kb0, ld, head * AT_D, kreg);
+    tile_to_regs(v, Nk, kb0, ld, head * AT_D, vreg);
+  }
+  for (int64_t k0 = kb0; k0 < Nk; k0 += kstep) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();                      // everyone is done reading the previous tile
     regs_to_lds(kreg, s_k);
@@ -114,9 +126,9 @@ __device__ __forceinline__ void attention_tile(const float* __restrict__ q, cons
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (k0 + 32 < Nk) {                                   // next tile's loads fly while this tile's 32 MFMAs run
-      tile_to_regs(k, Nk, k0 + 32, ld, head * AT_D, kreg);
-      tile_to_regs(v, Nk, k0 + 32, ld, head * AT_D, vreg);
+    if (k0 + kstep < Nk) {                                // next tile's loads fly while this tile's 32 MFMAs run
+      tile_to_regs(k, Nk, k0 + kstep, ld, head * AT_D, kreg);
+      tile_to_regs(v, Nk, k0 + kstep, ld, head * AT_D, vreg);
     }
     // S^T[key][query] = sum_d K[key][d] * Q[query][d]
     floatx16 s;
@@ -165,23 +177,46 @@ __device__ __forceinline__ void attention_tile(const float* __restrict__ q, cons
       o = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, o, 0, 0, 0);
     }
   }
+  // merge the AT_SPLIT partial states: wavefront w finishes accumulator rows 4w .. 4w+3 of every lane
+  if (half == 0) {
+    mg->m[wsp][col] = m;                                    // -inf / 0 for a wavefront without key blocks (fewer than 32 w keys)
+    mg->l[wsp][col] = l;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mg->o[wsp][r][lane] = o[r];
+  __syncthreads();
+  float mm = -INFINITY;
+#pragma unroll
+  for (int u = 0; u < AT_SPLIT; ++u) mm = fmaxf(mm, mg->m[u][col]);
+  float lsum = 0.f, wgt[AT_SPLIT];
+#pragma unroll
+  for (int u = 0; u < AT_SPLIT; ++u) {
+    wgt[u] = expf(mg->m[u][col] - mm);                      // exp(-inf) = 0; wavefront 0 always has a block, so mm is finite
+    lsum += mg->l[u][col] * wgt[u];
+  }
   // O^T[d][query]: lane = query `col`, rows d = (r&3) + 8*(r>>2) + 4*half
   const int64_t qi = q0 + col;
   if (qi < Nq) {
-    const float inv = 1.f / l;
+    const float inv = 1.f / lsum;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int rr = 0; rr < 16 / AT_SPLIT; ++rr) {
+      const int r = wsp * (16 / AT_SPLIT) + rr;
+      float acc = 0.f;
+#pragma unroll
+      for (int u = 0; u < AT_SPLIT; ++u) acc += mg->o[u][r][lane] * wgt[u];
       const int d = (r & 3) + 8 * (r >> 2) + 4 * half;
-      out[qi * ld + head * AT_D + d] = o[r] * inv;
+      out[qi * ld + head * AT_D + d] = acc * inv;
     }
   }
 }
 
 // grid (ceil(Nq/32), H)
-__global__ __launch_bounds__(64) void k_attention(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-                                                  int64_t Nq, int64_t Nk, int heads, float scale, float* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) float s_q[32 * AT_LD], s_k[32 * AT_LD], s_v[32 * AT_LD];
-  attention_tile(q, k, v, Nq, Nk, heads, scale, out, static_cast<int64_t>(blockIdx.x) * 32, blockIdx.y, s_q, s_k, s_v);
+__global__ __launch_bounds__(64 * AT_SPLIT) void k_attention(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                             int64_t Nq, int64_t Nk, int heads, float scale, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float s_q[32 * AT_LD], s_k[AT_SPLIT][32 * AT_LD], s_v[AT_SPLIT][32 * AT_LD];
+  __shared__ AttnMerge s_mg;
+  const int wsp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  attention_tile(q, k, v, Nq, Nk, heads, scale, out, static_cast<int64_t>(blockIdx.x) * 32, blockIdx.y, s_q, s_k[wsp], s_v[wsp], &s_mg);
 }
 
 // Several independent attention problems in ONE launch (registration pairs batched per call: the self layers of 2P clouds, the
@@ -192,15 +227,17 @@ struct AttnSeg {
   int P;
   int q_off[AT_MAX_P + 1], k_off[AT_MAX_P + 1], tile_off[AT_MAX_P + 1];   // row offsets; first query tile of every problem
 };
-__global__ __launch_bounds__(64) void k_attention_seg(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-                                                      AttnSeg seg, int heads, float scale, float* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) float s_q[32 * AT_LD], s_k[32 * AT_LD], s_v[32 * AT_LD];
+__global__ __launch_bounds__(64 * AT_SPLIT) void k_attention_seg(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                                 AttnSeg seg, int heads, float scale, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float s_q[32 * AT_LD], s_k[AT_SPLIT][32 * AT_LD], s_v[AT_SPLIT][32 * AT_LD];
+  __shared__ AttnMerge s_mg;
+  const int wsp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int p = 0;
   while (p + 1 < seg.P && static_cast<int>(blockIdx.x) >= seg.tile_off[p + 1]) ++p;      // block-uniform, scalar
   const int ld = heads * AT_D;
   const int64_t qo = seg.q_off[p], ko = seg.k_off[p];
   attention_tile(q + qo * ld, k + ko * ld, v + ko * ld, seg.q_off[p + 1] - qo, seg.k_off[p + 1] - ko, heads, scale, out + qo * ld,
-                 static_cast<int64_t>(static_cast<int>(blockIdx.x) - seg.tile_off[p]) * 32, blockIdx.y, s_q, s_k, s_v);
+                 static_cast<int64_t>(static_cast<int>(blockIdx.x) - seg.tile_off[p]) * 32, blockIdx.y, s_q, s_k[wsp], s_v[wsp], &s_mg);
 }
 
 // y = LayerNorm(a + b) * gamma + beta, rows of D (<= 1024) features; one wavefront per row
@@ -260,7 +297,7 @@ extern "C" int lcr_attention_f32(const float* q, const float* k, const float* v,
   if (Nq == 0) return LCR_OK;
   const float scale = 1.f / sqrtf(static_cast<float>(head_dim));
   KernelTimerScope timed(KT_ATTENTION, static_cast<hipStream_t>(stream), Nq * Nk, 1, heads, head_dim);
-  hipLaunchKernelGGL(k_attention, dim3(static_cast<int>((Nq + 31) / 32), heads), dim3(64), 0, static_cast<hipStream_t>(stream), q, k, v, Nq, Nk,
+  hipLaunchKernelGGL(k_attention, dim3(static_cast<int>((Nq + 31) / 32), heads), dim3(64 * AT_SPLIT), 0, static_cast<hipStream_t>(stream), q, k, v, Nq, Nk,
                      heads, scale, out);
   return check_launch("lcr_attention_f32");
 }
@@ -299,7 +336,7 @@ extern "C" int lcr_attention_seg_f32(const float* q, const float* k, const float
   int64_t qk = 0;
   for (int p = 0; p < P; ++p) qk += q_len_host[p] * k_len_host[p];
   KernelTimerScope timed(KT_ATTENTION, static_cast<hipStream_t>(stream), qk, P, heads, head_dim);
-  hipLaunchKernelGGL(k_attention_seg, dim3(static_cast<int>(to), heads), dim3(64), 0, static_cast<hipStream_t>(stream), q, k, v, seg, heads, scale, out);
+  hipLaunchKernelGGL(k_attention_seg, dim3(static_cast<int>(to), heads), dim3(64 * AT_SPLIT), 0, static_cast<hipStream_t>(stream), q, k, v, seg, heads, scale, out);
   return check_launch("lcr_attention_seg_f32");
 }
 
