@@ -361,7 +361,11 @@ __global__ __launch_bounds__(SKR_T) void k_log_sinkhorn_reg(float* __restrict__ 
     if (t >= N1) v[t] = 0.f;
   }
   __syncthreads();
+  // Exact early exit: when a whole iteration leaves every u AND every v bit-identical, all later iterations repeat it — the result is
+  // the one the full `iters` would give, to the bit.  (The patch problems of real pairs reach their fp32 fixed point long before the
+  // reference's 100 iterations; a problem that keeps flipping a last bit simply runs them all.)
   for (int it = 0; it < iters; ++it) {
+    int changed = 0;
     {
       float2v x[SKR_P];
 #pragma unroll
@@ -370,7 +374,11 @@ __global__ __launch_bounds__(SKR_T) void k_log_sinkhorn_reg(float* __restrict__ 
         x[k] = R[k] + d;
       }
       const float lse = skr_lse2(x, row_live);
-      if (row_live && part == 0) u[line] = log_mu[line] - lse;
+      if (row_live && part == 0) {
+        const float un = log_mu[line] - lse;
+        changed |= __float_as_uint(un) != __float_as_uint(u[line]);
+        u[line] = un;
+      }
     }
     __syncthreads();
     {
@@ -381,9 +389,13 @@ __global__ __launch_bounds__(SKR_T) void k_log_sinkhorn_reg(float* __restrict__ 
         x[k] = Cc[k] + d;
       }
       const float lse = skr_lse2(x, col_live);
-      if (col_live && part == 0) v[line] = log_nu[line] - lse;
+      if (col_live && part == 0) {
+        const float vn = log_nu[line] - lse;
+        changed |= __float_as_uint(vn) != __float_as_uint(v[line]);
+        v[line] = vn;
+      }
     }
-    __syncthreads();
+    if (!__syncthreads_or(changed)) break;
   }
   if (row_live) {
     const float ui = u[line], nrm = s_norm;
