@@ -338,6 +338,12 @@ int lcr_build_padded_scores(const float* raw, const uint8_t* row_mask, const uin
 /* LearnableLogOptimalTransport.forward (learnable_sinkhorn.py:13-66) in place on S; uv_ws: B*(2*(M+N+2)+1) floats. */
 int lcr_log_sinkhorn(float* S, const uint8_t* row_mask, const uint8_t* col_mask, int64_t B, int M, int N, int iters,
                      float inf_val, float* uv_ws, void* stream);
+/* same with a workspace of lcr_log_sinkhorn_ws_floats(B, M, N) floats: matrices beyond LDS (the ~350 x 330 node level) then run as ONE
+ * persistent launch (row slabs per workgroup, one counter hand-off per iteration) instead of two launches per iteration; the last
+ * floats of the workspace hold a status word (bit 0: a hand-off timed out — the result is then invalid). */
+int lcr_log_sinkhorn_ws_floats(int64_t B, int M, int N, size_t* floats);
+int lcr_log_sinkhorn_ex(float* S, const uint8_t* row_mask, const uint8_t* col_mask, int64_t B, int M, int N, int iters,
+                        float inf_val, float* uv_ws, size_t uv_floats, void* stream);
 /* Dustbin top-1 matching in the exp domain (superpoint_matching.py:130-162; local_global_registration.py:49-92 with k=1,
  * mutual=False, use_dustbin=True): (b,i,j) kept if it is its row's maximum beating the dustbin column OR its column's
  * maximum beating the dustbin row (and row/col masks, if given).  Phase 1: out_bij == NULL -> *total (device i64);

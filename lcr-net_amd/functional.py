@@ -380,6 +380,22 @@ def point_to_node_partition(points, nodes, point_limit):
     return p2n, nm.bool(), knn, km.bool()
 
 
+class _PendingStatus(threading.local):
+    def __init__(self):
+        self.items = []
+
+
+_pending_ot_status = _PendingStatus()
+
+
+def check_transport_status():
+    """Raise if a persistent optimal-transport launch issued by this thread reported a timed-out hand-off (its result is invalid).
+    One host read; called where the caller synchronises anyway (top1_matching reads a count back right after the transport)."""
+    items, _pending_ot_status.items = _pending_ot_status.items, []
+    if items and int(torch.stack([t.reshape(()) for t in items]).max().item()) != 0:
+        raise RuntimeError("lcr_log_sinkhorn: a workgroup hand-off of the persistent form timed out (set LCR_SINKHORN_COOP=0)")
+
+
 def log_optimal_transport(raw_scores, row_masks, col_masks, alpha, scale=1.0, iters=100, inf=1e12):
     """LearnableLogOptimalTransport on raw products [B,M,N] (scaled by `scale`) -> log scores [B,M+1,N+1]."""
     B, M, N = raw_scores.shape
@@ -388,8 +404,12 @@ def log_optimal_transport(raw_scores, row_masks, col_masks, alpha, scale=1.0, it
     S = torch.empty((B, M + 1, N + 1), dtype=torch.float32, device=dev)
     _lib.check(_L().lcr_build_padded_scores(_lib.ptr(raw_scores.contiguous()), _lib.ptr(rm), _lib.ptr(cm), B, M, N, float(scale),
                                             _lib.ptr(alpha.reshape(1).float()), float(inf), _lib.ptr(S), _sp(S)), "lcr_build_padded_scores")
-    uv = torch.empty((B * (2 * (M + N + 2) + 1),), dtype=torch.float32, device=dev)
-    _lib.check(_L().lcr_log_sinkhorn(_lib.ptr(S), _lib.ptr(rm), _lib.ptr(cm), B, M, N, int(iters), float(inf), _lib.ptr(uv), _sp(S)),
+    nfl = ctypes.c_size_t(0)
+    _lib.check(_L().lcr_log_sinkhorn_ws_floats(B, M, N, ctypes.byref(nfl)), "lcr_log_sinkhorn_ws_floats")
+    uv = torch.empty((nfl.value,), dtype=torch.float32, device=dev)
+    uv[-1:].zero_()                                   # status word: bit 0 = a hand-off of the persistent form timed out
+    _pending_ot_status.items.append(uv[-1:].view(torch.int32))
+    _lib.check(_L().lcr_log_sinkhorn_ex(_lib.ptr(S), _lib.ptr(rm), _lib.ptr(cm), B, M, N, int(iters), float(inf), _lib.ptr(uv), uv.numel(), _sp(S)),
                "lcr_log_sinkhorn")
     return S
 
@@ -408,6 +428,7 @@ def top1_matching(log_scores, row_masks=None, col_masks=None):
     args = (_lib.ptr(log_scores.contiguous()), B, M, N, _lib.ptr(rm), _lib.ptr(cm))
     _lib.check(_L().lcr_top1_matching(*args, _lib.ptr(total), None, None, _lib.ptr(ws), ws.numel(), _sp(log_scores)), "lcr_top1_matching")
     n = int(total.item())
+    check_transport_status()
     bij = torch.empty((max(n, 1), 3), dtype=torch.int32, device=dev)
     sc = torch.empty((max(n, 1),), dtype=torch.float32, device=dev)
     if n:
