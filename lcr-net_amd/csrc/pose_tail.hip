@@ -336,9 +336,11 @@ __device__ __forceinline__ float skr_lse2(const float2v (&x)[SKR_P], bool live) 
 }
 
 __global__ __launch_bounds__(SKR_T) void k_log_sinkhorn_reg(float* __restrict__ S, const uint8_t* __restrict__ row_mask,
-                                                            const uint8_t* __restrict__ col_mask, int M, int N, int iters, float inf_val) {
+                                                            const uint8_t* __restrict__ col_mask, int M, int N, int iters, float inf_val,
+                                                            const unsigned* __restrict__ only) {
   __shared__ float u[SKR_LINES + 8], v[SKR_LINES + 8], log_mu[SKR_LINES + 8], log_nu[SKR_LINES + 8];
   __shared__ float s_norm;
+  if (only && !only[blockIdx.x]) return;      // second launch behind k_sinkhorn_scaled: only the problems it handed back
   const int64_t b = blockIdx.x;
   const int M1 = M + 1, N1 = N + 1;
   float* sg = S + b * M1 * N1;
@@ -528,6 +530,220 @@ __global__ __launch_bounds__(256) void k_sk_final(float* __restrict__ S, int M, 
   }
 }
 
+// (a'') patch level, SCALED form (the default for matrices up to 132 x 132): the same iteration as the log-domain kernels, carried in the
+//      exponential domain.  With gauges a, b (base-2 logarithms) and K~_ij = 2^(S2_ij + a_i + b_j), the duals are u_i = a_i + log2 u~_i,
+//      v_j = b_j + log2 v~_j and one iteration is  u~_i = mu_i / sum_j K~_ij v~_j,  v~_j = nu_j / sum_i K~_ij u~_i  — one packed FMA per
+//      two entries instead of a max, a subtraction and a quarter-rate exponential per entry.  It is the reference's sequence of iterates
+//      (optimal_transport's u/v updates) in exact arithmetic for ANY gauge; fp32 range is kept by re-gauging: whenever a scale leaves
+//      [2^-40, 2^40] the scales are folded into a, b and K~ is rebuilt from the scores (one exponential pass, a handful of times per
+//      problem, all in its first iterations).  Entries below 2^-126 of their row's largest flush to zero — they are below 2^-80 of
+//      every sum they enter.  A problem whose sums leave [2^-100, 2^100] anyway (or turn NaN) is handed back untouched through
+//      `redo[b]` to the log-domain kernel launched behind this one.  Fully masked lines keep u = 0 / v = 0, as the reference's fp32
+//      arithmetic gives them (-1e12 - (-1e12)).  Entry e of part p is column (row) 33 p + e, so a thread's 33 scales are 8 ds_read_b128
+//      + one b64 from a 36-float-strided copy of the scale vector.
+constexpr int SKS_STRIDE = 36;
+constexpr float SKS_BAND_HI = 1.099511627776e12f, SKS_BAND_LO = 1.f / 1.099511627776e12f;      // 2^40
+constexpr float SKS_FAIL_HI = 1.2676506e30f, SKS_FAIL_LO = 1.f / 1.2676506e30f;                // 2^100
+__device__ __forceinline__ int sks_pos(int idx) { return (idx / SKR_E) * SKS_STRIDE + idx % SKR_E; }
+
+__device__ __forceinline__ void sks_build(const float* __restrict__ sm, int line, int part, bool row_live, bool col_live, int M1, int N1,
+                                          const float* ga, const float* gb, float2v (&KR)[SKR_P], float2v (&KC)[SKR_P]) {
+  const int pl = sks_pos(min(line, SKR_LINES - 1));
+  const float ar = row_live ? ga[pl] : 0.f, bc = col_live ? gb[pl] : 0.f;
+  // reads are unconditional from clamped (in-range) LDS addresses and selected afterwards
+  const int rl = min(line, M1 - 1), cl = min(line, N1 - 1);
+  const float* gpa = ga + part * SKS_STRIDE;
+  const float* gpb = gb + part * SKS_STRIDE;
+  {
+    float t[2 * SKR_P];
+#pragma unroll
+    for (int e = 0; e < SKR_E; ++e) t[e] = sm[rl * N1 + min(part * SKR_E + e, N1 - 1)];
+    t[2 * SKR_P - 1] = 0.f;
+#pragma unroll
+    for (int e = 0; e < SKR_E; ++e) {
+      const float x = exp2_hw(fmaf(t[e], SKR_LOG2E, ar + gpb[e]));
+      t[e] = (row_live && part * SKR_E + e < N1) ? x : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < SKR_P; ++k) KR[k] = float2v{t[2 * k], t[2 * k + 1]};
+  }
+  {
+    float t[2 * SKR_P];
+#pragma unroll
+    for (int e = 0; e < SKR_E; ++e) t[e] = sm[min(part * SKR_E + e, M1 - 1) * N1 + cl];
+    t[2 * SKR_P - 1] = 0.f;
+#pragma unroll
+    for (int e = 0; e < SKR_E; ++e) {
+      const float x = exp2_hw(fmaf(t[e], SKR_LOG2E, gpa[e] + bc));
+      t[e] = (col_live && part * SKR_E + e < M1) ? x : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < SKR_P; ++k) KC[k] = float2v{t[2 * k], t[2 * k + 1]};
+  }
+}
+
+// sum over this thread's 33 entries of K[e] * scale[33 part + e], folded over the four parts of the line
+__device__ __forceinline__ float sks_dot(const float2v (&K)[SKR_P], const float* sc, int part) {
+  const float4* sp = reinterpret_cast<const float4*>(sc + part * SKS_STRIDE);
+  float4 t[SKR_P / 2];
+#pragma unroll
+  for (int q = 0; q < SKR_P / 2; ++q) t[q] = sp[q];
+  const float2 t2 = *reinterpret_cast<const float2*>(sc + part * SKS_STRIDE + 4 * (SKR_P / 2));
+  float2v acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < SKR_P / 2; ++q) {
+    acc0 += K[2 * q] * float2v{t[q].x, t[q].y};
+    acc1 += K[2 * q + 1] * float2v{t[q].z, t[q].w};
+  }
+  acc0 += K[SKR_P - 1] * float2v{t2.x, t2.y};
+  acc0 += acc1;
+  return quad_sum(acc0.x + acc0.y);
+}
+
+// Line 128 (the dustbin row / column of the 129 x 129 patch problems) would cost a ninth, almost empty wavefront the full 80-instruction
+// pass and leave one SIMD with three wavefronts against two on the others (the pass is issue bound: 1325 -> ~800 us per launch in a
+// timing experiment without it).  That wavefront instead holds line 128 SPREAD over its 64 lanes — entry l + 64 q of the row and of the
+// column in lane l — so its pass is three multiply-adds and one wavefront sum.
+constexpr int SKS_MAIN = 128;                 // lines with four threads each (wavefronts 0..7)
+constexpr int SKS_XQ = 3;                     // spread entries per lane of the extra line: 3 * 64 >= 129
+__device__ __forceinline__ void sks_build_x(const float* __restrict__ sm, int lane, bool row_live, bool col_live, int M1, int N1,
+                                            const float* ga, const float* gb, float (&KRx)[SKS_XQ], float (&KCx)[SKS_XQ]) {
+  const int px = sks_pos(SKS_MAIN);
+  const float ar = ga[px], bc = gb[px];
+#pragma unroll
+  for (int q = 0; q < SKS_XQ; ++q) {
+    const int j = lane + 64 * q;
+    const float r = exp2_hw(fmaf(sm[min(SKS_MAIN, M1 - 1) * N1 + min(j, N1 - 1)], SKR_LOG2E, ar + gb[sks_pos(min(j, SKR_LINES - 1))]));
+    const float c = exp2_hw(fmaf(sm[min(j, M1 - 1) * N1 + min(SKS_MAIN, N1 - 1)], SKR_LOG2E, ga[sks_pos(min(j, SKR_LINES - 1))] + bc));
+    KRx[q] = (row_live && j < N1) ? r : 0.f;
+    KCx[q] = (col_live && j < M1) ? c : 0.f;
+  }
+}
+__device__ __forceinline__ float sks_dot_x(const float (&K)[SKS_XQ], const float* sc, int lane) {
+  float acc = 0.f;
+#pragma unroll
+  for (int q = 0; q < SKS_XQ; ++q) acc = fmaf(K[q], sc[sks_pos(min(lane + 64 * q, SKR_LINES - 1))], acc);
+  return wave_sum(acc);
+}
+
+// The matrix is staged once through LDS (coalesced read), the two register copies of K~ are built from there, and the result leaves
+// from there (coalesced write): the scores cross HBM once in each direction.  Two barriers per iteration: the "anything changed" and
+// "out of band" words are plain LDS flags read behind the second one (double-buffered by iteration parity).  M + 1, N + 1 <= 129.
+__global__ __launch_bounds__(SKR_T) void k_sinkhorn_scaled(float* __restrict__ S, const uint8_t* __restrict__ row_mask,
+                                                           const uint8_t* __restrict__ col_mask, int M, int N, int iters, float inf_val,
+                                                           unsigned* __restrict__ redo) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];      // [M1][N1] scores
+  __shared__ float u[SKR_LINES + 8], v[SKR_LINES + 8], log_mu[SKR_LINES + 8], log_nu[SKR_LINES + 8];
+  __shared__ __attribute__((aligned(16))) float ga[4 * SKS_STRIDE], gb[4 * SKS_STRIDE], su[4 * SKS_STRIDE], sv[4 * SKS_STRIDE];
+  __shared__ float s_norm;
+  __shared__ int s_flag, s_chg[2];
+  const int64_t b = blockIdx.x;
+  const int M1 = M + 1, N1 = N + 1;
+  float* sg = S + b * M1 * N1;
+  const int lane = threadIdx.x & 63;
+  const bool extra = threadIdx.x >= 4 * SKS_MAIN;        // wavefront 8: line 128, spread over the lanes
+  const int part = threadIdx.x & 3, line = extra ? SKS_MAIN : threadIdx.x >> 2, pl = sks_pos(line);
+  const bool owner = extra ? lane == 0 : part == 0;      // the thread that publishes the line's scale
+  const bool row_live = line < M1, col_live = line < N1;
+#pragma unroll 8
+  for (int t = threadIdx.x; t < M1 * N1; t += SKR_T) sm[t] = sg[t];
+  sk_setup(row_mask, col_mask, b, M, N, inf_val, u, v, log_mu, log_nu, &s_norm);
+  const bool row_on = row_live && log_mu[line] > -0.5f * inf_val, col_on = col_live && log_nu[line] > -0.5f * inf_val;
+  const float mu = row_on ? exp2_hw(log_mu[line] * SKR_LOG2E) : 0.f, nu = col_on ? exp2_hw(log_nu[line] * SKR_LOG2E) : 0.f;
+  float mx = -INFINITY;
+  {
+    const int rl = min(line, M1 - 1);                    // clamped reads: repeats of in-row entries
+    if (!extra) {
+#pragma unroll
+      for (int e = 0; e < SKR_E; ++e) mx = fmaxf(mx, sm[rl * N1 + min(part * SKR_E + e, N1 - 1)]);
+      mx = quad_max(mx);
+    } else {
+#pragma unroll
+      for (int q = 0; q < SKS_XQ; ++q) mx = fmaxf(mx, sm[rl * N1 + min(lane + 64 * q, N1 - 1)]);
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    }
+  }
+  for (int t = threadIdx.x; t < 4 * SKS_STRIDE; t += SKR_T) {
+    ga[t] = 0.f;
+    gb[t] = 0.f;
+    su[t] = 1.f;
+    sv[t] = 1.f;
+  }
+  if (threadIdx.x == 0) {
+    s_flag = 0;
+    s_chg[0] = 0;
+  }
+  __syncthreads();
+  if (row_on && owner) ga[pl] = -mx * SKR_LOG2E;         // first gauge: every live row's largest entry becomes 1
+  __syncthreads();
+  float2v KR[SKR_P], KC[SKR_P];
+  float KRx[SKS_XQ], KCx[SKS_XQ];
+  if (!extra) sks_build(sm, line, part, row_live, col_live, M1, N1, ga, gb, KR, KC);
+  else sks_build_x(sm, lane, row_live, col_live, M1, N1, ga, gb, KRx, KCx);
+  float uo = 1.f, vo = 1.f;                              // the scale this thread last wrote
+  for (int it = 0; it < iters; ++it) {
+    int changed = 0;
+    {
+      const float sum = extra ? sks_dot_x(KRx, sv, lane) : sks_dot(KR, sv, part);
+      if (row_on && owner) {
+        const float un = mu * __builtin_amdgcn_rcpf(sum);
+        changed |= __float_as_uint(un) != __float_as_uint(uo);
+        if (!(un >= SKS_BAND_LO && un <= SKS_BAND_HI)) atomicOr(&s_flag, (un >= SKS_FAIL_LO && un <= SKS_FAIL_HI) ? 1 : 2);
+        su[pl] = uo = un;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_chg[(it + 1) & 1] = 0;       // nobody reads or writes the other parity's word between these two barriers
+    {
+      const float sum = extra ? sks_dot_x(KCx, su, lane) : sks_dot(KC, su, part);
+      if (col_on && owner) {
+        const float vn = nu * __builtin_amdgcn_rcpf(sum);
+        changed |= __float_as_uint(vn) != __float_as_uint(vo);
+        if (!(vn >= SKS_BAND_LO && vn <= SKS_BAND_HI)) atomicOr(&s_flag, (vn >= SKS_FAIL_LO && vn <= SKS_FAIL_HI) ? 1 : 2);
+        sv[pl] = vo = vn;
+      }
+    }
+    if (changed) s_chg[it & 1] = 1;
+    __syncthreads();
+    const int any = s_chg[it & 1], flag = s_flag;        // block-uniform: written before the barrier above
+    if (flag & 2) {                                      // out of fp32 range: the log-domain kernel redoes this problem from its input
+      if (threadIdx.x == 0) redo[b] = 1u;
+      return;
+    }
+    if (!any) break;                                     // exact early exit (see k_log_sinkhorn_reg): a repeated iterate repeats forever
+    if (flag) {                                          // fold the scales into the gauges, rebuild K~ from the scores
+      if (owner) {
+        if (row_on) {
+          ga[pl] += log2_hw(uo);
+          su[pl] = uo = 1.f;
+        }
+        if (col_on) {
+          gb[pl] += log2_hw(vo);
+          sv[pl] = vo = 1.f;
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) s_flag = 0;
+      if (!extra) sks_build(sm, line, part, row_live, col_live, M1, N1, ga, gb, KR, KC);
+      else sks_build_x(sm, lane, row_live, col_live, M1, N1, ga, gb, KRx, KCx);
+      __syncthreads();
+    }
+  }
+  if (owner) {
+    if (row_on) ga[pl] += log2_hw(uo);
+    if (col_on) gb[pl] += log2_hw(vo);
+  }
+  if (threadIdx.x == 0) redo[b] = 0u;
+  __syncthreads();
+  const float nrm = s_norm;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int i = w; i < M1; i += SKR_T / 64) {             // a wavefront per row: coalesced stores
+    const float ui = ga[sks_pos(i)];
+    for (int j = lane; j < N1; j += 64) sg[i * N1 + j] = sm[i * N1 + j] + fmaf(ui + gb[sks_pos(j)], SKR_LN2, -nrm);
+  }
+}
+
 // (c) round 3: the node-level problems as ONE persistent launch.  A matrix (~350 x 330 floats = 466 KB) is cut into G row slabs
 //     that fit LDS (117 KB at G = 4); workgroup g of problem b keeps its slab, its rows' u and a full copy of v in LDS for all
 //     iterations.  A row half-iteration is local.  A column half-iteration needs every slab: each workgroup publishes the
@@ -576,27 +792,53 @@ __global__ __launch_bounds__(SKC_T) void k_log_sinkhorn_coop(float* __restrict__
   const int sub = tid / N1, jc = tid - sub * N1;     // column pass: thread (row part, column); threads beyond nsub * N1 idle
   const int third = (nr + nsub - 1) / nsub;
   for (int it = 0; it < iters; ++it) {
-    // rows of the slab: one wavefront per row, lanes over the columns
-    for (int i = w; i < nr; i += SKC_T / 64) {
+    // rows of the slab: 16 lanes per row (64 rows at a time), ONE pass with a running (max, sum) per lane, four independent loads per step
+    // (the two-pass form was bound by the LDS latency of its dependent loop, not by LDS bandwidth), DPP row permutes for the 16-lane merge
+    for (int i = tid >> 4; i < nr; i += SKC_T / 16) {
       const float* row = s_mat + i * N1;
-      float mx = -INFINITY;
-      for (int j = lane; j < N1; j += 64) mx = fmaxf(mx, row[j] + v[j]);
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
-      float sum = 0.f;
-      for (int j = lane; j < N1; j += 64) sum += fast_exp(row[j] + v[j] - mx);
-      sum = wave_sum(sum);
-      if (lane == 0) u[r0 + i] = log_mu[r0 + i] - (mx + fast_log(sum));
+      const int l16 = tid & 15;
+      float m = -INFINITY, sum = 0.f;
+      int j = l16;
+      for (; j + 48 < N1; j += 64) {
+        const float x0 = row[j] + v[j], x1 = row[j + 16] + v[j + 16], x2 = row[j + 32] + v[j + 32], x3 = row[j + 48] + v[j + 48];
+        const float mn = fmaxf(fmaxf(fmaxf(x0, x1), fmaxf(x2, x3)), m);
+        sum = sum * fast_exp(m - mn) + ((fast_exp(x0 - mn) + fast_exp(x1 - mn)) + (fast_exp(x2 - mn) + fast_exp(x3 - mn)));
+        m = mn;
+      }
+      for (; j < N1; j += 16) {
+        const float x = row[j] + v[j];
+        const float mn = fmaxf(x, m);
+        sum = sum * fast_exp(m - mn) + fast_exp(x - mn);
+        m = mn;
+      }
+      float mx = fmaxf(m, dpp0<DPP_QUAD_1032>(m));
+      mx = fmaxf(mx, dpp0<DPP_QUAD_2301>(mx));
+      mx = fmaxf(mx, dpp0<DPP_ROW_HALF_MIRROR>(mx));
+      mx = fmaxf(mx, dpp0<DPP_ROW_MIRROR>(mx));
+      sum = row_sum16(sum * fast_exp(m - mx));            // a lane without columns: 0 * exp(-inf) = 0
+      if (l16 == 0) u[r0 + i] = log_mu[r0 + i] - (mx + fast_log(sum));
     }
     __syncthreads();
-    // columns: (max, sum of exp) over this slab's rows, three row thirds per column folded through LDS
+    // columns: running (max, sum of exp) over this slab's rows, `nsub` row parts per column folded through LDS
     if (sub < nsub) {
       const int ia = min(nr, sub * third), ib = min(nr, ia + third);
-      float mx = -INFINITY;
-      for (int i = ia; i < ib; ++i) mx = fmaxf(mx, s_mat[i * N1 + jc] + u[r0 + i]);
-      float sum = 0.f;
-      for (int i = ia; i < ib; ++i) sum += fast_exp(s_mat[i * N1 + jc] + u[r0 + i] - mx);
-      s_red[(sub * N1 + jc) * 2] = mx;
+      const float* col = s_mat + jc;
+      const float* ur = u + r0;
+      float m = -INFINITY, sum = 0.f;
+      int i = ia;
+      for (; i + 4 <= ib; i += 4) {
+        const float x0 = col[i * N1] + ur[i], x1 = col[(i + 1) * N1] + ur[i + 1], x2 = col[(i + 2) * N1] + ur[i + 2], x3 = col[(i + 3) * N1] + ur[i + 3];
+        const float mn = fmaxf(fmaxf(fmaxf(x0, x1), fmaxf(x2, x3)), m);
+        sum = sum * fast_exp(m - mn) + ((fast_exp(x0 - mn) + fast_exp(x1 - mn)) + (fast_exp(x2 - mn) + fast_exp(x3 - mn)));
+        m = mn;
+      }
+      for (; i < ib; ++i) {
+        const float x = col[i * N1] + ur[i];
+        const float mn = fmaxf(x, m);
+        sum = sum * fast_exp(m - mn) + fast_exp(x - mn);
+        m = mn;
+      }
+      s_red[(sub * N1 + jc) * 2] = m;
       s_red[(sub * N1 + jc) * 2 + 1] = sum;
     }
     __syncthreads();
@@ -636,14 +878,16 @@ __global__ __launch_bounds__(SKC_T) void k_log_sinkhorn_coop(float* __restrict__
       return;
     }
     if (tid < N1) {
-      const float* base = c.part + ((static_cast<int64_t>(it & 1) * gridDim.x + static_cast<int64_t>(b) * c.G) * N1) * 2;
+      const float2* base = reinterpret_cast<const float2*>(c.part + ((static_cast<int64_t>(it & 1) * gridDim.x + static_cast<int64_t>(b) * c.G) * N1) * 2) + tid;
+      float2 pv[SKC_MAX_G];                               // all slabs' partials in flight at once (they come from the other XCDs' memory side)
+#pragma unroll
+      for (int q = 0; q < SKC_MAX_G; ++q) pv[q] = q < c.G ? base[static_cast<int64_t>(q) * N1] : make_float2(-INFINITY, 0.f);
       float mx = -INFINITY;
-      for (int q = 0; q < c.G; ++q) mx = fmaxf(mx, base[(static_cast<int64_t>(q) * N1 + tid) * 2]);
+#pragma unroll
+      for (int q = 0; q < SKC_MAX_G; ++q) mx = fmaxf(mx, pv[q].x);
       float sum = 0.f;
-      for (int q = 0; q < c.G; ++q) {
-        const float m_q = base[(static_cast<int64_t>(q) * N1 + tid) * 2];
-        sum += m_q == -INFINITY ? 0.f : base[(static_cast<int64_t>(q) * N1 + tid) * 2 + 1] * fast_exp(m_q - mx);
-      }
+#pragma unroll
+      for (int q = 0; q < SKC_MAX_G; ++q) sum += pv[q].x == -INFINITY ? 0.f : pv[q].y * fast_exp(pv[q].x - mx);
       v[tid] = log_nu[tid] - (mx + fast_log(sum));
     }
     __syncthreads();
@@ -1139,8 +1383,10 @@ static bool sk_coop_plan(int64_t B, int M, int N, int* G_out, int* slab_out) {
   const size_t room = 144 * 1024;
   if (fixed + sizeof(float) * N1 > room) return false;
   const int slab_max = static_cast<int>((room - fixed) / (sizeof(float) * N1));
-  const int G = (M1 + slab_max - 1) / slab_max;
+  int G = (M1 + slab_max - 1) / slab_max;
   if (G > SKC_MAX_G || B * G > 64) return false;
+  const int G64 = (M1 + 63) / 64;                        // slabs of <= 64 rows: one round of the 16-lanes-per-row pass
+  if (G64 > G && G64 <= SKC_MAX_G && B * G64 <= 64) G = G64;
   if (G_out) *G_out = G;
   if (slab_out) *slab_out = (M1 + G - 1) / G;
   return true;
@@ -1166,7 +1412,20 @@ extern "C" int lcr_log_sinkhorn_ex(float* S, const uint8_t* row_mask, const uint
   if (!S || !row_mask || !col_mask || !uv_ws || B < 1 || M < 1 || N < 1 || iters < 0) return LCR_EARG;
   const size_t mat_bytes = sizeof(float) * (static_cast<size_t>(M + 1) * (N + 1) + 2 * (M + N + 2));   // matrix + u, v, log_mu, log_nu
   if (M + 1 <= SKR_LINES && N + 1 <= SKR_LINES) {
-    hipLaunchKernelGGL(k_log_sinkhorn_reg, dim3(static_cast<int>(B)), dim3(SKR_T), 0, ST(stream), S, row_mask, col_mask, M, N, iters, inf_val);
+    static const bool scaled_on = !(getenv("LCR_SINKHORN_SCALED") && atoi(getenv("LCR_SINKHORN_SCALED")) == 0);
+    const bool scaled = scaled_on && M + 1 <= SKS_MAIN + 1 && N + 1 <= SKS_MAIN + 1;
+    unsigned* redo = scaled ? reinterpret_cast<unsigned*>(uv_ws) : nullptr;      // B words of the workspace: problems handed back
+    if (scaled) {
+      const size_t lds = sizeof(float) * static_cast<size_t>(M + 1) * (N + 1);
+      static bool attr_set = false;
+      if (!attr_set) {   // up to 132 x 132 floats of dynamic LDS beside the static vectors
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sinkhorn_scaled), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(sizeof(float) * SKR_LINES * SKR_LINES));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(k_sinkhorn_scaled, dim3(static_cast<int>(B)), dim3(SKR_T), lds, ST(stream), S, row_mask, col_mask, M, N, iters, inf_val, redo);
+    }
+    hipLaunchKernelGGL(k_log_sinkhorn_reg, dim3(static_cast<int>(B)), dim3(SKR_T), 0, ST(stream), S, row_mask, col_mask, M, N, iters, inf_val, redo);
   } else if (mat_bytes <= 150 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {   // > 64 KB of dynamic LDS needs an explicit opt-in
