@@ -103,14 +103,15 @@ def test_log_sinkhorn_and_top1_matching():
 WIDE_CASES = {1.0: 1e-5, 12.0: 3e-4, 40.0: 1.5e-3}
 
 
+@pytest.mark.parametrize("size", [128, 129])
 @pytest.mark.parametrize("spread", [1.0, 12.0, 40.0])
-def test_patch_sinkhorn_survives_wide_score_ranges(spread):
-    """The patch-level problems (129 x 129 + dustbins, register-resident kernel) with scores spread over +-3*spread — the widest
-    case puts most of exp(score) below fp32's smallest normal — masked rows / columns, a row far below everything else and a
-    column that dominates its rows: finite everywhere, within the per-spread bound of an fp64 run, and never more than 2x farther
-    from it than the fp32 torch oracle is."""
+def test_patch_sinkhorn_survives_wide_score_ranges(spread, size):
+    """The patch-level problems (size 128: the model's 128-point patches, 129 x 129 with the dustbins — the scaled-domain kernel with its
+    re-gauging; size 129: the log-domain register kernel) with scores spread over +-3*spread — the widest case puts most of exp(score)
+    below fp32's smallest normal — masked rows / columns, a row far below everything else and a column that dominates its rows:
+    finite everywhere, within the per-spread bound of an fp64 run, and never more than 2x farther from it than the fp32 torch oracle is."""
     g = torch.Generator().manual_seed(int(spread))
-    B, M, N = 9, 129, 129
+    B, M, N = 9, size, size
     raw = torch.randn(B, M, N, generator=g) * spread
     raw[:, 7, :] -= 6 * spread
     raw[:, :, 11] += 5 * spread
@@ -125,6 +126,56 @@ def test_patch_sinkhorn_survives_wide_score_ranges(spread):
     print("patch sinkhorn spread %.0f: HIP vs fp64 %.2e (fp32 torch vs fp64 %.2e)" % (spread, e64, floor))
     assert e64 < WIDE_CASES[spread], e64
     assert e64 < 2.0 * floor + 1e-5, (e64, floor)
+
+
+def _sinkhorn_padded(S, iters=100):
+    """The reference's iteration (learnable_sinkhorn.py:20-49) on an already padded score matrix, all rows / columns valid."""
+    B, M1, N1 = S.shape
+    M, N = M1 - 1, N1 - 1
+    norm = -torch.log(torch.tensor(float(M + N), dtype=S.dtype))
+    log_mu = norm.expand(B, M1).clone()
+    log_mu[:, M] = torch.log(torch.tensor(float(N), dtype=S.dtype)) + norm
+    log_nu = norm.expand(B, N1).clone()
+    log_nu[:, N] = torch.log(torch.tensor(float(M), dtype=S.dtype)) + norm
+    u, v = torch.zeros_like(log_mu), torch.zeros_like(log_nu)
+    for _ in range(iters):
+        u = log_mu - torch.logsumexp(S + v[:, None, :], dim=2)
+        v = log_nu - torch.logsumexp(S + u[:, :, None], dim=1)
+    return S + u[:, :, None] + v[:, None, :] - norm
+
+
+def test_scaled_sinkhorn_regauge_and_hand_back():
+    """The scaled-domain patch kernel's two rare paths, forced through the C-ABI on padded 129 x 129 matrices (the hand-back words are
+    the first B words of the workspace): problem 0 is ordinary; problem 1 has a column 45 nats below every row's maximum — dustbin row
+    included, which the model's own padding never produces — so its scale passes 2^40 and the gauges are folded; problem 2 has that
+    column 300 nats down, its sums leave fp32 and the problem is handed back to the log-domain kernel.  All three match an fp64 run of
+    the reference iteration."""
+    import ctypes
+    from lcrnet_amd import _lib
+    g = torch.Generator().manual_seed(11)
+    B, M, N = 3, 128, 128
+    S = torch.randn(B, M + 1, N + 1, generator=g)
+    S[:, M, :] = 1.0
+    S[:, :, N] = 1.0
+    S[1, :, 5] = -45.0
+    S[2, :, 5] = -300.0
+    want = _sinkhorn_padded(S.double())
+    Sg = S.cuda().contiguous()
+    ones_r = torch.ones(B, M, dtype=torch.uint8, device="cuda")
+    ones_c = torch.ones(B, N, dtype=torch.uint8, device="cuda")
+    L = _lib.lib()
+    nfl = ctypes.c_size_t(0)
+    _lib.check(L.lcr_log_sinkhorn_ws_floats(B, M, N, ctypes.byref(nfl)), "ws")
+    uv = torch.zeros(nfl.value, dtype=torch.float32, device="cuda")
+    _lib.check(L.lcr_log_sinkhorn_ex(_lib.ptr(Sg), _lib.ptr(ones_r), _lib.ptr(ones_c), B, M, N, 100, 1e12, _lib.ptr(uv), uv.numel(),
+                                     _lib.stream_ptr(Sg.device)), "lcr_log_sinkhorn_ex")
+    torch.cuda.synchronize()
+    redo = uv[:B].view(torch.int32).cpu().tolist()
+    assert redo == [0, 0, 1], redo
+    err = (Sg.cpu().double() - want).abs().amax(dim=(1, 2))
+    print("scaled sinkhorn: ordinary %.2e, re-gauged %.2e, handed back %.2e vs fp64" % tuple(err.tolist()))
+    assert torch.isfinite(Sg).all()
+    assert err[0] < 1e-5 and err[1] < 5e-5 and err[2] < 5e-4, err
 
 
 def test_procrustes_and_lgr_pieces():
