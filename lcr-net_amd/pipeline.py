@@ -8,6 +8,7 @@ are `record_stream`ed so the caching allocator cannot recycle them early.
 """
 import os
 import threading
+import weakref
 import time
 
 import torch
@@ -169,6 +170,9 @@ class DescriptorPipeline:
             self._streams = _native_streams(dev, self.pre_workers, prio) + distinct_queue_streams(dev, 2, 0)
         self.pre_stream = self._streams[0] if overlap else None
         self.pre_streams = self._streams[:self.pre_workers] if (overlap and producer_thread) else []
+        # a pipeline that is dropped without close() still hands its native streams back (the wrapper does not own the handle)
+        self._finalizer = weakref.finalize(self, release_streams, list(self._streams))
+        self._finalizer.atexit = False               # nothing to hand back to at interpreter exit (and the runtime may be gone)
         self.stats = {"pre_wait_s": 0.0, "pre_busy_s": 0.0, "enc_wait_s": 0.0, "batches": 0}   # where the two host threads wait
         self._ones_buf = None
         self.enc_streams = None      # set by enable_dual_encoder(): consecutive batches' encoders on alternating streams
@@ -403,6 +407,8 @@ class PairPipeline:
         self.device = next(model.parameters()).device
         # worker streams: created and probed ONCE per pipeline (two busy streams on one hardware queue serialise each other)
         self._streams = distinct_queue_streams(self.device, self.workers) if self.workers > 1 else []
+        self._finalizer = weakref.finalize(self, release_streams, list(self._streams))
+        self._finalizer.atexit = False               # nothing to hand back to at interpreter exit (and the runtime may be gone)
 
     def close(self):
         """Give the worker streams back (idempotent; see `release_streams`)."""
