@@ -332,6 +332,15 @@ int lcr_neighbor_mean(const float* pts, const void* idx, int idx_is_64, int64_t 
 int lcr_point_to_node_ws_bytes(int64_t N, int M, size_t* bytes);
 int lcr_point_to_node_partition(const float* points, int64_t N, const float* nodes, int M, int K, int32_t* p2n, int64_t* knn,
                                 uint8_t* knn_mask, uint8_t* node_mask, uint32_t* status, void* ws, size_t ws_bytes, void* stream);
+
+/* The same partition for C stacked clouds in one launch sequence (cloud c: points [point_off[c], point_off[c+1]), nodes
+ * [node_off[c], node_off[c+1]); HOST offsets, C <= 64): per-cloud results stacked, indices local to their cloud, knn padded with the
+ * cloud's own point count.  Workspace: lcr_point_to_node_ws_bytes(total points, total nodes).  The pair model's group path calls
+ * this once per group of pairs instead of once per cloud (reference: ops/pointcloud_partition.py:60-107, called per cloud at
+ * model_family/LCRNet.py:150-165). */
+int lcr_point_to_node_partition_stack(const float* points, const int64_t* point_off, const float* nodes, const int64_t* node_off, int C, int K,
+                                      int32_t* p2n_out, int64_t* knn, uint8_t* knn_mask, uint8_t* node_mask, uint32_t* status, void* ws,
+                                      size_t ws_bytes, void* stream);
 /* S[B,M+1,N+1] = scale*raw with dustbin row/col = alpha[0] and masked rows/cols = -inf_val (learnable_sinkhorn.py:36-45). */
 int lcr_build_padded_scores(const float* raw, const uint8_t* row_mask, const uint8_t* col_mask, int64_t B, int M, int N,
                             float scale, const float* alpha, float inf_val, float* S, void* stream);

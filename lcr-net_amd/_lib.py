@@ -69,6 +69,7 @@ _SIGS = {
     "lcr_neighbor_mean": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_i64, c_vp, c_vp]),
     "lcr_point_to_node_ws_bytes": (c_int, [c_i64, c_int, c_size_p]),
     "lcr_point_to_node_partition": (c_int, [c_vp, c_i64, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "lcr_point_to_node_partition_stack": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "lcr_build_padded_scores": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_float, c_vp, c_float, c_vp, c_vp]),
     "lcr_log_sinkhorn": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_float, c_vp, c_vp]),
     "lcr_log_sinkhorn_ws_floats": (c_int, [c_i64, c_int, c_int, c_size_p]),

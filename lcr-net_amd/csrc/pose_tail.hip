@@ -210,6 +210,94 @@ __global__ __launch_bounds__(256) void k_node_topk(const float* __restrict__ poi
   if (threadIdx.x == 0) node_mask[m] = n_all > 0 ? 1 : 0;
 }
 
+// The same partition for a STACK of clouds in one launch sequence (the pair model calls it for the 2P clouds of a group of pairs:
+// 12 x (2 fills + 3 kernels + a scan) per 6 pairs otherwise).  Offsets are host values passed by value; point / node indices in the
+// outputs stay LOCAL to their cloud, as the per-cloud call returns them.
+constexpr int P2N_MAX_CLOUDS = 64;
+struct P2nStack {
+  int64_t po[P2N_MAX_CLOUDS + 1];   // first point row of every cloud
+  int32_t mo[P2N_MAX_CLOUDS + 1];   // first node row of every cloud
+  int     C;
+};
+__global__ __launch_bounds__(256) void k_point_to_node_stack(const float* __restrict__ points, const float* __restrict__ nodes, P2nStack sk,
+                                                              int32_t* __restrict__ p2n, int32_t* __restrict__ node_cnt) {
+  extern __shared__ float s_nodes[];   // [M_c][4] (x,y,z,|n|^2)
+  const int c = blockIdx.y;
+  const int64_t p0 = sk.po[c], N = sk.po[c + 1] - p0;
+  const int m0 = sk.mo[c], M = sk.mo[c + 1] - m0;
+  for (int i = threadIdx.x; i < M; i += blockDim.x) {
+    const float x = nodes[3 * (m0 + i)], y = nodes[3 * (m0 + i) + 1], z = nodes[3 * (m0 + i) + 2];
+    s_nodes[4 * i] = x;
+    s_nodes[4 * i + 1] = y;
+    s_nodes[4 * i + 2] = z;
+    s_nodes[4 * i + 3] = x * x + y * y + z * z;
+  }
+  __syncthreads();
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < N; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const float px = points[3 * (p0 + i)], py = points[3 * (p0 + i) + 1], pz = points[3 * (p0 + i) + 2];
+    const float p2 = px * px + py * py + pz * pz;
+    float best = INFINITY;
+    int bi = 0;
+    for (int m = 0; m < M; ++m) {
+      const float d = p2n_dist(s_nodes[4 * m], s_nodes[4 * m + 1], s_nodes[4 * m + 2], s_nodes[4 * m + 3], px, py, pz, p2);
+      if (d < best) {
+        best = d;
+        bi = m;
+      }
+    }
+    p2n[p0 + i] = bi;
+    if (M > 0) atomicAdd(&node_cnt[m0 + bi], 1);
+  }
+}
+__global__ __launch_bounds__(256) void k_p2n_scatter_stack(const int32_t* __restrict__ p2n, P2nStack sk, const int32_t* __restrict__ node_start,
+                                                           int32_t* __restrict__ cursor, int32_t* __restrict__ members) {
+  const int c = blockIdx.y;
+  const int64_t p0 = sk.po[c], N = sk.po[c + 1] - p0;
+  const int m0 = sk.mo[c];
+  if (sk.mo[c + 1] == m0) return;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < N; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int m = m0 + p2n[p0 + i];
+    members[node_start[m] + atomicAdd(&cursor[m], 1)] = static_cast<int32_t>(i);      // local point index
+  }
+}
+__global__ __launch_bounds__(256) void k_node_topk_stack(const float* __restrict__ points, const float* __restrict__ nodes, P2nStack sk,
+                                                         const int32_t* __restrict__ node_start, const int32_t* __restrict__ members, int K,
+                                                         int64_t* __restrict__ knn, uint8_t* __restrict__ knn_mask, uint8_t* __restrict__ node_mask,
+                                                         uint32_t* __restrict__ status) {
+  __shared__ uint64_t s_key[PT_CAP];
+  const int m = blockIdx.x;
+  int c = 0;
+  while (c + 1 < sk.C && m >= sk.mo[c + 1]) ++c;            // block-uniform
+  const int64_t p0 = sk.po[c], N = sk.po[c + 1] - p0;
+  const float* pts = points + 3 * p0;
+  const int a = node_start[m], n_all = node_start[m + 1] - a;
+  const int n = n_all < PT_CAP ? n_all : PT_CAP;
+  if (n_all > PT_CAP && threadIdx.x == 0) atomicOr(status, LCR_STATUS_LEN_MISMATCH);
+  const float nx = nodes[3 * m], ny = nodes[3 * m + 1], nz = nodes[3 * m + 2];
+  const float n2 = nx * nx + ny * ny + nz * nz;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int32_t pi = members[a + i];
+    const float px = pts[3 * pi], py = pts[3 * pi + 1], pz = pts[3 * pi + 2];
+    const float d = p2n_dist(nx, ny, nz, n2, px, py, pz, px * px + py * py + pz * pz);
+    s_key[i] = (static_cast<uint64_t>(__float_as_uint(d)) << 32) | static_cast<uint32_t>(pi);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    const uint64_t key = s_key[e];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += s_key[j] < key;
+    if (rank < K) {
+      knn[static_cast<int64_t>(m) * K + rank] = static_cast<int64_t>(static_cast<uint32_t>(key));
+      knn_mask[static_cast<int64_t>(m) * K + rank] = 1;
+    }
+  }
+  for (int col = n + threadIdx.x; col < K; col += blockDim.x) {
+    knn[static_cast<int64_t>(m) * K + col] = N;
+    knn_mask[static_cast<int64_t>(m) * K + col] = 0;
+  }
+  if (threadIdx.x == 0) node_mask[m] = n_all > 0 ? 1 : 0;
+}
+
 // ---- log-domain Sinkhorn with dustbins ---------------------------------------------------------------------------------------
 // S: [B, M+1, N+1] padded score matrices (dustbin row/column = alpha, masked entries = -inf_val), overwritten by the result
 // S + u + v - norm.  One workgroup per matrix; u, v live in global scratch (L2 resident).
@@ -1361,6 +1449,59 @@ extern "C" int lcr_point_to_node_partition(const float* points, int64_t N, const
   hipLaunchKernelGGL(k_node_topk, dim3(M), dim3(256), 0, st, points, N, nodes, start, members, K, knn, knn_mask, node_mask, status);
   if (p2n_out) hipMemcpyAsync(p2n_out, p2n, sizeof(int32_t) * N, hipMemcpyDeviceToDevice, st);
   return check_launch("lcr_point_to_node_partition");
+}
+
+// point_to_node_partition of C stacked clouds (cloud c: points [point_off[c], point_off[c+1]), nodes [node_off[c], node_off[c+1]); host
+// offsets): the per-cloud results stacked — p2n i32[N_total] and knn i64[M_total, K] hold indices LOCAL to the cloud, knn padded with the
+// cloud's own point count.  Workspace: lcr_point_to_node_ws_bytes(N_total, M_total).
+extern "C" int lcr_point_to_node_partition_stack(const float* points, const int64_t* point_off, const float* nodes, const int64_t* node_off, int C,
+                                                 int K, int32_t* p2n_out, int64_t* knn, uint8_t* knn_mask, uint8_t* node_mask, uint32_t* status,
+                                                 void* ws, size_t ws_bytes, void* stream) {
+  if (!points || !point_off || !nodes || !node_off || !knn || !knn_mask || !node_mask || !status || !ws || C < 1 || C > P2N_MAX_CLOUDS || K < 1) {
+    set_error("lcr_point_to_node_partition_stack: bad argument (1 <= clouds <= %d)", P2N_MAX_CLOUDS);
+    return LCR_EARG;
+  }
+  P2nStack sk;
+  sk.C = C;
+  int64_t n_max = 0;
+  int m_max = 0;
+  for (int c = 0; c <= C; ++c) {
+    if (c && (point_off[c] < point_off[c - 1] || node_off[c] < node_off[c - 1])) return LCR_EARG;
+    sk.po[c] = point_off[c] - point_off[0];
+    sk.mo[c] = static_cast<int32_t>(node_off[c] - node_off[0]);
+    if (c) {
+      n_max = std::max(n_max, sk.po[c] - sk.po[c - 1]);
+      m_max = std::max(m_max, sk.mo[c] - sk.mo[c - 1]);
+    }
+  }
+  const int64_t N = sk.po[C];
+  const int M = sk.mo[C];
+  if (N < 1 || M < 1 || m_max > 4000) {
+    set_error("lcr_point_to_node_partition_stack: empty stack or more than 4000 nodes in a cloud");
+    return LCR_EARG;
+  }
+  points += 3 * point_off[0];
+  nodes += 3 * node_off[0];
+  size_t need = 0;
+  lcr_point_to_node_ws_bytes(N, M, &need);
+  if (need > ws_bytes) return LCR_ESPACE;
+  Carver cv(ws, ws_bytes);
+  int32_t* p2n = cv.take<int32_t>(N + 1);
+  int32_t* cnt = cv.take<int32_t>(M + 2);
+  int32_t* start = cv.take<int32_t>(M + 2);
+  int32_t* cursor = cv.take<int32_t>(M + 2);
+  int32_t* members = cv.take<int32_t>(N + 1);
+  void* sws = cv.take<char>(scan_ws_bytes(M + 2));
+  hipStream_t st = ST(stream);
+  hipMemsetAsync(cnt, 0, static_cast<size_t>(reinterpret_cast<char*>(cursor + M + 2) - reinterpret_cast<char*>(cnt)), st);   // counts .. cursor: one fill
+  const int bx = blocks_for(n_max, 256, 2048);
+  hipLaunchKernelGGL(k_point_to_node_stack, dim3(bx, C), dim3(256), sizeof(float) * 4 * m_max, st, points, nodes, sk, p2n, cnt);
+  int rc = exclusive_scan_i32(cnt, start, M + 1, nullptr, sws, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_p2n_scatter_stack, dim3(blocks_for(n_max), C), dim3(256), 0, st, p2n, sk, start, cursor, members);
+  hipLaunchKernelGGL(k_node_topk_stack, dim3(M), dim3(256), 0, st, points, nodes, sk, start, members, K, knn, knn_mask, node_mask, status);
+  if (p2n_out) hipMemcpyAsync(p2n_out, p2n, sizeof(int32_t) * N, hipMemcpyDeviceToDevice, st);
+  return check_launch("lcr_point_to_node_partition_stack");
 }
 
 extern "C" int lcr_build_padded_scores(const float* raw, const uint8_t* row_mask, const uint8_t* col_mask, int64_t B, int M, int N, float scale,

@@ -380,6 +380,32 @@ def point_to_node_partition(points, nodes, point_limit):
     return p2n, nm.bool(), knn, km.bool()
 
 
+def point_to_node_partition_stack(points, point_off, nodes, node_off, point_limit):
+    """`point_to_node_partition` of every cloud of a stack in ONE launch sequence: cloud c owns points[point_off[c]:point_off[c+1]] and
+    nodes[node_off[c]:node_off[c+1]] (host offset lists).  -> (point_to_node i32[N], node_masks bool[M], node_knn_indices i64[M,K],
+    node_knn_masks bool[M,K]) stacked in cloud order; indices are local to their cloud, knn rows padded with the cloud's point count —
+    slices of these are exactly what the per-cloud call returns."""
+    import numpy as np
+    C = len(point_off) - 1
+    assert len(node_off) == C + 1 and C >= 1
+    dev = points.device
+    N, M = int(point_off[-1] - point_off[0]), int(node_off[-1] - node_off[0])
+    po = np.ascontiguousarray(point_off, dtype=np.int64)
+    mo = np.ascontiguousarray(node_off, dtype=np.int64)
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(_L().lcr_point_to_node_ws_bytes(N, M, ctypes.byref(nbytes)), "lcr_point_to_node_ws_bytes")
+    ws = _lib.workspace(nbytes.value, dev)
+    p2n = torch.empty((N,), dtype=torch.int32, device=dev)
+    knn = torch.empty((M, point_limit), dtype=torch.int64, device=dev)
+    km = torch.empty((M, point_limit), dtype=torch.uint8, device=dev)
+    nm = torch.empty((M,), dtype=torch.uint8, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(_L().lcr_point_to_node_partition_stack(_lib.ptr(points.contiguous()), po.ctypes.data, _lib.ptr(nodes.contiguous()), mo.ctypes.data, C,
+                                                      int(point_limit), _lib.ptr(p2n), _lib.ptr(knn), _lib.ptr(km), _lib.ptr(nm), _lib.ptr(status),
+                                                      _lib.ptr(ws), ws.numel(), _sp(points)), "lcr_point_to_node_partition_stack")
+    return p2n, nm.bool(), knn, km.bool()
+
+
 class _PendingStatus(threading.local):
     def __init__(self):
         self.items = []

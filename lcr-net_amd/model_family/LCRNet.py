@@ -282,9 +282,12 @@ class LCRNet(nn.Module):
         dev = pts_f.device
         n_all = pts_f.shape[0]
         parts = []
-        for c in range(2 * P):
-            _, nm, knn, km = F.point_to_node_partition(pts_f[off_f[c]:off_f[c + 1]].contiguous(), vd["points_c"][off_m[c]:off_m[c + 1]].contiguous(), K)
-            parts.append((nm, knn, km))
+        for g0 in range(0, 2 * P, 64):                                  # one launch sequence per 64 clouds of the stack
+            g1 = min(2 * P, g0 + 64)
+            _, nm, knn, km = F.point_to_node_partition_stack(pts_f, off_f[g0:g1 + 1], vd["points_c"], off_m[g0:g1 + 1], K)
+            for c in range(g0, g1):
+                lo, hi = off_m[c] - off_m[g0], off_m[c + 1] - off_m[g0]
+                parts.append((nm[lo:hi], knn[lo:hi], km[lo:hi]))
         m = [off_m[c + 1] - off_m[c] for c in range(2 * P)]
         Mx, Nx = max(m[0::2]), max(m[1::2])
         fc = vd["feats_c"]

@@ -50,6 +50,33 @@ def test_point_to_node_partition():
     assert (knn.cpu() == wknn).float().mean().item() > 0.998 and (km.cpu() == wkm).float().mean().item() > 0.999   # exact-up-to-fp64-near-ties is asserted on the reference's own nodes in test_pose_chain_gpu.py (stage D1)
 
 
+def test_point_to_node_partition_of_a_stack_equals_the_per_cloud_calls():
+    """The pair model partitions the 2P clouds of a group in one launch sequence: identical, cloud by cloud, to the per-cloud op —
+    ragged clouds, a cloud with a single node, a node that owns no point, and a stack that starts at a non-zero offset."""
+    from lcrnet_amd import functional as F
+    g = torch.Generator().manual_seed(5)
+    clouds, nodes = [], []
+    for name, n_pts, n_nodes in (("004481", 9000, 300), ("003854", 16963, 349), ("000958", 700, 1), ("004481", 3000, 40)):
+        pts = torch.from_numpy(load_scan(name))[:n_pts]
+        nd = pts[torch.randperm(len(pts), generator=g)[:n_nodes]] + 0.3 * torch.randn(n_nodes, 3, generator=g)
+        clouds.append(pts)
+        nodes.append(nd)
+    nodes[0][7] = torch.tensor([500.0, 500.0, 0.0])
+    lead_p, lead_n = torch.randn(57, 3, generator=g), torch.randn(5, 3, generator=g)      # rows in front of the stack that is partitioned
+    P = torch.cat([lead_p] + clouds).cuda()
+    Nn = torch.cat([lead_n] + nodes).cuda()
+    po, mo = [57], [5]
+    for c, n in zip(clouds, nodes):
+        po.append(po[-1] + len(c))
+        mo.append(mo[-1] + len(n))
+    p2n, nm, knn, km = F.point_to_node_partition_stack(P, po, Nn, mo, 128)
+    assert p2n.shape[0] == po[-1] - po[0] and knn.shape == (mo[-1] - mo[0], 128)
+    for c in range(len(clouds)):
+        w = F.point_to_node_partition(clouds[c].cuda(), nodes[c].cuda(), 128)
+        ps, ms = slice(po[c] - po[0], po[c + 1] - po[0]), slice(mo[c] - mo[0], mo[c + 1] - mo[0])
+        assert torch.equal(p2n[ps], w[0]) and torch.equal(nm[ms], w[1]) and torch.equal(knn[ms], w[2]) and torch.equal(km[ms], w[3]), c
+
+
 def _ot_errors(raw, rm, cm, alpha, scale):
     """-> (valid mask, HIP result, fp32 torch oracle, fp64 torch oracle) of one LearnableLogOptimalTransport problem set."""
     from lcrnet_amd import functional as F
