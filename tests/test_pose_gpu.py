@@ -155,6 +155,24 @@ def test_patch_sinkhorn_survives_wide_score_ranges(spread, size):
     assert e64 < 2.0 * floor + 1e-5, (e64, floor)
 
 
+@pytest.mark.parametrize("shape", [(5, 7, 3), (16, 33, 34), (9, 128, 17), (7, 64, 128), (4, 1, 1), (6, 2, 128), (3, 97, 97)])
+def test_scaled_sinkhorn_ragged_shapes_and_masks(shape):
+    """The scaled-domain kernel on every kind of matrix it accepts (up to 128 x 128 + dustbins): fewer columns than one thread part,
+    one part partly filled, a single row / column, rectangular both ways — random masks with at least one valid line each, one problem
+    with every row masked but one.  Within 1e-5 of an fp64 run of the reference iteration on the valid entries."""
+    B, M, N = shape
+    g = torch.Generator().manual_seed(B * 1000 + M * 10 + N)
+    raw = torch.randn(B, M, N, generator=g) * 3
+    rm = torch.rand(B, M, generator=g) > 0.3
+    cm = torch.rand(B, N, generator=g) > 0.3
+    rm[:, 0] = cm[:, 0] = True
+    rm[0, 1:] = False
+    valid, got, want32, want64 = _ot_errors(raw, rm, cm, torch.tensor(1.0), 1.0)
+    assert torch.isfinite(got).all()
+    e64 = (got.double() - want64)[valid].abs().max().item()
+    assert e64 < 1e-5, (shape, e64)
+
+
 def _sinkhorn_padded(S, iters=100):
     """The reference's iteration (learnable_sinkhorn.py:20-49) on an already padded score matrix, all rows / columns valid."""
     B, M1, N1 = S.shape
