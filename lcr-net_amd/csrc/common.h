@@ -50,10 +50,27 @@ inline int div_up(int64_t a, int64_t b) { return static_cast<int>((a + b - 1) / 
 
 #ifdef __HIPCC__
 // ---- exact fp32 arithmetic (never contracted into FMA) ------------------------------------------
-__device__ __forceinline__ float fsub(float a, float b) { return __fsub_rn(a, b); }
-__device__ __forceinline__ float fadd(float a, float b) { return __fadd_rn(a, b); }
-__device__ __forceinline__ float fmul(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ float fdiv(float a, float b) { return __fdiv_rn(a, b); }
+// `__fmul_rn` / `__fadd_rn` are plain `*` / `+` to the compiler: under hipcc's default (-ffp-contract=fast)
+// fadd(fmul(dx, dx), fmul(dy, dy)) comes out as v_fma_f32(dy, dy, dx * dx) — one rounding where the reference (and the oracle) round
+// twice, a d² that differs by an ulp for a tenth of all offsets.  The library is built with -ffp-contract=off (csrc/build.py), which
+// is what has kept the rows exact; the pragma additionally strips the `contract` flag from these operations themselves, so they stay
+// exact under any build flags (tests/test_ops_gpu.py::test_distance_arithmetic_is_not_contracted places supports where it matters).
+__device__ __forceinline__ float fsub(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+__device__ __forceinline__ float fadd(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float fmul(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float fdiv(float a, float b) {
+#pragma clang fp contract(off)
+  return __fdiv_rn(a, b);
+}
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ uint64_t lanemask_lt() {

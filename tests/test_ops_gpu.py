@@ -98,6 +98,54 @@ def test_dense_ball_exceeds_lds_capacity():
     assert np.array_equal(got.cpu().numpy(), want)
 
 
+def _d2_forms(x, y, z):
+    """The reference's d2 = ((x*x + y*y) + z*z), every operation rounded to fp32 (nanoflann.hpp:432-440), and what a compiler that
+    contracts a product into a neighbouring add (hipcc's default, -ffp-contract=fast) can make of it: one product left exact inside
+    an FMA, possibly after commuting the adds."""
+    x, y, z = (np.asarray(a, dtype=np.float32) for a in (x, y, z))
+    f32, f64 = np.float32, np.float64
+    xx, yy, zz = x * x, y * y, z * z                                   # rounded products
+    ex, ey, ez = x.astype(f64) * x.astype(f64), y.astype(f64) * y.astype(f64), z.astype(f64) * z.astype(f64)   # exact (48 bits)
+    return {"plain": (xx + yy) + zz,
+            "fma(y,y,xx)+zz": (xx.astype(f64) + ey).astype(f32) + zz,
+            "fma(x,x,yy)+zz": (ex + yy.astype(f64)).astype(f32) + zz,
+            "fma(z,z,xx+yy)": ((xx + yy).astype(f64) + ez).astype(f32),
+            "xx+fma(y,y,zz)": xx + (ey + zz.astype(f64)).astype(f32),
+            "xx+fma(z,z,yy)": xx + (yy.astype(f64) + ez).astype(f32)}
+
+
+def test_distance_arithmetic_is_not_contracted():
+    """d2 must be ((dx*dx + dy*dy) + dz*dz) with five fp32 roundings.  hipcc contracts a product into a neighbouring add by default
+    (`__fmul_rn` / `__fadd_rn` do not stop it): one rounding less, d2 off by an ulp for a tenth of all offsets, which shows only when a
+    support lies within that ulp of r2 (about 0.3 cases per 8-scan batch).  The library is built with -ffp-contract=off and the exact
+    helpers carry `#pragma clang fp contract(off)`; this test places supports exactly where each possible contraction would change the
+    membership, so a build that loses either protection fails here, not once in a few batches."""
+    from lcrnet_amd.modules.ops import radius_search, radius_count
+    rng = np.random.default_rng(17)
+    radius = np.float32(1.275)
+    r2 = radius * radius
+    fams = {}
+    while min([len(v) for v in fams.values()] or [0]) < 24 or len(fams) < 5:
+        v = rng.standard_normal((400000, 3))
+        v = (v / np.linalg.norm(v, axis=1, keepdims=True) * float(radius) * (1 + rng.uniform(-2e-7, 2e-7, (400000, 1)))).astype(np.float32)
+        forms = _d2_forms(v[:, 0], v[:, 1], v[:, 2])
+        for name, d2 in forms.items():
+            if name != "plain":
+                fams.setdefault(name, [])
+                fams[name] += list(v[(forms["plain"] < r2) != (d2 < r2)][:24])
+    for name, pts in fams.items():
+        s = np.stack(pts[:24]).astype(np.float32)
+        q = np.zeros((1, 3), dtype=np.float32)        # query at the origin: dx = -s exactly
+        ql, sl = np.array([1]), np.array([len(s)])
+        want, cnt = oracle_ops.radius_search(q, s, ql, sl, float(radius), len(s), return_counts=True, ref_width=True)
+        forms = _d2_forms(s[:, 0], s[:, 1], s[:, 2])
+        assert (forms["plain"] < r2).sum() == cnt[0] and (forms[name] < r2).sum() != cnt[0], name      # the generator did its job
+        got_cnt = radius_count(dev(q), dev(s), dev(ql), dev(sl), float(radius)).cpu().numpy()
+        assert got_cnt[0] == cnt[0], "in-radius count follows the contracted form %s: %d vs %d" % (name, got_cnt[0], cnt[0])
+        got = radius_search(dev(q), dev(s), dev(ql), dev(sl), float(radius), len(s))
+        assert np.array_equal(got.cpu().numpy(), want), name
+
+
 def test_exact_ties_order_by_index():
     from lcrnet_amd.modules.ops import radius_search
     # lattice points: many exactly equal distances -> order must be (d2, idx)
