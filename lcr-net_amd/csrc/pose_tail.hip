@@ -679,11 +679,11 @@ __device__ __forceinline__ float sks_dot(const float2v (&K)[SKR_P], const float*
   const float2 t2 = *reinterpret_cast<const float2*>(sc + part * SKS_STRIDE + 4 * (SKR_P / 2));
   float2v acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
 #pragma unroll
-  for (int q = 0; q < SKR_P / 2; ++q) {
-    acc0 += K[2 * q] * float2v{t[q].x, t[q].y};
-    acc1 += K[2 * q + 1] * float2v{t[q].z, t[q].w};
+  for (int q = 0; q < SKR_P / 2; ++q) {                 // explicit FMAs: the library is built with -ffp-contract=off
+    acc0 = __builtin_elementwise_fma(K[2 * q], float2v{t[q].x, t[q].y}, acc0);
+    acc1 = __builtin_elementwise_fma(K[2 * q + 1], float2v{t[q].z, t[q].w}, acc1);
   }
-  acc0 += K[SKR_P - 1] * float2v{t2.x, t2.y};
+  acc0 = __builtin_elementwise_fma(K[SKR_P - 1], float2v{t2.x, t2.y}, acc0);
   acc0 += acc1;
   return quad_sum(acc0.x + acc0.y);
 }
@@ -890,13 +890,13 @@ __global__ __launch_bounds__(SKC_T) void k_log_sinkhorn_coop(float* __restrict__
       for (; j + 48 < N1; j += 64) {
         const float x0 = row[j] + v[j], x1 = row[j + 16] + v[j + 16], x2 = row[j + 32] + v[j + 32], x3 = row[j + 48] + v[j + 48];
         const float mn = fmaxf(fmaxf(fmaxf(x0, x1), fmaxf(x2, x3)), m);
-        sum = sum * fast_exp(m - mn) + ((fast_exp(x0 - mn) + fast_exp(x1 - mn)) + (fast_exp(x2 - mn) + fast_exp(x3 - mn)));
+        sum = fmaf(sum, fast_exp(m - mn), (fast_exp(x0 - mn) + fast_exp(x1 - mn)) + (fast_exp(x2 - mn) + fast_exp(x3 - mn)));
         m = mn;
       }
       for (; j < N1; j += 16) {
         const float x = row[j] + v[j];
         const float mn = fmaxf(x, m);
-        sum = sum * fast_exp(m - mn) + fast_exp(x - mn);
+        sum = fmaf(sum, fast_exp(m - mn), fast_exp(x - mn));
         m = mn;
       }
       float mx = fmaxf(m, dpp0<DPP_QUAD_1032>(m));
@@ -917,13 +917,13 @@ __global__ __launch_bounds__(SKC_T) void k_log_sinkhorn_coop(float* __restrict__
       for (; i + 4 <= ib; i += 4) {
         const float x0 = col[i * N1] + ur[i], x1 = col[(i + 1) * N1] + ur[i + 1], x2 = col[(i + 2) * N1] + ur[i + 2], x3 = col[(i + 3) * N1] + ur[i + 3];
         const float mn = fmaxf(fmaxf(fmaxf(x0, x1), fmaxf(x2, x3)), m);
-        sum = sum * fast_exp(m - mn) + ((fast_exp(x0 - mn) + fast_exp(x1 - mn)) + (fast_exp(x2 - mn) + fast_exp(x3 - mn)));
+        sum = fmaf(sum, fast_exp(m - mn), (fast_exp(x0 - mn) + fast_exp(x1 - mn)) + (fast_exp(x2 - mn) + fast_exp(x3 - mn)));
         m = mn;
       }
       for (; i < ib; ++i) {
         const float x = col[i * N1] + ur[i];
         const float mn = fmaxf(x, m);
-        sum = sum * fast_exp(m - mn) + fast_exp(x - mn);
+        sum = fmaf(sum, fast_exp(m - mn), fast_exp(x - mn));
         m = mn;
       }
       s_red[(sub * N1 + jc) * 2] = m;
