@@ -104,8 +104,9 @@ __device__ __forceinline__ void attention_tile(const float* __restrict__ q, cons
   __syncthreads();
   // B operand of S^T = K·Q^T: B[kd][j=query] = Q[query][kd]; hoisted: 16 values per lane
   float qf[16];
+  const float scale2 = scale * 1.44269504088896341f;
 #pragma unroll
-  for (int kk = 0; kk < 16; ++kk) qf[kk] = s_q[col * AT_LD + 2 * kk + half] * scale;
+  for (int kk = 0; kk < 16; ++kk) qf[kk] = s_q[col * AT_LD + 2 * kk + half] * scale2;     // scores in base-2 units: exp2 below is the bare v_exp_f32
 
   floatx16 o;   // O^T[d = row][query = col]
 #pragma unroll
@@ -149,11 +150,11 @@ __device__ __forceinline__ void attention_tile(const float* __restrict__ q, cons
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
     const float m_new = fmaxf(m, tmax);                 // finite: every tile holds at least one valid key
-    const float alpha = expf(m - m_new);                 // exp(-inf) = 0 on the first tile
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);   // exp2(-inf) = 0 on the first tile
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      s[r] = expf(s[r] - m_new);
+      s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
       psum += s[r];
     }
     psum += __shfl_xor(psum, 32);
@@ -191,7 +192,7 @@ __device__ __forceinline__ void attention_tile(const float* __restrict__ q, cons
   float lsum = 0.f, wgt[AT_SPLIT];
 #pragma unroll
   for (int u = 0; u < AT_SPLIT; ++u) {
-    wgt[u] = expf(mg->m[u][col] - mm);                      // exp(-inf) = 0; wavefront 0 always has a block, so mm is finite
+    wgt[u] = __builtin_amdgcn_exp2f(mg->m[u][col] - mm);                      // exp(-inf) = 0; wavefront 0 always has a block, so mm is finite
     lsum += mg->l[u][col] * wgt[u];
   }
   // O^T[d][query]: lane = query `col`, rows d = (r&3) + 8*(r>>2) + 4*half
