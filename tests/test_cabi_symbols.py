@@ -88,3 +88,18 @@ def test_stats_arena_hands_out_disjoint_zeroed_tables():
         e = F._zero_stats(2, 32, dev)               # outer arena exhausted
         assert float(e.sum()) == 0.0
     assert F._ARENA.buf is None
+
+
+def test_library_is_built_without_fp_contraction():
+    """Bit-exact neighbour rows need d2 = ((dx*dx + dy*dy) + dz*dz) with every operation rounded (nanoflann.hpp:432-440); hipcc's default
+    -ffp-contract=fast would fuse a product into the add.  The build recipe must keep contraction off (the exact helpers of common.h
+    also carry the pragma; the GPU test test_distance_arithmetic_is_not_contracted checks the result)."""
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lcr_build", os.path.join(here, "lcr-net_amd", "csrc", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert "-ffp-contract=off" in mod.FLAGS
+    src = open(os.path.join(here, "lcr-net_amd", "csrc", "common.h")).read()
+    assert src.count("#pragma clang fp contract(off)") >= 4
