@@ -46,6 +46,7 @@ struct GsHeader {
   uint32_t bb_min[GS_MAX_B][3], bb_max[GS_MAX_B][3];
   float    org[GS_MAX_B][3];
   uint64_t NX[GS_MAX_B], NY[GS_MAX_B];
+  uint64_t top[GS_MAX_B];           // NX * NY * NZ when the escape range below is in use, else 0
   int32_t  M[GS_MAX_B];              // distinct voxels per cloud
   int64_t  n_seg;                    // total distinct voxels
 };
@@ -166,9 +167,18 @@ __global__ void k_gs_params(GsHeader* h, float voxel, float inv_voxel, int key_b
     h->NY[b] = NY;
     // largest key of this cloud (if the product overflows 64 bits the key is not sortable together with a cloud id)
     const unsigned __int128 top = static_cast<unsigned __int128>(NX) * NY * NZ;
+    // A point can land one cell BELOW the origin: origin = floor(min * fl(1/v)) * v is rounded twice, so (min - origin) / v may come
+    // out as -epsilon, its floor as -1, and the reference's (size_t) cast turns that into 2^64 - 1 (grid_subsampling_cpu.cpp:32-35;
+    // the key then wraps mod 2^64 — a voxel of its own, found by the fuzz at 1 in ~2700 random stacks).  Such keys are -1 - NX - NX*NY
+    // at the lowest, so they are sorted in an escape range [top, 3 top + 3) behind the regular keys (sort key = top + (-key)) and turned
+    // back into the true 64-bit key for the hash-order replay (k_gs_reduce).  Two more key bits per cloud.
+    h->top[b] = 0;
     int kb = 64;
-    if ((top >> 64) == 0) kb = bits_of(static_cast<uint64_t>(top));
-    else kb = 65;
+    if ((top >> 64) != 0) kb = 65;
+    else if (static_cast<uint64_t>(top) < (1ull << 61)) {
+      h->top[b] = static_cast<uint64_t>(top);
+      kb = bits_of(3 * static_cast<uint64_t>(top) + 3);
+    } else kb = bits_of(static_cast<uint64_t>(top));
     kbits = max(kbits, kb);
   }
   const int cbits = bits_of(static_cast<uint64_t>(B - 1));
@@ -193,7 +203,12 @@ __global__ __launch_bounds__(256) void k_gs_keys(GsHeader* h, const float* __res
     const uint64_t ix = f2u64(floorf(fdiv(fsub(xyz[3 * i + 0], h->org[b][0]), voxel)));   // :32
     const uint64_t iy = f2u64(floorf(fdiv(fsub(xyz[3 * i + 1], h->org[b][1]), voxel)));   // :33
     const uint64_t iz = f2u64(floorf(fdiv(fsub(xyz[3 * i + 2], h->org[b][2]), voxel)));   // :34
-    const uint64_t key = ix + h->NX[b] * iy + h->NX[b] * h->NY[b] * iz;                    // :35 (wraps mod 2^64 like size_t)
+    uint64_t key = ix + h->NX[b] * iy + h->NX[b] * h->NY[b] * iz;                          // :35 (wraps mod 2^64 like size_t)
+    const uint64_t top = h->top[b];
+    if (top && key >= top) {                                                               // below the origin on some axis: escape range
+      const uint64_t neg = 0ull - key;
+      if (static_cast<int64_t>(key) < 0 && neg <= 2 * top + 2) key = top + neg;
+    }
     // a key that does not fit the promised bits is reported AND truncated: the result of this call is then garbage (the host
     // retries), but the cloud field stays intact, so every cloud's voxels remain inside its own slice of the work arrays
     if (kbits < 64 && (key >> kbits) != 0) atomicOr(status, LCR_STATUS_KEY_OVERFLOW);
@@ -290,11 +305,12 @@ __global__ __launch_bounds__(256) void k_gs_reduce(GsHeader* h, const float* __r
     bary[3 * seg + 1] = fmul(sy, rc);
     bary[3 * seg + 2] = fmul(sz, rc);
     const int b = kbits < 64 ? static_cast<int>(key >> kbits) : 0;
-    seg_key[seg] = kbits < 64 ? (key & ((1ull << kbits) - 1ull)) : key;
+    uint64_t vk = kbits < 64 ? (key & ((1ull << kbits) - 1ull)) : key;
+    if (h->top[b] && vk >= h->top[b]) vk = 0ull - (vk - h->top[b]);       // escape range -> the reference's wrapped 64-bit key
+    seg_key[seg] = vk;
     const uint32_t f = v[i];   // stable sort => first element of the run is the first occurrence
     seg_first[seg] = f;
     first_flag[f] = 1;
-    (void)b;
   }
 }
 
