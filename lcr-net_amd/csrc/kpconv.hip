@@ -137,7 +137,7 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate_vec(const fl
     if (n > 0) {
       auto compute = [&](int s, const float4& pp, const VecT (&ff)[NL]) {
         const float ex = pp.x - kx, ey = pp.y - ky, ez = pp.z - kz;
-        const float wv = fmaxf(1.f - __builtin_amdgcn_sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * inv_sigma, 0.f);
+        const float wv = fmaxf(fmaf(-__builtin_amdgcn_sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))), inv_sigma, 1.f), 0.f);
 #pragma unroll
         for (int q = 0; q < NL; ++q)
 #pragma unroll
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(KP_WAVES * 64, 3) void k_kpconv_fused32(const float
       if (n > 0) {
         auto compute = [&](int st, const float4& pp, const float2& ff) {
           const float ex = pp.x - kx, ey = pp.y - ky, ez = pp.z - kz;
-          float wv = fmaxf(1.f - __builtin_amdgcn_sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * inv_sigma, 0.f);
+          float wv = fmaxf(fmaf(-__builtin_amdgcn_sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))), inv_sigma, 1.f), 0.f);
           wv = (real_k && 4 * st + sub < n) ? wv : 0.f;
           acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, ff.x, acc[0], 0, 0, 0);
           acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, ff.y, acc[1], 0, 0, 0);
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_cin1(const float* __re
 #pragma unroll
       for (int k = 0; k < KP_K; ++k) {
         const float ex = dx - kp.p[k][0], ey = dy - kp.p[k][1], ez = dz - kp.p[k][2];
-        a[k] = fmaf(fmaxf(1.f - __builtin_amdgcn_sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * inv_sigma, 0.f), f, a[k]);
+        a[k] = fmaf(fmaxf(fmaf(-__builtin_amdgcn_sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))), inv_sigma, 1.f), 0.f), f, a[k]);
       }
     };
     if (r0.j >= 0 && r0.j < Ns) add(n0.f, n0.x, n0.y, n0.z);
