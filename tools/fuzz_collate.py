@@ -1,6 +1,6 @@
 """Whole native collate (raw scans -> 0.3 m voxels -> 3 subsamples -> 10 searches, one native call) vs the C++ oracle on random
 stacks of decimated synthetic scans under random rigid motions (large translations stress the fp32 voxel arithmetic):
-    python tools/fuzz_collate.py FIRST_SEED LAST_SEED"""
+    python tools/fuzz_collate.py FIRST_SEED LAST_SEED [dense]"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
@@ -12,10 +12,11 @@ t0 = time.time(); bad = []; n = 0
 base = {i: synthetic.synthetic_scan(i) for i in range(6)}
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     rng = np.random.default_rng(seed)
-    B = int(rng.integers(1, 5))
+    dense = len(sys.argv) > 3 and sys.argv[3] == "dense"          # fuller scans, up to 8 clouds per stack
+    B = int(rng.integers(1, 9 if dense else 5))
     clouds = []
     for _ in range(B):
-        s = base[int(rng.integers(0, 6))][:: int(rng.integers(4, 40))]
+        s = base[int(rng.integers(0, 6))][:: int(rng.integers(1, 6) if dense else rng.integers(4, 40))]
         a = rng.uniform(0, 2 * np.pi)
         R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], dtype=np.float32)
         t = (rng.normal(0, [300, 300, 20])).astype(np.float32)
