@@ -351,6 +351,9 @@ int lcr_log_sinkhorn(float* S, const uint8_t* row_mask, const uint8_t* col_mask,
  * persistent launch (row slabs per workgroup, one counter hand-off per iteration) instead of two launches per iteration; the last
  * floats of the workspace hold a status word (bit 0: a hand-off timed out — the result is then invalid). */
 int lcr_log_sinkhorn_ws_floats(int64_t B, int M, int N, size_t* floats);
+/* which form lcr_log_sinkhorn_ex takes for (B, M, N) with a workspace of lcr_log_sinkhorn_ws_floats floats: 0 register-resident
+ * (scaled / log domain), 1 LDS-resident, 2 persistent (the ONLY form that writes the status word), 3 two launches per iteration. */
+int lcr_log_sinkhorn_form(int64_t B, int M, int N, int* form);
 int lcr_log_sinkhorn_ex(float* S, const uint8_t* row_mask, const uint8_t* col_mask, int64_t B, int M, int N, int iters,
                         float inf_val, float* uv_ws, size_t uv_floats, void* stream);
 /* Dustbin top-1 matching in the exp domain (superpoint_matching.py:130-162; local_global_registration.py:49-92 with k=1,

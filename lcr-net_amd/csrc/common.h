@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
+#include <atomic>
 #include <mutex>
 #endif
 
@@ -47,6 +48,28 @@ struct Carver {
 };
 
 inline int div_up(int64_t a, int64_t b) { return static_cast<int>((a + b - 1) / b); }
+
+// Opt-in to more than 64 KB of dynamic LDS for one kernel.  Function attributes are PER DEVICE and this library is called from several
+// host threads (pipeline workers), so the "already done" state is one atomic per (kernel, device): racing callers both set the
+// attribute (idempotent), nobody launches before it is set on HIS device.  One static DynLds object per kernel at the call site.
+struct DynLds {
+  static constexpr int MAX_DEV = 64;
+  std::atomic<int> have[MAX_DEV];
+  DynLds() { for (auto& h : have) h.store(0, std::memory_order_relaxed); }
+  hipError_t need(const void* kernel, size_t bytes) {
+    int dev = 0;
+    const int want = static_cast<int>(bytes);
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV)       // unknown device: set it every time (cheap, idempotent)
+      return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    if (have[dev].load(std::memory_order_acquire) >= want) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    if (e == hipSuccess) {
+      int cur = have[dev].load(std::memory_order_relaxed);
+      while (cur < want && !have[dev].compare_exchange_weak(cur, want, std::memory_order_release)) {}
+    }
+    return e;
+  }
+};
 
 #ifdef __HIPCC__
 // ---- exact fp32 arithmetic (never contracted into FMA) ------------------------------------------

@@ -755,9 +755,8 @@ extern "C" int lcr_grid_subsample_ex(const float* xyz, const int64_t* len, int B
   rc = exclusive_scan_i32(L.first, L.first, n_cap + 1, nullptr, L.scan_ws, st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_gs_insertion, dim3(nblk), dim3(256), 0, st, L.hdr, L.first, L.seg_key, L.seg_first, L.ins_key, L.ins_seg);
-  static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gs_hashorder),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(HM_LDS_BYTES));
-  if (lds_ok != hipSuccess) {
+  static DynLds hm_opt_in;
+  if (hm_opt_in.need(reinterpret_cast<const void*>(&k_gs_hashorder), HM_LDS_BYTES) != hipSuccess) {
     set_error("lcr_grid_subsample: cannot reserve %zu B of LDS for the hash-order kernel", HM_LDS_BYTES);
     return LCR_EHIP;
   }

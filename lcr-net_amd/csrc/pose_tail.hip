@@ -724,7 +724,7 @@ __global__ __launch_bounds__(SKR_T) void k_sinkhorn_scaled(float* __restrict__ S
   __shared__ float u[SKR_LINES + 8], v[SKR_LINES + 8], log_mu[SKR_LINES + 8], log_nu[SKR_LINES + 8];
   __shared__ __attribute__((aligned(16))) float ga[4 * SKS_STRIDE], gb[4 * SKS_STRIDE], su[4 * SKS_STRIDE], sv[4 * SKS_STRIDE];
   __shared__ float s_norm;
-  __shared__ int s_flag, s_chg[2];
+  __shared__ int s_flag[2], s_chg[2];                    // both double-buffered by iteration parity (see the loop)
   const int64_t b = blockIdx.x;
   const int M1 = M + 1, N1 = N + 1;
   float* sg = S + b * M1 * N1;
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(SKR_T) void k_sinkhorn_scaled(float* __restrict__ S
     sv[t] = 1.f;
   }
   if (threadIdx.x == 0) {
-    s_flag = 0;
+    s_flag[0] = 0;
     s_chg[0] = 0;
   }
   __syncthreads();
@@ -777,24 +777,27 @@ __global__ __launch_bounds__(SKR_T) void k_sinkhorn_scaled(float* __restrict__ S
       if (row_on && owner) {
         const float un = mu * __builtin_amdgcn_rcpf(sum);
         changed |= __float_as_uint(un) != __float_as_uint(uo);
-        if (!(un >= SKS_BAND_LO && un <= SKS_BAND_HI)) atomicOr(&s_flag, (un >= SKS_FAIL_LO && un <= SKS_FAIL_HI) ? 1 : 2);
+        if (!(un >= SKS_BAND_LO && un <= SKS_BAND_HI)) atomicOr(&s_flag[it & 1], (un >= SKS_FAIL_LO && un <= SKS_FAIL_HI) ? 1 : 2);
         su[pl] = uo = un;
       }
     }
     __syncthreads();
-    if (threadIdx.x == 0) s_chg[(it + 1) & 1] = 0;       // nobody reads or writes the other parity's word between these two barriers
+    if (threadIdx.x == 0) {                              // nobody reads or writes the other parity's words between these two barriers:
+      s_chg[(it + 1) & 1] = 0;                           // their last readers (the block-uniform reads below, iteration it - 1) are
+      s_flag[(it + 1) & 1] = 0;                          // behind the barrier above, their next writers (iteration it + 1) behind the next
+    }
     {
       const float sum = extra ? sks_dot_x(KCx, su, lane) : sks_dot(KC, su, part);
       if (col_on && owner) {
         const float vn = nu * __builtin_amdgcn_rcpf(sum);
         changed |= __float_as_uint(vn) != __float_as_uint(vo);
-        if (!(vn >= SKS_BAND_LO && vn <= SKS_BAND_HI)) atomicOr(&s_flag, (vn >= SKS_FAIL_LO && vn <= SKS_FAIL_HI) ? 1 : 2);
+        if (!(vn >= SKS_BAND_LO && vn <= SKS_BAND_HI)) atomicOr(&s_flag[it & 1], (vn >= SKS_FAIL_LO && vn <= SKS_FAIL_HI) ? 1 : 2);
         sv[pl] = vo = vn;
       }
     }
     if (changed) s_chg[it & 1] = 1;
     __syncthreads();
-    const int any = s_chg[it & 1], flag = s_flag;        // block-uniform: written before the barrier above
+    const int any = s_chg[it & 1], flag = s_flag[it & 1];   // block-uniform: written before the barrier above, not again before two more
     if (flag & 2) {                                      // out of fp32 range: the log-domain kernel redoes this problem from its input
       if (threadIdx.x == 0) redo[b] = 1u;
       return;
@@ -812,7 +815,6 @@ __global__ __launch_bounds__(SKR_T) void k_sinkhorn_scaled(float* __restrict__ S
         }
       }
       __syncthreads();
-      if (threadIdx.x == 0) s_flag = 0;
       if (!extra) sks_build(sm, line, part, row_live, col_live, M1, N1, ga, gb, KR, KC);
       else sks_build_x(sm, lane, row_live, col_live, M1, N1, ga, gb, KRx, KCx);
       __syncthreads();
@@ -1542,6 +1544,16 @@ extern "C" int lcr_log_sinkhorn_ws_floats(int64_t B, int M, int N, size_t* float
   *floats = std::max(static_cast<size_t>(B) * (2 * (static_cast<size_t>(M) + N + 2) + 1), sk_coop_floats(B, M, N)) + 1;   // + the status word (last)
   return LCR_OK;
 }
+// must mirror the dispatch of lcr_log_sinkhorn_ex below (with a workspace of lcr_log_sinkhorn_ws_floats floats)
+extern "C" int lcr_log_sinkhorn_form(int64_t B, int M, int N, int* form) {
+  if (!form || B < 1 || M < 1 || N < 1) return LCR_EARG;
+  const size_t mat_bytes = sizeof(float) * (static_cast<size_t>(M + 1) * (N + 1) + 2 * (M + N + 2));
+  if (M + 1 <= SKR_LINES && N + 1 <= SKR_LINES) *form = 0;
+  else if (mat_bytes <= 150 * 1024) *form = 1;
+  else if (sk_coop_plan(B, M, N, nullptr, nullptr)) *form = 2;
+  else *form = 3;
+  return LCR_OK;
+}
 extern "C" int lcr_log_sinkhorn_ex(float* S, const uint8_t* row_mask, const uint8_t* col_mask, int64_t B, int M, int N, int iters, float inf_val,
                                    float* uv_ws, size_t uv_floats, void* stream);
 extern "C" int lcr_log_sinkhorn(float* S, const uint8_t* row_mask, const uint8_t* col_mask, int64_t B, int M, int N, int iters, float inf_val,
@@ -1558,20 +1570,19 @@ extern "C" int lcr_log_sinkhorn_ex(float* S, const uint8_t* row_mask, const uint
     unsigned* redo = scaled ? reinterpret_cast<unsigned*>(uv_ws) : nullptr;      // B words of the workspace: problems handed back
     if (scaled) {
       const size_t lds = sizeof(float) * static_cast<size_t>(M + 1) * (N + 1);
-      static bool attr_set = false;
-      if (!attr_set) {   // up to 132 x 132 floats of dynamic LDS beside the static vectors
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sinkhorn_scaled), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            static_cast<int>(sizeof(float) * SKR_LINES * SKR_LINES));
-        attr_set = true;
+      static DynLds opt_in;                              // up to 132 x 132 floats of dynamic LDS beside the static vectors
+      if (opt_in.need(reinterpret_cast<const void*>(&k_sinkhorn_scaled), sizeof(float) * SKR_LINES * SKR_LINES) != hipSuccess) {
+        set_error("lcr_log_sinkhorn: cannot reserve dynamic LDS for the scaled-domain kernel");
+        return LCR_EHIP;
       }
       hipLaunchKernelGGL(k_sinkhorn_scaled, dim3(static_cast<int>(B)), dim3(SKR_T), lds, ST(stream), S, row_mask, col_mask, M, N, iters, inf_val, redo);
     }
     hipLaunchKernelGGL(k_log_sinkhorn_reg, dim3(static_cast<int>(B)), dim3(SKR_T), 0, ST(stream), S, row_mask, col_mask, M, N, iters, inf_val, redo);
   } else if (mat_bytes <= 150 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {   // > 64 KB of dynamic LDS needs an explicit opt-in
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_log_sinkhorn_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-      attr_set = true;
+    static DynLds opt_in;                                // > 64 KB of dynamic LDS needs an explicit opt-in
+    if (opt_in.need(reinterpret_cast<const void*>(&k_log_sinkhorn_lds), 150 * 1024) != hipSuccess) {
+      set_error("lcr_log_sinkhorn: cannot reserve dynamic LDS for the LDS-resident kernel");
+      return LCR_EHIP;
     }
     hipLaunchKernelGGL(k_log_sinkhorn_lds, dim3(static_cast<int>(B)), dim3(SK_T), mat_bytes, ST(stream), S, row_mask, col_mask, M, N, iters, inf_val,
                        uv_ws);
@@ -1587,10 +1598,10 @@ extern "C" int lcr_log_sinkhorn_ex(float* S, const uint8_t* row_mask, const uint
     c.slab = slab;
     c.nsub = std::min(4, SKC_T / N1);
     const size_t lds = sizeof(float) * (static_cast<size_t>(slab) * N1 + 2 * (M1 + N1) + 2 * static_cast<size_t>(c.nsub) * N1);
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_log_sinkhorn_coop), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-      attr_lds = lds;
+    static DynLds opt_in;
+    if (opt_in.need(reinterpret_cast<const void*>(&k_log_sinkhorn_coop), lds) != hipSuccess) {
+      set_error("lcr_log_sinkhorn: cannot reserve %zu B of dynamic LDS for the persistent kernel", lds);
+      return LCR_EHIP;
     }
     hipLaunchKernelGGL(k_sk_coop_init, dim3(1), dim3(64), 0, ST(stream), c.counter, c.status, static_cast<int>(B));
     hipLaunchKernelGGL(k_log_sinkhorn_coop, dim3(static_cast<int>(B) * G), dim3(SKC_T), lds, ST(stream), S, row_mask, col_mask, M, N, iters, inf_val, c);

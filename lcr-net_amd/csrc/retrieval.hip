@@ -132,9 +132,10 @@ __global__ __launch_bounds__(TK_T) void k_row_topk(const float* __restrict__ dot
       if (key <= thr) s_key[atomicAdd(&s_cnt, 1)] = key;
     }
     __syncthreads();
-    const int n = s_cnt;                   // block-uniform
+    const int n = s_cnt;
+    __syncthreads();                       // every thread holds the SAME n before the next chunk's admissions move s_cnt again:
+                                           // a late reader would otherwise take the re-selection branch (barriers inside) alone
     if (n + TK_STEP > TK_CAND || c1 >= lim) {
-      __syncthreads();
       reselect(n);
       if (tid == 0) s_cnt = nbest;
       __syncthreads();

@@ -412,6 +412,7 @@ class _PendingStatus(threading.local):
 
 
 _pending_ot_status = _PendingStatus()
+_PENDING_OT_MAX = 32
 
 
 def check_transport_status():
@@ -433,10 +434,19 @@ def log_optimal_transport(raw_scores, row_masks, col_masks, alpha, scale=1.0, it
     nfl = ctypes.c_size_t(0)
     _lib.check(_L().lcr_log_sinkhorn_ws_floats(B, M, N, ctypes.byref(nfl)), "lcr_log_sinkhorn_ws_floats")
     uv = torch.empty((nfl.value,), dtype=torch.float32, device=dev)
-    uv[-1:].zero_()                                   # status word: bit 0 = a hand-off of the persistent form timed out
-    _pending_ot_status.items.append(uv[-1:].view(torch.int32))
+    form = ctypes.c_int(0)
+    _lib.check(_L().lcr_log_sinkhorn_form(B, M, N, ctypes.byref(form)), "lcr_log_sinkhorn_form")
+    persistent = form.value == 2                      # the only form with hand-offs, i.e. the only one that writes a status word
+    if persistent:
+        uv[-1:].zero_()                               # status word: bit 0 = a hand-off of the persistent form timed out
     _lib.check(_L().lcr_log_sinkhorn_ex(_lib.ptr(S), _lib.ptr(rm), _lib.ptr(cm), B, M, N, int(iters), float(inf), _lib.ptr(uv), uv.numel(), _sp(S)),
                "lcr_log_sinkhorn")
+    if persistent:
+        # a stream-ordered 1-element copy (not a view: a view would pin the whole workspace until somebody drains the list)
+        items = _pending_ot_status.items
+        items.append(uv[-1:].view(torch.int32).clone())
+        if len(items) > _PENDING_OT_MAX:              # callers that never reach top1_matching: fold on the device, no host sync
+            _pending_ot_status.items = [torch.stack([t.reshape(()) for t in items]).max().reshape(1)]
     return S
 
 

@@ -354,11 +354,13 @@ def test_radius_search_fuzz_against_the_oracle(seed):
         q_sizes[0] = 70000                                   # > 65 536 queries: four per turn
     extent = np.array([rng.uniform(5, 60), rng.uniform(5, 60), rng.uniform(0.5, 6)])
     s_list, q_list = [], []
+    dense_seen = False                                       # some query certainly sees a planted dense ball (premise of the last assert)
     for b in range(B):
         s = rng.random((int(s_sizes[b]), 3)) * extent - extent / 2
         if seed % 3 == 0:
             s = np.round(s / 0.25) * 0.25                    # lattice: exact ties, points on common planes
-        if seed % 3 == 1 and len(s) > 700:
+        planted = seed % 3 == 1 and len(s) > 700             # per CLOUD: the ball goes into every cloud that is large enough
+        if planted:
             s[:700] = s[0] + rng.standard_normal((700, 3)) * 0.05 * radius      # a ball with > 512 points inside the radius
         q = rng.random((int(q_sizes[b]), 3)) * extent * 1.3 - extent * 0.65       # some queries outside the support box
         if len(q) and len(s):
@@ -366,6 +368,12 @@ def test_radius_search_fuzz_against_the_oracle(seed):
             q[:k] = s[rng.integers(0, len(s), k)]           # half of the queries ON support points
         s_list.append(s.astype(np.float32))
         q_list.append(q.astype(np.float32))
+        if planted and len(q):
+            # a query of THIS cloud within r / 2 of the ball's centre (points 0 .. 699 lie within ~0.25 r of it: 5 sigma) has more than
+            # 512 of them inside its radius
+            far = np.linalg.norm(s_list[-1][:700].astype(np.float64) - s_list[-1][0], axis=1).max()
+            near = np.linalg.norm(q_list[-1].astype(np.float64) - s_list[-1][0], axis=1).min()
+            dense_seen |= bool(near + far < 0.999 * radius)
     s, q = np.concatenate(s_list), np.concatenate(q_list)
     sl, ql = s_sizes.astype(np.int64), q_sizes.astype(np.int64)
     if len(q) == 0 or len(s) == 0:
@@ -376,8 +384,8 @@ def test_radius_search_fuzz_against_the_oracle(seed):
     got, gcnt = grid.query(dev(q), dev(ql), limit, want_counts=True)
     assert np.array_equal(gcnt.cpu().numpy(), cnt), "in-radius counts"
     assert np.array_equal(got.cpu().numpy().astype(np.int64), want), "neighbour rows"
-    if seed % 3 == 1 and len(s) > 700:
-        assert cnt.max() > 512                               # the storage-free fallback ran
+    if dense_seen:
+        assert cnt.max() > 512, "generator premise: a query inside a planted dense ball must take the storage-free fallback"
 
 
 def test_more_than_64_clouds_per_call():
