@@ -36,8 +36,11 @@ if ROOT not in sys.path:
 BATCH = int(os.environ.get("LCR_BENCH_BATCH", "8"))   # BASELINE configs[1]: 8 scans per step (override only for experiments)
 VOXEL, RADIUS, NUM_STAGES = 0.3, 1.275, 4
 LIMITS = [64, 65, 74, 80]          # reference training/eval default (dataset_loop_detection.py:25,80)
+ISO_PASSES = 3                     # clocked passes per distinct batch for the kernel-alone figures
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3           # dense fp32 MFMA/vector peak
+RS_VALU_PER_QUERY = 354            # SQ_INSTS_VALU per query of the search kernel (rocprofv3 --pmc)
+RS_VALU_SOURCE = "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU per query, profiles/r02_radius_pmc.md; 256 CUs at 2.4 GHz"
 PMC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # written by tools/pmc_summary.py from separate rocprofv3 --pmc passes
 
 
@@ -241,6 +244,18 @@ def spawn_ranks(args):
     sys.exit(rc)
 
 
+def rotated_inputs(scans, nb_in, dev):
+    """nb_in resident input batches: the scans rotated about the vertical axis by k * 37 degrees (other voxels, other neighbourhoods, same
+    scene statistics) -> [(points f32 [sum N, 3], lengths i64 [B])] on `dev`."""
+    inputs = []
+    for k in range(nb_in):
+        a = np.deg2rad(float(os.environ.get("LCR_BENCH_ROT_DEG", "37")) * k)
+        R = np.array([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]], dtype=np.float32)
+        inputs.append((torch.from_numpy(np.concatenate([s @ R.T for s in scans]).astype(np.float32)).to(dev),
+                       torch.tensor([len(s) for s in scans], dtype=torch.int64, device=dev)))
+    return inputs
+
+
 def search_bytes(stage_points, upsampling):
     """SURVEY §8d a-2, int32 indices: (Nq + Ns) * 12 B + Nq * limit * 4 B for each of the 10 (7) searches of one batch."""
     n, tot = stage_points, 0
@@ -293,12 +308,7 @@ def main():
     scans = make_batch(rank)
     # the steps cycle through a few DISTINCT resident batches (not one buffer re-fed every step): the scans rotated about z
     nb_in = max(1, args.distinct_batches)
-    inputs = []
-    for k in range(nb_in):
-        a = np.deg2rad(float(os.environ.get("LCR_BENCH_ROT_DEG", "37")) * k)
-        R = np.array([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]], dtype=np.float32)
-        inputs.append((torch.from_numpy(np.concatenate([s @ R.T for s in scans]).astype(np.float32)).to(dev),
-                       torch.tensor([len(s) for s in scans], dtype=torch.int64, device=dev)))
+    inputs = rotated_inputs(scans, nb_in, dev)
     raw_pts, raw_lens = inputs[0]
     gathered = torch.empty((world * BATCH, 256), dtype=torch.float32, device=dev) if world > 1 else None
 
@@ -371,107 +381,136 @@ def main():
     if os.environ.get("LCR_PIPE_STATS") and rank == 0:
         print("pipeline host threads:", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in pipe.stats.items()}, file=sys.stderr)
 
-    iso = iso_rs = None
+    iso = None
     summ = timer.records() if rank == 0 else None     # read the timed region's log before anything else is logged
     if rank == 0 and not os.environ.get("LCR_BENCH_NO_KTIMER"):
-        # the same launches once more with nothing else on the GPU (one stream, outside the timed region): in the timed
-        # region four streams share the CUs, so a launch's event-to-event duration includes time it spent waiting for them
-        iso_timer = F.KernelTimer({"gemm", "radius_query"})
-        dd_iso = pipe.preprocess(raw_pts, raw_lens)
-        pipe.encode(dd_iso)
-        torch.cuda.synchronize()
-        F.set_timer(iso_timer)
-        for _ in range(3):
-            dd_iso = pipe.preprocess(raw_pts, raw_lens)
-            pipe.encode(dd_iso)
-        torch.cuda.synchronize()
-        F.set_timer(None)
-        s_iso = iso_timer.records()
-        g = s_iso["gemm"]
-        iso = sum(2.0 * m[0] * m[1] * m[2] for _, _, m in g) / sum((k if k is not None else b) for b, k, _ in g) / 1e12
-        iso_rs = sum((k if k is not None else b) for b, k, _ in s_iso["radius_query"]) / 3.0
+        # Every distinct batch once more with NOTHING else on the GPU (one stream, one batch in flight, outside the timed region) and
+        # EVERY launch clocked: the kernels' own durations as a kernel trace of the encoder alone reports them
+        # (profiles/rNN_encoder_alone_kernel_summary.md), and the exact flops / launches of a step (no sampling).
+        iso = {"t_gemm": 0.0, "t_agg": 0.0, "t_rs": 0.0, "flops": [], "flops_agg": [], "n_gemm": 0, "n_agg": 0, "n_rs": 0, "passes": 0}
+        for pts_k, lens_k in inputs:
+            pipe.encode(pipe.preprocess(pts_k, lens_k))                # warm: this batch's allocations and cache lines
+            torch.cuda.synchronize()
+            for _ in range(ISO_PASSES):
+                iso_timer = F.KernelTimer({"kpconv_aggregate", "gemm", "radius_query"})
+                F.set_timer(iso_timer)
+                pipe.encode(pipe.preprocess(pts_k, lens_k))
+                torch.cuda.synchronize()
+                F.set_timer(None)
+                r = iso_timer.records()
+                own = lambda recs: sum((k if k is not None else b) for b, k, _ in recs)
+                iso["t_gemm"] += own(r["gemm"])
+                iso["t_agg"] += own(r["kpconv_aggregate"])
+                iso["t_rs"] += own(r["radius_query"])
+                iso["n_gemm"] += len(r["gemm"])
+                iso["n_agg"] += len(r["kpconv_aggregate"])
+                iso["n_rs"] += len(r["radius_query"])
+                iso["passes"] += 1
+            iso["flops"].append(sum(2.0 * m[0] * m[1] * m[2] for _, _, m in r["gemm"]))
+            iso["flops_agg"].append(sum(2.0 * 15 * nnz.get((M, Ns), M * H) * C for _, _, (M, Ns, H, C, isz) in r["kpconv_aggregate"]))
     if rank == 0 and os.environ.get("LCR_BENCH_NO_KTIMER"):            # A/B run without per-launch events: the headline only
         print(json.dumps({"value": round(world * BATCH * args.steps / dt, 3), "ms_per_step": round(dt / args.steps * 1e3, 3),
                           "ms_per_step_min": round(dt_min / args.steps * 1e3, 3), "ms_per_step_max": round(dt_max / args.steps * 1e3, 3), "ktimer": False}), flush=True)
         rank = -1
     if rank == 0:
         assert torch.isfinite(desc).all() and abs(float(desc.norm(dim=1).mean()) - 1.0) < 1e-3
-        # ---- roofline of the dominant kernel family, measured live with HIP events on the launch stream.
-        # Dominant by time = lcr::k_gemm_f32 (all tile variants; profiles/): compute-bound on the fp32 matrix cores, so
-        # "achieved" = algorithmic flops (2*M*N*K per launch) / launch time vs the 157.3 TFLOP/s dense fp32 MFMA peak.
-        # Two clocks per launch (lcr_ktimer_read2): the kernel's OWN begin-to-end time (hipExtLaunchKernel's start / stop events: what
-        # rocprofv3's kernel trace reports — `achieved` / `frac` below follow from profiles/*_kernel_summary.md) and the time between
-        # two events bracketing the launch on its stream (`*_event_bracketed`: includes the wait behind the other three streams).
+        # ---- roofline of the dominant kernel family (by time: the fp32 GEMMs, lcr::k_gemm_f32_deep + k_gemm_f32, profiles/).
+        # Compute-bound on the fp32 matrix cores: achieved = algorithmic flops (2*M*N*K per launch) / the kernels' own
+        # begin-to-end durations (hipExtLaunchKernel start / stop events on the launch stream = what a kernel trace reports) vs the
+        # 157.3 TFLOP/s dense fp32 MFMA peak.  TWO measurements, both live in this run:
+        #   * `achieved` / `frac` / `avg_launch_us`: every GEMM launch of ISO_PASSES passes over each distinct batch with nothing else on
+        #     the GPU.  This is the figure a rocprofv3 kernel trace reproduces (profiles/rNN_encoder_alone_kernel_summary.md: launches x
+        #     avg us of the k_gemm_f32* rows), because under the profiler the host is too slow for kernels of different streams to overlap.
+        #   * `in_pipeline`: every SAMPLE-th launch inside the timed region, where four streams share the CUs and a kernel's begin-to-end
+        #     time is about twice its time alone (NOT reproducible from a profile: rocprofv3 removes the overlap it would have to show).
+        # The only fraction that is purely the driver's clock is `whole_step`: the exact fp32 MFMA flops of a step / the step time.
         kown = lambda recs: sum((k if k is not None else b) for b, k, _ in recs)
         gem_r, agg_r, rsq_r = summ["gemm"], summ["kpconv_aggregate"], summ["radius_query"]
         tk_gemm, tk_agg, tk_rs = kown(gem_r), kown(agg_r), kown(rsq_r)
         gem, agg, rsq = [(b, m) for b, _, m in gem_r], [(b, m) for b, _, m in agg_r], [(b, m) for b, _, m in rsq_r]
         t_gemm, t_agg, t_rs = sum(t for t, _ in gem), sum(t for t, _ in agg), sum(t for t, _ in rsq)
-        flops = sum(2.0 * m[0] * m[1] * m[2] for _, m in gem)
+        flops = sum(2.0 * m[0] * m[1] * m[2] for _, m in gem)                          # of the SAMPLED launches (in-pipeline rate only)
+        flops_agg = sum(2.0 * 15 * nnz.get((M, Ns), M * H) * C for _, (M, Ns, H, C, isz) in agg)
+        uses = [len(range(k, args.steps, nb_in)) for k in range(nb_in)]              # how often the timed region fed each batch
+        mix = lambda per_batch: sum(u * v for u, v in zip(uses, per_batch)) / max(args.steps, 1)
+        flops_step, flops_agg_step = mix(iso["flops"]), mix(iso["flops_agg"])          # exact per step: no sampling involved
+        gemm_alone = sum(iso["flops"]) * ISO_PASSES / iso["t_gemm"] / 1e12             # TFLOP/s over all clocked passes
+        agg_alone = sum(iso["flops_agg"]) * ISO_PASSES / iso["t_agg"] / 1e12
+        iso_rs = iso["t_rs"] / max(iso["n_rs"], 1)                                     # one launch per batch (all searches)
         # KPConv layer = aggregation + its (15C x Cout) contraction, against SURVEY §8d's a-4 bytes: indices + query/support xyz +
         # support features + OUTPUT features + weights (the materialised (M,15C) aggregate is NOT algorithmic traffic)
         contr = [((k if k is not None else b), m) for b, k, m in gem_r if m[2] % 15 == 0 and m[2] >= 480]
         bytes_kp = sum(M * H * isz + (M + Ns) * 12 + Ns * C * 4 for _, (M, Ns, H, C, isz) in agg) + \
             sum(M * N * 4 + K * N * 4 for _, (M, N, K) in contr)
         t_kp = tk_agg + sum(t for t, _ in contr)
-        # the aggregation is MFMA work too (D[16 kernel points x C] += W[16 x 4] F[4 x C] per four neighbours): 2*15*nnz*C flops
-        flops_agg = sum(2.0 * 15 * nnz.get((M, Ns), M * H) * C for _, (M, Ns, H, C, isz) in agg)
         n_search = 7 if args.no_upsampling else 10
         rs_launch = tk_rs / max(len(rsq), 1)                                         # one launch per step (all searches of a batch)
         sp0 = stage_points
         n_queries = 2 * sp0[0] + 3 * sp0[1] + 3 * sp0[2] + 2 * sp0[3] if not args.no_upsampling else sp0[0] + 2 * sp0[1] + 2 * sp0[2] + 2 * sp0[3]
-        uses = [len(range(k, args.steps, nb_in)) for k in range(nb_in)]              # how often the timed region fed each batch
-        bytes_rs = sum(u * search_bytes(sp, not args.no_upsampling) for u, sp in zip(uses, stage_points_all)) / max(args.steps, 1)
+        bytes_rs = mix([search_bytes(sp, not args.no_upsampling) for sp in stage_points_all])
+        bytes_rs_iso = sum(search_bytes(sp, not args.no_upsampling) for sp in stage_points_all) / len(stage_points_all)
         traffic, traffic_src, traffic_rs = None, None, None
         if os.path.exists(PMC_JSON):
             pmc = json.load(open(PMC_JSON))
             traffic = pmc.get("k_gemm_f32", {}).get("traffic_bytes")
             traffic_rs = (pmc.get("k_radius_query_multi") or pmc.get("k_radius_query") or {}).get("traffic_bytes")
             traffic_src = "profiles/pmc_traffic.json: separate rocprofv3 --pmc passes of this command (2*FETCH_SIZE + WRITE_SIZE per launch), not measured in this run"
-        per_step = lambda recs: round(len(recs) * SAMPLE / max(args.steps, 1))
-        roof = {"bound": "mfma", "kernel": "lcr::k_gemm_f32 / k_gemm_f32_deep (fp32 MFMA, %d launches/step)" % per_step(gem),
-                "achieved": round(flops / tk_gemm / 1e12, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(flops / tk_gemm / 1e12 / FP32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "clock": "kernel begin-to-end (hipExtLaunchKernel start/stop events) of every %d-th launch over the timed region, four streams sharing the CUs" % SAMPLE,
-                "launches_timed": len(gem),
-                "avg_launch_us": round(tk_gemm / max(len(gem), 1) * 1e6, 2),
-                "achieved_event_bracketed": round(flops / t_gemm / 1e12, 2), "frac_event_bracketed": round(flops / t_gemm / 1e12 / FP32_PEAK_TFLOPS, 4),
-                "avg_launch_us_event_bracketed": round(t_gemm / max(len(gem), 1) * 1e6, 2),
-                "achieved_alone": round(iso, 2), "frac_alone": round(iso / FP32_PEAK_TFLOPS, 4),
-                "gflop_per_launch": round(flops / max(len(gem), 1) / 1e9, 3),
-                "gflop_per_step": round(flops * SAMPLE / max(args.steps, 1) / 1e9, 1),
+        gemm_per_step = iso["n_gemm"] / iso["passes"]
+        roof = {"bound": "mfma", "kernel": "lcr::k_gemm_f32 / k_gemm_f32_deep (fp32 MFMA, %d launches/step)" % round(gemm_per_step),
+                "achieved": round(gemm_alone, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(gemm_alone / FP32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "clock": "kernel begin-to-end (hipExtLaunchKernel start/stop events) of EVERY GEMM launch of %d passes over each of the %d distinct "
+                         "batches, encoder + pre-processing alone on the GPU, after the timed region; reproducible from "
+                         "profiles/*_encoder_alone_kernel_summary.md (launches x avg us of the k_gemm_f32* rows)" % (ISO_PASSES, nb_in),
+                "launches_timed": iso["n_gemm"],
+                "avg_launch_us": round(iso["t_gemm"] / max(iso["n_gemm"], 1) * 1e6, 2),
+                "kernel_ms_per_step": round(iso["t_gemm"] / iso["passes"] * 1e3, 4),
+                "gflop_per_launch": round(flops_step / gemm_per_step / 1e9, 3),
+                "gflop_per_step": round(flops_step / 1e9, 1),
+                "in_pipeline": {"achieved": round(flops / tk_gemm / 1e12, 2), "frac": round(flops / tk_gemm / 1e12 / FP32_PEAK_TFLOPS, 4),
+                                "avg_launch_us": round(tk_gemm / max(len(gem), 1) * 1e6, 2), "launches_timed": len(gem),
+                                "clock": "kernel begin-to-end of every %d-th launch INSIDE the timed region: four streams share the CUs, a kernel "
+                                         "takes about twice its time alone; not reproducible from a profile (rocprofv3 slows the host until "
+                                         "streams no longer overlap)" % SAMPLE,
+                                "achieved_event_bracketed": round(flops / t_gemm / 1e12, 2),
+                                "avg_launch_us_event_bracketed": round(t_gemm / max(len(gem), 1) * 1e6, 2)},
                 "kernel_time_over_step_time": {"gemm": round(tk_gemm * SAMPLE / dt, 3), "kpconv_aggregate": round(tk_agg * SAMPLE / dt, 3),
                                                "radius_query": round(tk_rs * SAMPLE / dt, 3),
-                                               "note": "sum of kernel begin-to-end times (sampled, scaled) / wall time; streams overlap, so the shares do not add up to 1"},
-                "neighbor": {"kernel": "lcr::k_radius_query[_multi] (%d searches in %d launch(es) per step)" % (n_search, max(1, per_step(rsq))),
+                                               "note": "sum of in-pipeline kernel begin-to-end times (sampled, scaled) / wall time; streams overlap, so the shares do not add up to 1"},
+                "neighbor": {"kernel": "lcr::k_radius_query[_multi] (%d searches in 1 launch per step)" % n_search,
                              "bound": "hbm",
-                             "algorithmic_mb_per_step": round(bytes_rs / 1e6, 2),
-                             "achieved": round(bytes_rs / rs_launch / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(bytes_rs / rs_launch / 1e9 / HBM_PEAK_GBS, 4),
-                             "ms_per_step": round(rs_launch * 1e3, 4),
-                             "ms_per_step_event_bracketed": round(t_rs / max(len(rsq), 1) * 1e3, 4),
-                             "algorithmic_bytes_per_launch": round(bytes_rs), "traffic": traffic_rs,
-                             "achieved_alone": round(search_bytes(stage_points, not args.no_upsampling) / iso_rs / 1e9, 1),
-                             "frac_alone": round(search_bytes(stage_points, not args.no_upsampling) / iso_rs / 1e9 / HBM_PEAK_GBS, 4),
-                             "ms_per_step_alone": round(iso_rs * 1e3, 4),
-                             # the search is bound by VALU ISSUE, not by HBM: rocprofv3 --pmc (profiles/r02_radius_pmc.md, unchanged kernel)
-                             # counts 354 VALU wavefront-instructions per query at 4 cycles each on a SIMD, i.e. 354 cycles per query and CU
-                             "instruction_floor": {"valu_cycles_per_query_per_cu": 354, "queries_per_step": int(n_queries),
-                                                   "ms_per_step": round(n_queries * 354 / 256 / 2.4e9 * 1e3, 4),
-                                                   "alone_over_floor": round(iso_rs / (n_queries * 354 / 256 / 2.4e9), 3),
-                                                   "source": "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU per query, profiles/r02_radius_pmc.md; 256 CUs at 2.4 GHz"}},
-                "aggregation": {"kernel": "lcr::k_kpconv_aggregate (fp32 MFMA 16x16x4, %d launches/step)" % per_step(agg), "bound": "mfma",
-                                "achieved": round(flops_agg / tk_agg / 1e12, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(flops_agg / tk_agg / 1e12 / FP32_PEAK_TFLOPS, 4), "gflop_per_step": round(flops_agg * SAMPLE / args.steps / 1e9, 2),
-                                "note": "2*15*nnz*C flops over the valid neighbours; kernel begin-to-end time inside the pipeline (other streams share the CUs)"},
-                "whole_step": {"gflop_per_step": round((flops + flops_agg) * SAMPLE / args.steps / 1e9, 1), "what": "GEMMs + KPConv aggregation (fp32 MFMA work of a step; sampled launches, scaled)",
-                               "tflops": round((flops + flops_agg) * SAMPLE / dt / 1e12, 2),
-                               "frac_of_fp32_mfma_peak": round((flops + flops_agg) * SAMPLE / dt / 1e12 / FP32_PEAK_TFLOPS, 4)},
+                             "algorithmic_mb_per_step": round(bytes_rs_iso / 1e6, 2),
+                             "achieved": round(bytes_rs_iso / iso_rs / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(bytes_rs_iso / iso_rs / 1e9 / HBM_PEAK_GBS, 4),
+                             "ms_per_step": round(iso_rs * 1e3, 4),
+                             "clock": "kernel begin-to-end, alone on the GPU (%d launches); in_pipeline = inside the timed region" % iso["n_rs"],
+                             "algorithmic_bytes_per_launch": round(bytes_rs_iso), "traffic": traffic_rs,
+                             "in_pipeline": {"achieved": round(bytes_rs / rs_launch / 1e9, 1), "frac": round(bytes_rs / rs_launch / 1e9 / HBM_PEAK_GBS, 4),
+                                             "ms_per_step": round(rs_launch * 1e3, 4),
+                                             "ms_per_step_event_bracketed": round(t_rs / max(len(rsq), 1) * 1e3, 4)},
+                             "north_star_target_frac": 0.6,
+                             # the search is bound by instruction issue, not by HBM: VALU wavefront-instructions per query
+                             # (rocprofv3 --pmc, profiles/) at 4 cycles each on a SIMD
+                             "instruction_floor": {"valu_cycles_per_query_per_cu": RS_VALU_PER_QUERY, "queries_per_step": int(n_queries),
+                                                   "ms_per_step": round(n_queries * RS_VALU_PER_QUERY / 256 / 2.4e9 * 1e3, 4),
+                                                   "alone_over_floor": round(iso_rs / (n_queries * RS_VALU_PER_QUERY / 256 / 2.4e9), 3),
+                                                   "source": RS_VALU_SOURCE}},
+                "aggregation": {"kernel": "lcr::k_kpconv_aggregate (fp32 MFMA 16x16x4, %d launches/step)" % round(iso["n_agg"] / iso["passes"]), "bound": "mfma",
+                                "achieved": round(agg_alone, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(agg_alone / FP32_PEAK_TFLOPS, 4), "gflop_per_step": round(flops_agg_step / 1e9, 2),
+                                "kernel_ms_per_step": round(iso["t_agg"] / iso["passes"] * 1e3, 4),
+                                "in_pipeline": {"achieved": round(flops_agg / tk_agg / 1e12, 2), "frac": round(flops_agg / tk_agg / 1e12 / FP32_PEAK_TFLOPS, 4)},
+                                "note": "2*15*nnz*C flops over the valid neighbours; alone on the GPU like `achieved` above"},
+                "whole_step": {"gflop_per_step": round((flops_step + flops_agg_step) / 1e9, 1),
+                               "what": "GEMMs + KPConv aggregation: exact fp32 MFMA flops of a step (every launch of a clocked pass over each distinct batch, "
+                                       "weighted by how often the timed region fed it) / the driver-visible step time",
+                               "tflops": round((flops_step + flops_agg_step) * args.steps / dt / 1e12, 2),
+                               "frac_of_fp32_mfma_peak": round((flops_step + flops_agg_step) * args.steps / dt / 1e12 / FP32_PEAK_TFLOPS, 4)},
                 "secondary": {"kernel": "KPConv layers: lcr::k_kpconv_aggregate + its (15C x Cout) contraction", "bound": "hbm",
                               "achieved": round(bytes_kp / t_kp / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(bytes_kp / t_kp / 1e9 / HBM_PEAK_GBS, 4),
                               "algorithmic_mb_per_step": round(bytes_kp * SAMPLE / args.steps / 1e6, 1),
-                              "ms_per_step": round(t_kp * SAMPLE / args.steps * 1e3, 3)}}
+                              "ms_per_step": round(t_kp * SAMPLE / args.steps * 1e3, 3), "clock": "in the pipeline (sampled)"}}
         line = {
             "metric": "scans/s (120k-pt KITTI-shape scan -> 256-D descriptor)",
             "value": round(world * BATCH * args.steps / dt, 3), "unit": "scans/s", "n_gpus": world, "steps": args.steps,

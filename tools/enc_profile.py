@@ -1,8 +1,8 @@
-"""Run only the encoder + NetVLAD on one pre-processed bench batch N times (for rocprofv3 --kernel-trace --stats)."""
+"""Run only the encoder + NetVLAD N times over the bench's distinct pre-processed batches, one stream, nothing else on the GPU (for
+rocprofv3 --kernel-trace --stats: the kernel-alone durations that bench.py's roofline.achieved / frac / avg_launch_us measure live)."""
 import os
 import sys
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,16 +13,14 @@ from lcrnet_amd.pipeline import DescriptorPipeline  # noqa: E402
 from lcrnet_amd.weights import seeded_state_dict  # noqa: E402
 
 dev = torch.device("cuda:0")
-scans = bench.make_batch(0)
-pts = torch.from_numpy(np.concatenate(scans)).to(dev)
-lens = torch.tensor([len(s) for s in scans], dtype=torch.int64, device=dev)
+inputs = bench.rotated_inputs(bench.make_batch(0), int(os.environ.get("LCR_ENC_PROFILE_BATCHES", "4")), dev)
 m = create_model()
 m.load_state_dict(seeded_state_dict(m.state_dict(), 7351))
 m = m.eval().to(dev)
 pipe = DescriptorPipeline(m, voxel_size=bench.VOXEL, radius=bench.RADIUS, num_stages=bench.NUM_STAGES, neighbor_limits=bench.LIMITS,
                           upsampling=False, raw_voxel=bench.VOXEL, overlap=False)
-dd = pipe.preprocess(pts, lens)
+dds = [pipe.preprocess(p, l) for p, l in inputs]
 torch.cuda.synchronize()
-for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 20):
-    pipe.encode(dd)
+for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 20):
+    pipe.encode(dds[i % len(dds)])
 torch.cuda.synchronize()

@@ -10,7 +10,8 @@ OUT=$ROOT/gpurun_out/prof
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o stats -- python "$ROOT/bench.py" --steps 50 --repeats 2 --no-cpu-baseline > "$OUT/stats_bench.log" 2>&1
-python "$ROOT/tools/rocprof_summary.py" "$(find /tmp/prof_s -name "*.db" | head -1)" > "$OUT/kernel_summary.md"
+python "$ROOT/tools/rocprof_summary.py" "$(find /tmp/prof_s -name "*.db" | head -1)" --bench-log "$OUT/stats_bench.log" \
+  --note "rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --repeats 2 --no-cpu-baseline (timed region + the clocked kernel-alone passes behind it)" > "$OUT/kernel_summary.md"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f -o fetch -- python "$ROOT/bench.py" --steps 25 --repeats 1 --no-cpu-baseline > "$OUT/fetch_bench.log" 2>&1
 cp $(find /tmp/prof_f -name "fetch_counter_collection.csv" | head -1) "$OUT/"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w -o write -- python "$ROOT/bench.py" --steps 25 --repeats 1 --no-cpu-baseline > "$OUT/write_bench.log" 2>&1
@@ -19,7 +20,8 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MO
   --kernel-trace --output-format csv -d /tmp/prof_m -o m -- python "$ROOT/tools/enc_profile.py" 3 > "$OUT/mfma_enc.log" 2>&1
 python "$ROOT/tools/pmc_mfma_summary.py" "$(find /tmp/prof_m -name "m_counter_collection.csv" | head -1)" > "$OUT/pmc_mfma_encoder.md"
 rocprofv3 --kernel-trace --stats -d /tmp/prof_e -o enc -- python "$ROOT/tools/enc_profile.py" 20 > "$OUT/enc_alone.log" 2>&1
-python "$ROOT/tools/rocprof_summary.py" "$(find /tmp/prof_e -name "*.db" | head -1)" > "$OUT/encoder_alone_kernel_summary.md"
+python "$ROOT/tools/rocprof_summary.py" "$(find /tmp/prof_e -name "*.db" | head -1)" \
+  --note "rocprofv3 --kernel-trace --stats -- python tools/enc_profile.py 20: 20 encoder passes over the bench batch on one stream, nothing else on the GPU (what roofline.achieved / frac / avg_launch_us of the bench line measure live)" > "$OUT/encoder_alone_kernel_summary.md"
 cd "$ROOT"
 python tools/pmc_summary.py "$OUT/fetch_counter_collection.csv" "$OUT/write_counter_collection.csv" "$OUT/pmc_traffic" > /dev/null
 tail -1 "$OUT/stats_bench.log" | cut -c1-300
