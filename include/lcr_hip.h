@@ -69,6 +69,12 @@ int lcr_grid_subsample(const float* xyz, const int64_t* len, int B, int64_t n_ca
 int lcr_grid_subsample_ex(const float* xyz, const int64_t* len, int B, int64_t n_cap, float voxel, int key_bits_hint,
                           float* out_xyz, int64_t* out_len, uint32_t* status,
                           void* ws, size_t ws_bytes, void* stream);
+/* Same on rows of `row_floats` (3 .. 64) floats whose first three are x, y, z — a KITTI velodyne scan f32[N,4] (x, y, z, intensity:
+ * data/Kitti/downsample_pcd.py:21; dataset_overlap_online.py:245 slices [:, :3] on the host) is consumed as it lies in memory; the
+ * output is f32[M,3]. */
+int lcr_grid_subsample_rows(const float* xyz, int row_floats, const int64_t* len, int B, int64_t n_cap, float voxel, int key_bits_hint,
+                            float* out_xyz, int64_t* out_len, uint32_t* status,
+                            void* ws, size_t ws_bytes, void* stream);
 /* HOST helper (no GPU): order[j] = insertion rank of the j-th element that libstdc++'s
  * std::unordered_map<size_t,...> visits after inserting the n distinct keys in the given order — the serial mirror of
  * the device kernel that fixes lcr_grid_subsample's output order (grid_subsampling_cpu.cpp:26,45-47). */
@@ -156,6 +162,11 @@ int lcr_precompute_layout(int64_t n0, int B, int num_stages, const int* limits, 
 int lcr_precompute_batch(const float* points0, const int64_t* lengths0, const LcrPrecomputeLayout* layout, float voxel_size,
                          float radius, float raw_voxel, int key_bits_hint, void* out, size_t out_bytes, void* ws, size_t ws_bytes,
                          int64_t* lengths_host, uint32_t* status_host, void* stream);
+/* raw-scan mode on rows of `raw_row_floats` floats (x, y, z first; 4 = KITTI velodyne [N,4] as loaded from a .bin / xyzi .npy file and
+ * uploaded unsliced): points0 is then f32[n_raw, raw_row_floats].  raw_row_floats = 3 is lcr_precompute_batch. */
+int lcr_precompute_batch_rows(const float* points0, int raw_row_floats, const int64_t* lengths0, const LcrPrecomputeLayout* layout,
+                              float voxel_size, float radius, float raw_voxel, int key_bits_hint, void* out, size_t out_bytes, void* ws,
+                              size_t ws_bytes, int64_t* lengths_host, uint32_t* status_host, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a-4 / a-5 / a-6  KPConv encoder building blocks (fp32).  Index tensors are [M,H] int32 or int64 (idx_is_64),

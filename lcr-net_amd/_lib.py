@@ -24,6 +24,7 @@ _SIGS = {
     "lcr_support_grid_build": (c_int, [c_vp, c_vp, c_int, c_i64, c_float, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "lcr_precompute_layout": (c_int, [c_i64, c_int, c_int, c_vp, c_int, c_i64, c_vp]),
     "lcr_precompute_batch": (c_int, [c_vp, c_vp, c_vp, c_float, c_float, c_float, c_int, c_vp, c_size_t, c_vp, c_size_t, c_vp, c_vp, c_vp]),
+    "lcr_precompute_batch_rows": (c_int, [c_vp, c_int, c_vp, c_vp, c_float, c_float, c_float, c_int, c_vp, c_size_t, c_vp, c_size_t, c_vp, c_vp, c_vp]),
     "lcr_radius_query_multi": (c_int, [c_vp, c_int, c_int, c_vp]),
     "lcr_radius_query": (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_i64, c_float, c_int, c_vp, c_vp, c_vp, c_vp]),
     "lcr_debug_spin": (c_int, [c_int, c_vp]),
@@ -34,6 +35,7 @@ _SIGS = {
     "lcr_grid_subsample_ws_bytes": (c_int, [c_i64, c_int, c_size_p]),
     "lcr_grid_subsample": (c_int, [c_vp, c_vp, c_int, c_i64, c_float, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "lcr_grid_subsample_ex": (c_int, [c_vp, c_vp, c_int, c_i64, c_float, c_int, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "lcr_grid_subsample_rows": (c_int, [c_vp, c_int, c_vp, c_int, c_i64, c_float, c_int, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "lcr_hashmap_order_host": (c_int, [c_vp, c_i64, c_vp]),
     "lcr_gemm_f32": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "lcr_gemm_f32_anorm": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_float, c_float, c_vp, c_int,

@@ -120,8 +120,9 @@ __device__ __forceinline__ float ord2f(uint32_t u) {
 // each cloud that intersects it (one, except for the B-1 chunks that straddle a boundary), reduces the rows in registers ->
 // shuffles -> LDS and issues 6 atomics.  (A per-row atomic fallback for the straddling chunks used to dominate the kernel:
 // same-address atomics serialise at ~0.4 us each.)  bb_* hold order-preserving encodings (f2ord).
+// rs = floats per input row (3: xyz; 4: KITTI velodyne x, y, z, intensity — the fourth column is never read)
 __device__ __forceinline__ void bbox_accumulate(const float* __restrict__ xyz, int64_t n, const int64_t* __restrict__ off, int B,
-                                                uint32_t (*bb_min)[3], uint32_t (*bb_max)[3]) {
+                                                uint32_t (*bb_min)[3], uint32_t (*bb_max)[3], int rs = 3) {
   __shared__ uint32_t s_mn[16][3], s_mx[16][3];
   const int64_t chunk = (n + gridDim.x - 1) / gridDim.x;
   const int64_t lo = static_cast<int64_t>(blockIdx.x) * chunk;
@@ -136,7 +137,7 @@ __device__ __forceinline__ void bbox_accumulate(const float* __restrict__ xyz, i
     for (int64_t i = r0 + threadIdx.x; i < r1; i += blockDim.x) {
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
-        const uint32_t u = f2ord(xyz[3 * i + d]);
+        const uint32_t u = f2ord(xyz[rs * i + d]);
         mn[d] = u < mn[d] ? u : mn[d];
         mx[d] = u > mx[d] ? u : mx[d];
       }

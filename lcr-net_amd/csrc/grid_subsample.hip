@@ -139,8 +139,8 @@ __global__ void k_gs_init(GsHeader* h, const int64_t* __restrict__ len, int B, i
   }
 }
 
-__global__ __launch_bounds__(256) void k_gs_bbox(GsHeader* h, const float* __restrict__ xyz) {
-  bbox_accumulate(xyz, h->rx.n, h->in_off, h->B, h->bb_min, h->bb_max);
+__global__ __launch_bounds__(256) void k_gs_bbox(GsHeader* h, const float* __restrict__ xyz, int rs) {
+  bbox_accumulate(xyz, h->rx.n, h->in_off, h->B, h->bb_min, h->bb_max, rs);
 }
 
 __device__ __forceinline__ int bits_of(uint64_t v) { return v ? 64 - __clzll(static_cast<long long>(v)) : 0; }
@@ -193,16 +193,16 @@ __global__ void k_gs_params(GsHeader* h, float voxel, float inv_voxel, int key_b
   h->rx.num_passes = radix_passes(total);
 }
 
-__global__ __launch_bounds__(256) void k_gs_keys(GsHeader* h, const float* __restrict__ xyz, float voxel, uint64_t* __restrict__ keyA,
+__global__ __launch_bounds__(256) void k_gs_keys(GsHeader* h, const float* __restrict__ xyz, int rs, float voxel, uint64_t* __restrict__ keyA,
                                                  uint32_t* __restrict__ valA, uint32_t* status) {
   const int B = h->B;
   const int64_t n = h->rx.n;
   const int kbits = h->kbits;
   for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
     const int b = cloud_of(h->in_off, B, i);
-    const uint64_t ix = f2u64(floorf(fdiv(fsub(xyz[3 * i + 0], h->org[b][0]), voxel)));   // :32
-    const uint64_t iy = f2u64(floorf(fdiv(fsub(xyz[3 * i + 1], h->org[b][1]), voxel)));   // :33
-    const uint64_t iz = f2u64(floorf(fdiv(fsub(xyz[3 * i + 2], h->org[b][2]), voxel)));   // :34
+    const uint64_t ix = f2u64(floorf(fdiv(fsub(xyz[rs * i + 0], h->org[b][0]), voxel)));   // :32
+    const uint64_t iy = f2u64(floorf(fdiv(fsub(xyz[rs * i + 1], h->org[b][1]), voxel)));   // :33
+    const uint64_t iz = f2u64(floorf(fdiv(fsub(xyz[rs * i + 2], h->org[b][2]), voxel)));   // :34
     uint64_t key = ix + h->NX[b] * iy + h->NX[b] * h->NY[b] * iz;                          // :35 (wraps mod 2^64 like size_t)
     const uint64_t top = h->top[b];
     if (top && key >= top) {                                                               // below the origin on some axis: escape range
@@ -260,7 +260,7 @@ __device__ __forceinline__ void gs_offsets(GsHeader* h, const int32_t* __restric
 }
 
 // one lane per voxel run: in-order fp32 sums (.h:17-20), barycentre = sum * float(1.0 / count) (:46)
-__global__ __launch_bounds__(256) void k_gs_reduce(GsHeader* h, const float* __restrict__ xyz, const uint64_t* __restrict__ kA,
+__global__ __launch_bounds__(256) void k_gs_reduce(GsHeader* h, const float* __restrict__ xyz, int rs, const uint64_t* __restrict__ kA,
                                                    const uint64_t* __restrict__ kB, const uint32_t* __restrict__ vA,
                                                    const uint32_t* __restrict__ vB, const int32_t* __restrict__ head_scan,
                                                    const int32_t* __restrict__ seg_start, float* __restrict__ bary,
@@ -286,9 +286,9 @@ __global__ __launch_bounds__(256) void k_gs_reduce(GsHeader* h, const float* __r
       float px[8], py[8], pz[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        px[u] = xyz[3 * static_cast<int64_t>(r[u]) + 0];
-        py[u] = xyz[3 * static_cast<int64_t>(r[u]) + 1];
-        pz[u] = xyz[3 * static_cast<int64_t>(r[u]) + 2];
+        px[u] = xyz[rs * static_cast<int64_t>(r[u]) + 0];
+        py[u] = xyz[rs * static_cast<int64_t>(r[u]) + 1];
+        pz[u] = xyz[rs * static_cast<int64_t>(r[u]) + 2];
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -715,8 +715,23 @@ extern "C" int lcr_grid_subsample_ws_bytes(int64_t n_cap, int B, size_t* bytes) 
   return LCR_OK;
 }
 
+extern "C" int lcr_grid_subsample_rows(const float* xyz, int row_floats, const int64_t* len, int B, int64_t n_cap, float voxel, int key_bits_hint,
+                                       float* out_xyz, int64_t* out_len, uint32_t* status, void* ws, size_t ws_bytes, void* stream);
 extern "C" int lcr_grid_subsample_ex(const float* xyz, const int64_t* len, int B, int64_t n_cap, float voxel, int key_bits_hint,
                                      float* out_xyz, int64_t* out_len, uint32_t* status, void* ws, size_t ws_bytes, void* stream) {
+  return lcr_grid_subsample_rows(xyz, 3, len, B, n_cap, voxel, key_bits_hint, out_xyz, out_len, status, ws, ws_bytes, stream);
+}
+
+// The same on rows of `row_floats` >= 3 floats whose first three are x, y, z: a KITTI velodyne scan (f32 [N, 4]: x, y, z, intensity;
+// data/Kitti/downsample_pcd.py:21, dataset_overlap_online.py:245 takes [:, :3] on the host) is consumed as it lies in memory — the three
+// kernels that touch the input (bounding box, voxel keys, in-order sums) step over the unused columns; the output is f32 [M, 3].
+extern "C" int lcr_grid_subsample_rows(const float* xyz, int row_floats, const int64_t* len, int B, int64_t n_cap, float voxel, int key_bits_hint,
+                                       float* out_xyz, int64_t* out_len, uint32_t* status, void* ws, size_t ws_bytes, void* stream) {
+  if (row_floats < 3 || row_floats > 64) {
+    set_error("lcr_grid_subsample: rows of %d floats (3 .. 64: x, y, z first)", row_floats);
+    return LCR_EARG;
+  }
+  const int rs = row_floats;
   if (!len || !out_len || !status || !ws || B < 1 || B > GS_MAX_B || n_cap < 0 || !(voxel > 0.f) || key_bits_hint < 0 ||
       key_bits_hint > 64) {
     set_error("lcr_grid_subsample: bad argument");
@@ -740,9 +755,9 @@ extern "C" int lcr_grid_subsample_ex(const float* xyz, const int64_t* len, int B
     return check_launch("lcr_grid_subsample");
   }
   // one workgroup per CU at most: every workgroup ends with 6 atomics on its cloud's box, and same-address atomics serialise
-  hipLaunchKernelGGL(k_gs_bbox, dim3(n_cap > 0 ? min(div_up(n_cap, 1024), 512) : 1), dim3(256), 0, st, L.hdr, xyz);
+  hipLaunchKernelGGL(k_gs_bbox, dim3(n_cap > 0 ? min(div_up(n_cap, 1024), 512) : 1), dim3(256), 0, st, L.hdr, xyz, rs);
   hipLaunchKernelGGL(k_gs_params, dim3(1), dim3(64), 0, st, L.hdr, voxel, inv_voxel, key_bits_hint, status);
-  hipLaunchKernelGGL(k_gs_keys, dim3(nblk), dim3(256), 0, st, L.hdr, xyz, voxel, L.keyA, L.valA, status);
+  hipLaunchKernelGGL(k_gs_keys, dim3(nblk), dim3(256), 0, st, L.hdr, xyz, rs, voxel, L.keyA, L.valA, status);
   const int max_passes = radix_passes(key_bits_hint > 0 ? key_bits_hint : 64);
   int rc = radix_sort_pairs(&L.hdr->rx, L.keyA, L.keyB, L.valA, L.valB, n_cap, max_passes, L.hist, L.scan_ws, st);
   if (rc) return rc;
@@ -750,7 +765,7 @@ extern "C" int lcr_grid_subsample_ex(const float* xyz, const int64_t* len, int B
   rc = exclusive_scan_i32(L.head, L.head, n_cap + 1, nullptr, L.scan_ws, st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_gs_seg_starts, dim3(nblk), dim3(256), 0, st, L.hdr, L.head, L.seg_start);
-  hipLaunchKernelGGL(k_gs_reduce, dim3(nblk), dim3(256), 0, st, L.hdr, xyz, L.keyA, L.keyB, L.valA, L.valB, L.head, L.seg_start, L.bary,
+  hipLaunchKernelGGL(k_gs_reduce, dim3(nblk), dim3(256), 0, st, L.hdr, xyz, rs, L.keyA, L.keyB, L.valA, L.valB, L.head, L.seg_start, L.bary,
                      L.seg_key, L.seg_first, L.first, out_len);
   rc = exclusive_scan_i32(L.first, L.first, n_cap + 1, nullptr, L.scan_ws, st);
   if (rc) return rc;

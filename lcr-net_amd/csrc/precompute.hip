@@ -178,6 +178,17 @@ extern "C" int lcr_precompute_layout(int64_t n0, int B, int num_stages, const in
 extern "C" int lcr_precompute_batch(const float* points0, const int64_t* lengths0, const LcrPrecomputeLayout* L, float voxel_size,
                                     float radius, float raw_voxel, int key_bits_hint, void* out, size_t out_bytes, void* ws, size_t ws_bytes,
                                     int64_t* lengths_host, uint32_t* status_host, void* stream) {
+  return lcr_precompute_batch_rows(points0, 3, lengths0, L, voxel_size, radius, raw_voxel, key_bits_hint, out, out_bytes, ws, ws_bytes, lengths_host,
+                                   status_host, stream);
+}
+
+extern "C" int lcr_precompute_batch_rows(const float* points0, int raw_row_floats, const int64_t* lengths0, const LcrPrecomputeLayout* L,
+                                         float voxel_size, float radius, float raw_voxel, int key_bits_hint, void* out, size_t out_bytes, void* ws,
+                                         size_t ws_bytes, int64_t* lengths_host, uint32_t* status_host, void* stream) {
+  if (L && raw_row_floats != 3 && !(L->n_raw > 0)) {
+    set_error("lcr_precompute_batch: rows of %d floats need raw mode (stage-0 points are then produced as [n,3] inside the call)", raw_row_floats);
+    return LCR_EARG;
+  }
   if (!points0 || !lengths0 || !L || !out || !ws || !lengths_host || !status_host || !(voxel_size > 0.f) || !(radius > 0.f)) {
     set_error("lcr_precompute_batch: bad argument");
     return LCR_EARG;
@@ -226,8 +237,8 @@ extern "C" int lcr_precompute_batch(const float* points0, const int64_t* lengths
     ~PoolLoan() { scan_state_pool(nullptr, 0); }
   } loan(W.scan_pool, PRE_SCAN_POOL);
   if (raw) {
-    rc = TURN(lcr_grid_subsample_ex(points0, lengths0, B, L->n_raw, raw_voxel, key_bits_hint, const_cast<float*>(pts[0]),
-                                    const_cast<int64_t*>(lens[0]), W.status, W.raw_ws, W.raw_bytes, main));
+    rc = TURN(lcr_grid_subsample_rows(points0, raw_row_floats, lengths0, B, L->n_raw, raw_voxel, key_bits_hint, const_cast<float*>(pts[0]),
+                                      const_cast<int64_t*>(lens[0]), W.status, W.raw_ws, W.raw_bytes, main));
     if (rc) return rc;
   }
   float v = voxel_size, r = radius;

@@ -133,6 +133,9 @@ def precompute_batch_arena(points, lengths, num_stages, voxel_size, radius, neig
     B, S = lengths.numel(), num_stages
     raw = raw_voxel is not None
     n_raw = points.shape[0] if raw else 0
+    row_floats = int(points.shape[1]) if points.dim() == 2 else 3      # raw mode takes [N, C >= 3] rows (x, y, z first; 4 = KITTI xyzi)
+    if points.dim() != 2 or row_floats < 3 or (row_floats != 3 and not raw):
+        raise RuntimeError("points must be [N,3] (or [N, C >= 3] raw scans with raw_voxel set)")
     n0 = (int(capacity) if capacity else max(n_raw // 4, min(n_raw, 65536))) if raw else points.shape[0]
     lay = _layout_for(n0, B, S, neighbor_limits, upsampling, n_raw)
     stream = _lib.stream_ptr(dev)
@@ -140,9 +143,9 @@ def precompute_batch_arena(points, lengths, num_stages, voxel_size, radius, neig
     ws = _workspace(lay.ws_bytes, dev, stream)
     lens_host = (ctypes.c_int64 * (S * B))()
     status = ctypes.c_uint32(0)
-    _lib.check(_lib.lib().lcr_precompute_batch(_lib.ptr(points), _lib.ptr(lengths), ctypes.addressof(lay), float(voxel_size), float(radius),
-                                               float(raw_voxel) if raw else 0.0, int(key_bits_hint), _lib.ptr(out), out.numel(), _lib.ptr(ws),
-                                               ws.numel(), ctypes.addressof(lens_host), ctypes.addressof(status), stream),
+    _lib.check(_lib.lib().lcr_precompute_batch_rows(_lib.ptr(points), row_floats, _lib.ptr(lengths), ctypes.addressof(lay), float(voxel_size),
+                                                    float(radius), float(raw_voxel) if raw else 0.0, int(key_bits_hint), _lib.ptr(out), out.numel(),
+                                                    _lib.ptr(ws), ws.numel(), ctypes.addressof(lens_host), ctypes.addressof(status), stream),
                "lcr_precompute_batch")
     st = status.value
     if st & STATUS_KEY_OVERFLOW and key_bits_hint:

@@ -12,6 +12,8 @@ from ... import _lib
 
 def grid_subsample_device(points, lengths, voxel_size, key_bits_hint=0):
     """Sync-free form: returns (out_xyz [N,3] capacity buffer, out_len i64[B] on device, status).
+    points: f32 [N, C], C >= 3 with x, y, z first — a KITTI velodyne scan [N,4] (x, y, z, intensity) is consumed unsliced
+    (the reference slices `[:, :3]` on the host, dataset_overlap_online.py:245); the output is always [M,3].
     key_bits_hint > 0 promises voxel-key bits + cloud-id bits <= hint (fewer radix passes); a broken promise sets
     LCR_STATUS_KEY_OVERFLOW in `status` and the caller must retry with 0."""
     _lib.require_cuda(points)
@@ -33,9 +35,11 @@ def grid_subsample_device(points, lengths, voxel_size, key_bits_hint=0):
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     out = torch.empty((max(n, 1), 3), dtype=torch.float32, device=dev)
     out_len = torch.empty((B,), dtype=torch.int64, device=dev)
-    _lib.check(L.lcr_grid_subsample_ex(_lib.ptr(points), _lib.ptr(lengths), B, n, float(voxel_size), int(key_bits_hint),
-                                       _lib.ptr(out), _lib.ptr(out_len), _lib.ptr(status), _lib.ptr(ws), ws.numel(),
-                                       _lib.stream_ptr(dev)), "lcr_grid_subsample")
+    if points.dim() != 2 or points.shape[1] < 3:
+        raise RuntimeError("points must be [N, C] with C >= 3 (x, y, z first)")
+    _lib.check(L.lcr_grid_subsample_rows(_lib.ptr(points), int(points.shape[1]), _lib.ptr(lengths), B, n, float(voxel_size), int(key_bits_hint),
+                                         _lib.ptr(out), _lib.ptr(out_len), _lib.ptr(status), _lib.ptr(ws), ws.numel(),
+                                         _lib.stream_ptr(dev)), "lcr_grid_subsample")
     return out, out_len, status
 
 

@@ -141,6 +141,72 @@ def distinct_queue_streams(device, n, priority=0, pool=10):
     return chosen
 
 
+class HostIngest:
+    """Host -> device leg of the pipeline (the reference: `_load_point_cloud(...)[:, :3]` in a DataLoader worker,
+    dataset_overlap_online.py:245-253, then `to_cuda(data_dict)`, utils/engine/single_tester.py:59).
+
+    A batch arrives as HOST tensors — points f32 [sum N, C] with C = 3 or 4 (a KITTI velodyne scan is [N,4]: x, y, z, intensity; it is
+    uploaded unsliced and the voxel-key kernels step over the fourth column) and lengths i64 [B].  `upload` stages it in pinned memory
+    (skipped when the caller's tensor is pinned already), copies it to a device slot on a dedicated COPY stream (SDMA: no CU time) and
+    returns device views + the event the consumer's stream has to wait for.  `slots` batches can be in flight: a slot is taken by
+    `upload` and handed back by `release` once the pre-processing call that read it has returned (raw mode: stage-0 points are produced
+    inside the call, nothing references the raw rows afterwards)."""
+
+    def __init__(self, device, slots):
+        import queue
+        self.device = device
+        self.stream = torch.cuda.Stream(device)
+        self.free = queue.Queue()
+        for i in range(slots):
+            self.free.put(i)
+        self.pin = [None] * slots            # pinned staging (points as a flat f32 buffer, lengths)
+        self.dev = [None] * slots
+        self.pin_len = [None] * slots
+        self.dev_len = [None] * slots
+        self.uploaded_bytes = 0
+
+    def _room(self, slot, numel, B):
+        if self.pin[slot] is None or self.pin[slot].numel() < numel:
+            cap = int(numel * 1.25) + 1024
+            self.pin[slot] = torch.empty(cap, dtype=torch.float32).pin_memory()
+            self.dev[slot] = torch.empty(cap, dtype=torch.float32, device=self.device)
+        if self.pin_len[slot] is None or self.pin_len[slot].numel() < B:
+            self.pin_len[slot] = torch.empty(max(B, 64), dtype=torch.int64).pin_memory()
+            self.dev_len[slot] = torch.empty(max(B, 64), dtype=torch.int64, device=self.device)
+
+    def upload(self, points, lengths, stop=None):
+        """-> (points_dev [N,C], lengths_dev [B], ready event, slot) or None if `stop` was set while waiting for a slot."""
+        import queue
+        if points.dtype != torch.float32 or points.dim() != 2 or points.shape[1] < 3 or not points.is_contiguous():
+            raise RuntimeError("host scans must be a contiguous float32 [N, C >= 3] tensor")
+        while True:
+            try:
+                slot = self.free.get(timeout=0.05)
+                break
+            except queue.Empty:
+                if stop is not None and stop.is_set():
+                    return None
+        n, c, B = points.shape[0], points.shape[1], lengths.numel()
+        self._room(slot, n * c, B)
+        src = points.reshape(-1)
+        if not points.is_pinned():
+            self.pin[slot][:n * c].copy_(src)                 # pageable -> pinned (host memcpy in this thread)
+            src = self.pin[slot][:n * c]
+        self.pin_len[slot][:B].copy_(lengths.to(torch.int64).reshape(-1))
+        with torch.cuda.stream(self.stream):
+            d = self.dev[slot][:n * c]
+            d.copy_(src, non_blocking=True)
+            dl = self.dev_len[slot][:B]
+            dl.copy_(self.pin_len[slot][:B], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.uploaded_bytes += 4 * n * c
+        return d.view(n, c), dl, ev, slot
+
+    def release(self, slot):
+        self.free.put(slot)
+
+
 class DescriptorPipeline:
     def __init__(self, model, voxel_size=0.3, radius=1.275, num_stages=4, neighbor_limits=(64, 65, 74, 80), upsampling=False,
                  raw_voxel=None, overlap=True, producer_thread=True, depth=2, pre_workers=2):
@@ -243,6 +309,8 @@ class DescriptorPipeline:
             raise RuntimeError("DescriptorPipeline is closed")      # its streams were given back: threaded mode would start no producer and wait forever
         if not self.overlap:
             for pts, lens in batches:
+                if not pts.is_cuda:                      # host batch, no pipelining: plain upload on the current stream
+                    pts, lens = pts.to(self.device), lens.to(self.device)
                 yield self.encode(self.preprocess(pts, lens))
             return
         if self.producer_thread:
@@ -253,6 +321,8 @@ class DescriptorPipeline:
         pending = None            # (data dict, ready event) of the batch whose encoder has not been launched yet
         first = True
         for pts, lens in batches:
+            if not pts.is_cuda:
+                pts, lens = pts.to(self.device), lens.to(self.device)
             if pending is not None:
                 dd, ready = pending
                 main.wait_event(ready)
@@ -292,9 +362,50 @@ class DescriptorPipeline:
             st.wait_stream(main)
         out = queue.Queue()
         slots = threading.Semaphore(self.depth + W - 1)      # batches pre-processed but not yet consumed
-        it = enumerate(iter(batches))
-        it_lock = threading.Lock()
         stop = threading.Event()                             # set when the consumer leaves (exhaustion, break, exception)
+        batches = iter(batches)
+        first = next(batches, None)
+        feeder, ingest = None, None
+        if first is not None and not first[0].is_cuda:
+            # HOST batches: a feeder thread uploads them on the copy stream, up to `depth + W` batches ahead of the pre-processing
+            # workers, which then only wait for an event on their own stream
+            if self.raw_voxel is None and first[0].shape[1] != 3:
+                raise RuntimeError("host scans with more than 3 columns need raw_voxel (the raw-scan ingest produces the [n,3] stage-0 points)")
+            ingest = self._ingest = getattr(self, "_ingest", None) or HostIngest(dev, self.depth + W + 1)
+            fed = queue.Queue()
+
+            def feed():
+                try:
+                    torch.cuda.set_device(dev)
+                    item = first
+                    while item is not None and not stop.is_set():
+                        up = ingest.upload(item[0], item[1], stop)
+                        if up is None:
+                            break
+                        fed.put(up)
+                        item = next(batches, None)
+                    fed.put(None)
+                except BaseException as e:                   # surfaces in a worker, from there in the consumer
+                    fed.put(e)
+
+            def fed_items():
+                while True:
+                    up = fed.get()
+                    if up is None:
+                        fed.put(None)                        # every worker sees the end marker
+                        return
+                    if isinstance(up, BaseException):
+                        fed.put(up)
+                        raise up
+                    yield up
+
+            feeder = threading.Thread(target=feed, daemon=True)
+            feeder.start()
+            it = enumerate(fed_items())
+        else:
+            import itertools
+            it = enumerate(itertools.chain([first] if first is not None else [], batches))
+        it_lock = threading.Lock()
 
         def producer(st):
             try:
@@ -311,8 +422,16 @@ class DescriptorPipeline:
                         if nxt is None:
                             slots.release()
                             break
-                        k, (pts, lens) = nxt
-                        dd = self.preprocess_arena(pts, lens)
+                        if ingest is not None:
+                            k, (pts, lens, up_ev, up_slot) = nxt
+                            st.wait_event(up_ev)              # the H2D copy of this batch (copy stream)
+                            try:
+                                dd = self.preprocess_arena(pts, lens)     # returns after synchronising `st`: the slot is dead
+                            finally:
+                                ingest.release(up_slot)
+                        else:
+                            k, (pts, lens) = nxt
+                            dd = self.preprocess_arena(pts, lens)
                         self.stats["pre_wait_s"] += t1 - t0           # blocked: the encoder side is behind
                         self.stats["pre_busy_s"] += time.perf_counter() - t1
                         self.stats["batches"] += 1
@@ -337,6 +456,9 @@ class DescriptorPipeline:
                 slots.release()
             for th in threads:
                 th.join()
+            if feeder is not None:
+                feeder.join()
+                ingest.stream.synchronize()
             for st in streams:
                 st.synchronize()
 

@@ -189,3 +189,74 @@ def test_pipeline_fuzz_ragged_batches_are_bit_identical_to_sequential():
             assert len(got) == len(seq)
             for a, b in zip(seq, got):
                 assert a.shape == b.shape and torch.equal(a, b)
+
+
+def _ingest_model():
+    from lcrnet_amd.model_family import create_model
+    from lcrnet_amd.weights import seeded_state_dict
+    m = create_model().eval()
+    m.load_state_dict(seeded_state_dict(m.state_dict(), 7351))
+    return m.cuda()
+
+
+def test_strided_rows_subsample_equals_sliced_rows():
+    """a-1 on KITTI velodyne rows f32[N,4] (x, y, z, intensity) consumed unsliced (lcr_grid_subsample_rows) == the same op on the
+    host-sliced [:, :3] copy (dataset_overlap_online.py:245) == the oracle, bit for bit, order included; 3 ragged clouds incl. an empty one."""
+    from oracle import ops as oracle_ops
+    from lcrnet_amd.modules.ops import grid_subsample
+    rng = np.random.default_rng(3)
+    clouds = [load_scan("003854"), np.zeros((0, 3), np.float32), load_scan("000958")[:7001]]
+    xyz = np.concatenate(clouds).astype(np.float32)
+    for cols in (4, 7):
+        rows = np.concatenate([xyz, rng.standard_normal((len(xyz), cols - 3)).astype(np.float32) * 1e6], axis=1)   # junk in the unused columns
+        lens = np.array([len(c) for c in clouds], dtype=np.int64)
+        for voxel in (0.3, 0.6):
+            p4, l4 = grid_subsample(torch.from_numpy(rows).cuda(), torch.from_numpy(lens).cuda(), voxel)
+            p3, l3 = grid_subsample(torch.from_numpy(xyz).cuda(), torch.from_numpy(lens).cuda(), voxel)
+            wp, wl = oracle_ops.grid_subsample(xyz, lens, voxel)
+            assert p4.shape[1] == 3 and l4.tolist() == l3.tolist() == wl.tolist()
+            assert torch.equal(p4, p3) and np.array_equal(p4.cpu().numpy().view(np.uint32), wp.view(np.uint32))
+    with pytest.raises(RuntimeError):
+        grid_subsample(torch.zeros(10, 2).cuda(), torch.tensor([10]).cuda(), 0.3)
+
+
+def test_host_xyzi_batches_give_the_resident_descriptors_bit_for_bit():
+    """Ingest leg: host batches f32[N,4] (pinned AND pageable) uploaded on the copy stream inside the threaded two-encoder pipeline
+    -> the descriptors of the resident f32[N,3] batches, bit for bit; every slot of the upload ring is reused several times."""
+    from lcrnet_amd.pipeline import DescriptorPipeline
+    m = _ingest_model()
+    rng = np.random.default_rng(11)
+    names = [["003854", "000958"], ["004481"], ["000026", "000560", "003528"], ["003854"], ["000958", "004481"]]
+    dev_batches, host_batches = [], []
+    for k, grp in enumerate(names * 3):                   # 15 batches through a ring of depth + W + 1 = 5 slots
+        scans = [load_scan(n) + np.float32(0.01 * (k // len(names))) for n in grp]       # repeats of a group are different clouds
+        xyz = np.concatenate(scans).astype(np.float32)
+        lens = torch.tensor([len(s) for s in scans], dtype=torch.int64)
+        rows = torch.from_numpy(np.concatenate([xyz, rng.random((len(xyz), 1), dtype=np.float32)], axis=1))
+        dev_batches.append((torch.from_numpy(xyz).cuda(), lens.cuda()))
+        host_batches.append((rows.pin_memory() if k % 2 == 0 else rows, lens))
+    limits = [74, 68, 70, 67]
+    with DescriptorPipeline(m, neighbor_limits=limits, raw_voxel=0.3, overlap=True) as pipe:
+        pipe.enable_dual_encoder()
+        want = [d.clone() for d in pipe.run(dev_batches)]
+        for rep in range(2):
+            got = [d.clone() for d in pipe.run(host_batches)]
+            torch.cuda.synchronize()
+            assert len(got) == len(want)
+            for a, b in zip(want, got):
+                assert a.shape == b.shape and torch.equal(a, b)
+        assert pipe._ingest.uploaded_bytes == 2 * sum(r.numel() * 4 for r, _ in host_batches)
+        # a consumer that leaves early must not leave the feeder / workers blocked on ring slots
+        it = pipe.run(host_batches)
+        first = next(it).clone()
+        it.close()
+        assert torch.equal(first, want[0])
+        again = [d.clone() for d in pipe.run(host_batches[:3])]
+        assert all(torch.equal(a, b) for a, b in zip(again, want[:3]))
+    # un-pipelined path takes host batches too
+    seq = [d.clone() for d in DescriptorPipeline(m, neighbor_limits=limits, raw_voxel=0.3, overlap=False).run(host_batches[:2])]
+    for a, b in zip(seq, want[:2]):
+        assert (a - b).abs().max().item() < 1e-6
+    # four columns without the raw-scan step: stage-0 points must be [n,3]
+    with pytest.raises(RuntimeError):
+        list(DescriptorPipeline(m, neighbor_limits=limits, overlap=True).run(host_batches[:1]))
