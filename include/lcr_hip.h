@@ -181,6 +181,13 @@ int lcr_precompute_batch_rows(const float* points0, int raw_row_floats, const in
 int lcr_gemm_f32(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB,
                  const float* bias, const float* rowdiv, const int64_t* seg_len, int S, int groups, double* stats,
                  void* stream);
+/* The K-deep contractions on the bf16 matrix cores with fp32-faithful operands: an fp32 number is exactly the sum of three bf16 numbers;
+ * lcr_split_bf16x3 writes those terms of a constant operand (weights [N,K]) as planes u16[3][N*K] once, lcr_gemm_f32_bsplit computes
+ * C = A[M,K] . B[N,K]^T with A split on the fly and six of the nine cross products (the dropped ones are <= 2^-24 of a product), fp32
+ * accumulation, same epilogue as lcr_gemm_f32.  K % 32 == 0.  Not bit-identical to lcr_gemm_f32 (other rounding points). */
+int lcr_split_bf16x3(const float* w, int64_t n, uint16_t* planes, void* stream);
+int lcr_gemm_f32_bsplit(const float* A, const uint16_t* Bs, float* C, int64_t M, int N, int K, const float* bias, const float* rowdiv,
+                        const int64_t* seg_len, int S, int groups, double* stats, void* stream);
 /* C = LeakyReLU(GroupNorm(A)) · B^T (+ bias, + statistics of C as above), A being the RAW [M,K] output of the layer whose sums are
  * a_stats[LCR_GN_REPLICAS,S,a_groups,2]: the normalisation happens while A's tiles are staged, the normalised tensor never
  * exists in memory.  Replaces norm_conv + leaky_relu + unary2.mlp of ResidualBlock.forward (modules/kpconv/modules.py:215-217).

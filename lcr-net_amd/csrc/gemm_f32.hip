@@ -828,6 +828,136 @@ static int launch_gemm_deep(const float* A, const float* B, float* C, int64_t M,
   return check_launch("lcr_gemm_f32");
 }
 
+// ---- split-bf16 form of the K-deep contractions: fp32 operands as three bf16 terms, six cross products on the bf16 matrix cores ----
+// The K-deep fp32 form above is bound by the matrix pipe (mfma_busy 0.82) on an instruction that runs at 1/16 of the bf16 rate
+// (v_mfma_f32_32x32x2_f32: 64 cycles for 4 096 flop; v_mfma_f32_32x32x16_bf16: 32 cycles for 32 768).  An fp32 number is EXACTLY the sum
+// of three bf16 numbers (8 + 8 + 8 significand bits: h1 = rn(x), h2 = rn(x - h1), h3 = rn(x - h1 - h2); both subtractions are exact in
+// fp32), so a·b = Σ_{i,j} a_i b_j over nine exact bf16 x bf16 products.  Kept: the six with i + j <= 4 (a1b1; a1b2, a2b1; a1b3, a2b2,
+// a3b1); dropped: a2b3, a3b2 (each <= 2^-24 |ab|) and a3b3 (2^-32): a product is carried to <= 2^-23 relative, accumulation in fp32 inside the
+// MFMA — six K=16 instructions (192 cycles) replace eight fp32 ones (512) per 32 x 32 x 16 block.
+//   * B (weights, constant) arrives pre-split: three bf16 planes [3][N][K] made once per weight by lcr_split_bf16x3;
+//   * A (activations) is split ONCE PER WORKGROUP on its way from registers to LDS (8 values per thread and K-step: 44 VALU), not per
+//     wavefront at the fragment read; planes are row-major bf16 tiles with 80-byte rows (16-B fragment reads of 16 rows hit 16 bank groups);
+//   * register-staged double buffering: tile t+1 is in flight in registers while tile t feeds the matrix cores from LDS.
+// Results are NOT bit-identical to the fp32 form (different rounding points); tests/test_gemm_split_gpu.py holds both against fp64.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {           // v_cvt_pk_bf16_f32 (round to nearest even): a -> low half
+  f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+// two fp32 values -> their three bf16 terms (packed pairs)
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& h1, uint32_t& h2, uint32_t& h3) {
+  h1 = pk_bf16(x0, x1);
+  const float r0 = fsub(x0, __uint_as_float(h1 << 16)), r1 = fsub(x1, __uint_as_float(h1 & 0xffff0000u));     // exact
+  h2 = pk_bf16(r0, r1);
+  const float s0 = fsub(r0, __uint_as_float(h2 << 16)), s1 = fsub(r1, __uint_as_float(h2 & 0xffff0000u));     // exact
+  h3 = pk_bf16(s0, s1);
+}
+
+__global__ __launch_bounds__(256) void k_split_bf16x3(const float* __restrict__ w, int64_t n, uint16_t* __restrict__ planes) {
+  for (int64_t i = (blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x) * 2; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x * 2) {
+    const float x0 = w[i], x1 = i + 1 < n ? w[i + 1] : 0.f;
+    uint32_t h1, h2, h3;
+    split2(x0, x1, h1, h2, h3);
+    planes[i] = static_cast<uint16_t>(h1), planes[n + i] = static_cast<uint16_t>(h2), planes[2 * n + i] = static_cast<uint16_t>(h3);
+    if (i + 1 < n) planes[i + 1] = static_cast<uint16_t>(h1 >> 16), planes[n + i + 1] = static_cast<uint16_t>(h2 >> 16), planes[2 * n + i + 1] = static_cast<uint16_t>(h3 >> 16);
+  }
+}
+
+constexpr int SP_LD = 80;            // bytes per LDS row of a bf16 plane tile (32 k = 64 B + 16 B pad: 16-B reads of rows r .. r+15 -> bank groups 5r mod 16)
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(GM_T, 4) void k_gemm_f32_bsplit(const float* __restrict__ A, const uint16_t* __restrict__ Bs, float* __restrict__ C,
+                                                             int64_t M, int N, int K, GemmEpilogue ep) {
+  static_assert(WM * WN == 4 && BM == 32 * WM && BN == 32 * WN && BM == 64 && BN == 64, "64 x 64 tile, one 32 x 32 accumulator per wavefront");
+  __shared__ __attribute__((aligned(16))) char sA[3][BM * SP_LD];
+  __shared__ __attribute__((aligned(16))) char sB[3][BN * SP_LD];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = w / WN, wn = w % WN;
+  const int ntn = (N + BN - 1) / BN;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;    // XCD-aware tile order, as in k_gemm_f32
+  const int64_t m_tile = static_cast<int64_t>(slot / ntn) * 8 + xcd;
+  const int64_t m0 = m_tile * BM;
+  const int n0 = (slot % ntn) * BN;
+  if (m0 >= M) return;
+  // staging: thread -> (row, chunk of 8 consecutive k) of the A tile (fp32) and of each B plane tile (bf16)
+  const int srow = threadIdx.x >> 2, skc = threadIdx.x & 3;
+  int64_t ga = m0 + srow;
+  ga = ga < M ? ga : M - 1;                                  // duplicate rows only feed outputs that are never stored
+  int gb = n0 + srow;
+  gb = gb < N ? gb : N - 1;
+  const float* ap = A + ga * K + skc * 8;
+  const int64_t plane = static_cast<int64_t>(N) * K;
+  const uint16_t* bp = Bs + static_cast<int64_t>(gb) * K + skc * 8;
+  const int soff = srow * SP_LD + skc * 16;
+  // fragments: lane (l & 31) owns row wm*32 + (l & 31) of A (wn*32 + .. of B); half l >> 5 the k range [8 half, 8 half + 8) of a K=16 block
+  const int fa = (wm * 32 + (lane & 31)) * SP_LD + (lane >> 5) * 16, fb = (wn * 32 + (lane & 31)) * SP_LD + (lane >> 5) * 16;
+  floatx16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int nk = K / GM_BK;
+  float4 ra0 = ld4(ap), ra1 = ld4(ap + 4);
+  uint4 rb0 = *reinterpret_cast<const uint4*>(bp), rb1 = *reinterpret_cast<const uint4*>(bp + plane), rb2 = *reinterpret_cast<const uint4*>(bp + 2 * plane);
+  float bias_v[1];
+  {
+    const int col = n0 + wn * 32 + (lane & 31);
+    bias_v[0] = (ep.bias && col < N) ? ep.bias[col] : 0.f;
+  }
+  int blk_first = 0;
+  int64_t blk_seg_start = 0, blk_seg_end = 0;
+  if (ep.stats != nullptr) {
+    blk_seg_end = ep.seg_len[0];
+    while (blk_first + 1 < ep.S && m0 >= blk_seg_end) {
+      ++blk_first;
+      blk_seg_start = blk_seg_end;
+      blk_seg_end += ep.seg_len[blk_first];
+    }
+  }
+  for (int t = 0; t < nk; ++t) {
+    {                                                          // tile t: registers -> (split) -> LDS
+      uint4 p1, p2, p3;
+      split2(ra0.x, ra0.y, p1.x, p2.x, p3.x);
+      split2(ra0.z, ra0.w, p1.y, p2.y, p3.y);
+      split2(ra1.x, ra1.y, p1.z, p2.z, p3.z);
+      split2(ra1.z, ra1.w, p1.w, p2.w, p3.w);
+      *reinterpret_cast<uint4*>(sA[0] + soff) = p1;
+      *reinterpret_cast<uint4*>(sA[1] + soff) = p2;
+      *reinterpret_cast<uint4*>(sA[2] + soff) = p3;
+      *reinterpret_cast<uint4*>(sB[0] + soff) = rb0;
+      *reinterpret_cast<uint4*>(sB[1] + soff) = rb1;
+      *reinterpret_cast<uint4*>(sB[2] + soff) = rb2;
+    }
+    __syncthreads();
+    if (t + 1 < nk) {                                          // tile t+1 on its way while tile t is multiplied
+      ap += GM_BK;
+      bp += GM_BK;
+      ra0 = ld4(ap), ra1 = ld4(ap + 4);
+      rb0 = *reinterpret_cast<const uint4*>(bp), rb1 = *reinterpret_cast<const uint4*>(bp + plane), rb2 = *reinterpret_cast<const uint4*>(bp + 2 * plane);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8_t a[3], b[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        a[p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sA[p] + fa + kk * 32));
+        b[p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sB[p] + fb + kk * 32));
+      }
+      // smallest terms first (a rounding of the running sum then sees the larger terms last)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  floatx16 accs[1] = {acc};
+  gemm_epilogue<BM, BN, WM, WN, 1>(accs, C, M, N, m0, n0, m_tile, ep, bias_v, blk_first, blk_seg_start, blk_seg_end, wm, wn, lane);
+}
+
 // ---- stream-K form of the K-deep contractions ---------------------------------------------------------------------------
 // With one tile per workgroup, 408 / 596 / 806 tiles of 64x64 on 256 CUs (<= 3 resident workgroups each) leave some CUs with one
 // tile more than others: the deepest KPConv contractions lose ~20 % to that quantisation.  Here the grid is a fixed number of
@@ -1212,6 +1342,38 @@ static int gemm_impl(const float* A, const float* B, float* C, int64_t M, int N,
   if (sk_mode && sk_legal && (sk_mode == 2 || sk_worth(M, N, K))) return launch_gemm_sk(A, B, C, M, N, K, ep, st);
   if (K >= 512 && b128 * nb128 >= 512) return launch_gemm<128, 128, 4, 1, true>(A, B, C, M, N, K, transA, transB, ep, st);
   return launch_gemm<64, 64, 2, 2, true>(A, B, C, M, N, K, transA, transB, ep, st);
+}
+
+// fp32 array -> its three bf16 terms, planes [3][n] (bf16 bit patterns); once per constant operand (weights)
+extern "C" int lcr_split_bf16x3(const float* w, int64_t n, uint16_t* planes, void* stream) {
+  if (!w || !planes || n < 0) {
+    set_error("lcr_split_bf16x3: bad argument");
+    return LCR_EARG;
+  }
+  if (n == 0) return LCR_OK;
+  hipLaunchKernelGGL(k_split_bf16x3, dim3(min(div_up(n, 512), 2048)), dim3(256), 0, static_cast<hipStream_t>(stream), w, n, planes);
+  return check_launch("lcr_split_bf16x3");
+}
+
+// C = A[M,K] · B[N,K]^T with B given as the bf16 planes of lcr_split_bf16x3 ([3][N][K]); epilogue as lcr_gemm_f32.
+extern "C" int lcr_gemm_f32_bsplit(const float* A, const uint16_t* Bs, float* C, int64_t M, int N, int K, const float* bias, const float* rowdiv,
+                                   const int64_t* seg_len, int S, int groups, double* stats, void* stream) {
+  if (!A || !Bs || !C || M < 0 || N <= 0 || K <= 0 || K % GM_BK != 0 || reinterpret_cast<uintptr_t>(A) % 16 != 0 || reinterpret_cast<uintptr_t>(Bs) % 16 != 0 ||
+      (static_cast<int64_t>(N) * K) % 8 != 0) {
+    set_error("lcr_gemm_f32_bsplit: needs K %% 32 == 0 and 16-byte aligned operands");
+    return LCR_EARG;
+  }
+  if (stats && (!seg_len || S < 1 || groups < 1 || N % groups != 0 || ((N / groups) & (N / groups - 1)) != 0)) {
+    set_error("lcr_gemm_f32_bsplit: statistics need seg_len, S >= 1 and groups dividing N into power-of-two sized groups");
+    return LCR_EARG;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  KernelTimerScope timed(KT_GEMM, st, M, N, K);
+  if (M == 0) return LCR_OK;
+  GemmEpilogue ep{bias, rowdiv, seg_len, S, groups, stats};
+  const int mt8 = (div_up(M, 64) + 7) / 8 * 8;
+  LCR_LAUNCH_TIMED((k_gemm_f32_bsplit<64, 64, 2, 2>), dim3(mt8 * div_up(N, 64)), dim3(GM_T), 0, st, A, Bs, C, M, N, K, ep);
+  return check_launch("lcr_gemm_f32_bsplit");
 }
 
 // Batched C_z = A_z^T·B_z (transA) with per-entry K — NetVLAD's per-scan aggregation (NetVlad.py:68): one launch for S scans.

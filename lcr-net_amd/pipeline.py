@@ -206,6 +206,17 @@ class HostIngest:
     def release(self, slot):
         self.free.put(slot)
 
+    def reset(self):
+        """All slots free again (only with no upload in flight and no consumer left: end of a run)."""
+        import queue
+        while True:
+            try:
+                self.free.get_nowait()
+            except queue.Empty:
+                break
+        for i in range(len(self.pin)):
+            self.free.put(i)
+
 
 class DescriptorPipeline:
     def __init__(self, model, voxel_size=0.3, radius=1.275, num_stages=4, neighbor_limits=(64, 65, 74, 80), upsampling=False,
@@ -459,6 +470,7 @@ class DescriptorPipeline:
             if feeder is not None:
                 feeder.join()
                 ingest.stream.synchronize()
+                ingest.reset()                               # batches uploaded but never consumed (early exit) give their slots back
             for st in streams:
                 st.synchronize()
 
