@@ -257,6 +257,7 @@ int lcr_groupnorm_apply(const float* x, const double* stats, const float* gamma,
 typedef struct LcrUnaryW {
   const float *w, *b;          /* nn.Linear weight [cout,cin], bias [cout] */
   const float *gn_w, *gn_b;    /* GroupNorm affine [cout] */
+  const uint16_t* w_split;     /* optional: lcr_split_bf16x3 planes of w (u16[3][cout*cin]); used for K-deep shapes (cin >= 288, cin % 32 == 0, cout >= 64) */
 } LcrUnaryW;
 typedef struct LcrBlockW {     /* ResidualBlock (modules.py:148-225) */
   int   cin, cout, strided;
@@ -264,6 +265,7 @@ typedef struct LcrBlockW {     /* ResidualBlock (modules.py:148-225) */
   const float* kernel_points_host;
   const float *kp_w, *kp_b;    /* KPConv weights [15, cout/4, cout/4], bias [cout/4] */
   const float* kp_wt;          /* optional: the same weights as [cout/4, 15 * cout/4] (k-contiguous rows: the K-deep GEMM form); NULL = not provided */
+  const uint16_t* kp_wt_split; /* optional: lcr_split_bf16x3 planes of kp_wt: the contraction then runs on the bf16 matrix cores (lcr_gemm_f32_bsplit; cout/4 >= 64) */
   const float *normconv_w, *normconv_b;
   LcrUnaryW unary1, unary2, shortcut;
 } LcrBlockW;

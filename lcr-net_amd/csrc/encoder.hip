@@ -64,7 +64,10 @@ static int unary_raw(const LcrUnaryW& u, const float* x, int64_t n, int cin, int
   float* y = ws.take<float>(static_cast<size_t>(n) * cout);
   double* stats = sp.take();
   if (!y || !stats) return LCR_ESPACE;
-  int rc = TURN(lcr_gemm_f32(x, u.w, y, n, cout, cin, 0, 1, u.b, nullptr, st.seg, sp.S, sp.groups, stats, s));
+  // K-deep Linears (stages 3-4) on the bf16 matrix cores when the caller provides the weight's three bf16 terms (fp32-faithful, gemm_f32.hip)
+  const bool split = u.w_split && cin >= 288 && cin % 32 == 0 && cout >= 64;
+  int rc = split ? TURN(lcr_gemm_f32_bsplit(x, u.w_split, y, n, cout, cin, u.b, nullptr, st.seg, sp.S, sp.groups, stats, s))
+                 : TURN(lcr_gemm_f32(x, u.w, y, n, cout, cin, 0, 1, u.b, nullptr, st.seg, sp.S, sp.groups, stats, s));
   *y_out = y;
   *stats_out = stats;
   return rc;
@@ -106,8 +109,10 @@ static int residual_block(const LcrBlockW& b, const float* s_feats, const StageI
   } else {
     if ((rc = TURN(lcr_kpconv_aggregate(x, pos, q.pts, sup.pts, idx, 0, M, Ns, H, mid, b.kernel_points_host, b.sigma, A, nn, q.order, s)))) return rc;
     // weights pre-transposed by the caller ([mid, 15 mid]): both operands k-contiguous -> the K-deep GEMM form
-    if ((rc = TURN(b.kp_wt ? lcr_gemm_f32(A, b.kp_wt, kpo, M, mid, 15 * mid, 0, 1, b.kp_b, nn, q.seg, sp.S, g, stc, s)
-                           : lcr_gemm_f32(A, b.kp_w, kpo, M, mid, 15 * mid, 0, 0, b.kp_b, nn, q.seg, sp.S, g, stc, s)))) return rc;
+    if (b.kp_wt_split && mid >= 64) {      // N = 32 contractions stream A at the HBM rate on the fp32 form already
+      if ((rc = TURN(lcr_gemm_f32_bsplit(A, b.kp_wt_split, kpo, M, mid, 15 * mid, b.kp_b, nn, q.seg, sp.S, g, stc, s)))) return rc;
+    } else if ((rc = TURN(b.kp_wt ? lcr_gemm_f32(A, b.kp_wt, kpo, M, mid, 15 * mid, 0, 1, b.kp_b, nn, q.seg, sp.S, g, stc, s)
+                                  : lcr_gemm_f32(A, b.kp_w, kpo, M, mid, 15 * mid, 0, 0, b.kp_b, nn, q.seg, sp.S, g, stc, s)))) return rc;
   }
   // 3. + 4. norm_conv + LeakyReLU + unary2 (normalised in step 7).  With segments of >= 64 rows and the light GEMM form, the
   // normalisation happens while unary2's GEMM stages its A tiles (lcr_gemm_f32_anorm) — same rule as ResidualBlock.forward.

@@ -837,12 +837,14 @@ static int launch_gemm_deep(const float* A, const float* B, float* C, int64_t M,
 // MFMA — six K=16 instructions (192 cycles) replace eight fp32 ones (512) per 32 x 32 x 16 block.
 //   * B (weights, constant) arrives pre-split: three bf16 planes [3][N][K] made once per weight by lcr_split_bf16x3;
 //   * A (activations) is split ONCE PER WORKGROUP on its way from registers to LDS (8 values per thread and K-step: 44 VALU), not per
-//     wavefront at the fragment read; planes are row-major bf16 tiles with 80-byte rows (16-B fragment reads of 16 rows hit 16 bank groups);
-//   * register-staged double buffering: tile t+1 is in flight in registers while tile t feeds the matrix cores from LDS.
+//     wavefront at the fragment read; planes are row-major bf16 tiles, 64-B rows with XOR-ed 16-B chunks (k_gemm_f32_bsplit_p);
+//   * LDS double-buffered, loads two tiles ahead in registers: one barrier per K-step.
 // Results are NOT bit-identical to the fp32 form (different rounding points); tests/test_gemm_split_gpu.py holds both against fp64.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));     // plain vector type: arrays of HIP's uint4 struct did not leave scratch memory
 
 __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {           // v_cvt_pk_bf16_f32 (round to nearest even): a -> low half
   f32x2_t v = {a, b};
@@ -867,39 +869,78 @@ __global__ __launch_bounds__(256) void k_split_bf16x3(const float* __restrict__ 
   }
 }
 
-constexpr int SP_LD = 80;            // bytes per LDS row of a bf16 plane tile (32 k = 64 B + 16 B pad: 16-B reads of rows r .. r+15 -> bank groups 5r mod 16)
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(GM_T, 4) void k_gemm_f32_bsplit(const float* __restrict__ A, const uint16_t* __restrict__ Bs, float* __restrict__ C,
+// 64 x 64 tile, 2 x 2 wavefronts of 32 x 32 (the stage-3/4 contractions are 200-600 such tiles on 256 CUs: little but the workgroup itself
+// hides its latencies).  Both operands' planes in LDS, DOUBLE-buffered: the split + plane writes of tile t+1 run under the MFMAs of tile t and
+// a K-step has ONE barrier; A rows are fetched as full 128-B lines (4 lanes per row), tiles t+1 and t+2 in flight / parked in two register
+// stages.  What was measured on the way (tools/gemm_split_bench.py): single-buffered LDS with two barriers per step 1.00x the
+// fp32 kernel; larger tiles (128 x 64, 128 x 128) lose on the encoder's shapes (too few tiles) and win on 8192 x 1024 x 1024 (1.45x); A straight
+// from global memory into fragment registers (no LDS for A) 0.92x (32-B pieces of 32 different lines per load instruction); four register
+// stages: no change (not memory latency); 80-byte padded LDS rows: a third of the LDS cycles were bank conflicts of the 16-B WRITES
+// (rocprofv3 SQ_LDS_BANK_CONFLICT) — the XOR layout below: 1.07x -> 1.17x; two alternating accumulators: same speed, half the error.
+constexpr int D = 2;
+__global__ __launch_bounds__(256, 2) void k_gemm_f32_bsplit_p(const float* __restrict__ A, const uint16_t* __restrict__ Bs, float* __restrict__ C,
                                                              int64_t M, int N, int K, GemmEpilogue ep) {
-  static_assert(WM * WN == 4 && BM == 32 * WM && BN == 32 * WN && BM == 64 && BN == 64, "64 x 64 tile, one 32 x 32 accumulator per wavefront");
-  __shared__ __attribute__((aligned(16))) char sA[3][BM * SP_LD];
-  __shared__ __attribute__((aligned(16))) char sB[3][BN * SP_LD];
+  // LDS plane tile: 64 rows x 64 B (32 bf16), no padding; the four 16-B chunks of row r are XOR-ed with (r >> 2) & 3.  A ds_write_b128 is
+  // serviced in groups of 8 consecutive lanes over 32 banks (two rows x four chunks: 128 distinct bytes), a ds_read_b128 in groups of 16 lanes
+  // over 64 banks (16 different rows, one logical chunk: rows r, r+4, r+8, r+12 share a 64-B bank quadrant and get four different chunks).
+  // (The 80-byte padded rows of the first version were conflict-free for the reads only: SQ_LDS_BANK_CONFLICT = a third of SQ_LDS_IDX_ACTIVE.)
+  constexpr int BM = 64, BN = 64, RS = 64, PL = 64 * RS, STG = 3 * PL;
+  __shared__ __attribute__((aligned(16))) char sA[2 * STG];
+  __shared__ __attribute__((aligned(16))) char sB[2 * STG];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = w / WN, wn = w % WN;
+  const int wm = w >> 1, wn = w & 1;
   const int ntn = (N + BN - 1) / BN;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;    // XCD-aware tile order, as in k_gemm_f32
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int64_t m_tile = static_cast<int64_t>(slot / ntn) * 8 + xcd;
   const int64_t m0 = m_tile * BM;
   const int n0 = (slot % ntn) * BN;
   if (m0 >= M) return;
-  // staging: thread -> (row, chunk of 8 consecutive k) of the A tile (fp32) and of each B plane tile (bf16)
   const int srow = threadIdx.x >> 2, skc = threadIdx.x & 3;
   int64_t ga = m0 + srow;
-  ga = ga < M ? ga : M - 1;                                  // duplicate rows only feed outputs that are never stored
+  ga = ga < M ? ga : M - 1;
   int gb = n0 + srow;
   gb = gb < N ? gb : N - 1;
   const float* ap = A + ga * K + skc * 8;
-  const int64_t plane = static_cast<int64_t>(N) * K;
   const uint16_t* bp = Bs + static_cast<int64_t>(gb) * K + skc * 8;
-  const int soff = srow * SP_LD + skc * 16;
-  // fragments: lane (l & 31) owns row wm*32 + (l & 31) of A (wn*32 + .. of B); half l >> 5 the k range [8 half, 8 half + 8) of a K=16 block
-  const int fa = (wm * 32 + (lane & 31)) * SP_LD + (lane >> 5) * 16, fb = (wn * 32 + (lane & 31)) * SP_LD + (lane >> 5) * 16;
-  floatx16 acc;
+  const int64_t plane = static_cast<int64_t>(N) * K;
+  const int soff = srow * RS + ((skc ^ ((srow >> 2) & 3)) << 4);
+  const int fsw = ((lane & 31) >> 2) & 3, fc0 = ((lane >> 5) ^ fsw) << 4, fc1 = (((lane >> 5) + 2) ^ fsw) << 4;     // chunks of K16 block 0 / 1
+  const int fa = (wm * 32 + (lane & 31)) * RS, fb = (wn * 32 + (lane & 31)) * RS;
+  floatx16 acc, acc2;                                          // two accumulators, alternating: consecutive MFMAs are independent
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f, acc2[r] = 0.f;
   const int nk = K / GM_BK;
-  float4 ra0 = ld4(ap), ra1 = ld4(ap + 4);
-  uint4 rb0 = *reinterpret_cast<const uint4*>(bp), rb1 = *reinterpret_cast<const uint4*>(bp + plane), rb2 = *reinterpret_cast<const uint4*>(bp + 2 * plane);
+  f32x4_t ra[D][2];                                            // D register stages: tiles t+1 .. t+D in flight / parked
+  u32x4_t rb[D][3];
+  auto fetch = [&](auto st_c, int t) {
+    constexpr int st = decltype(st_c)::value;
+    const int ko = (t < nk ? t : nk - 1) * GM_BK;
+    ra[st][0] = *reinterpret_cast<const f32x4_t*>(ap + ko), ra[st][1] = *reinterpret_cast<const f32x4_t*>(ap + ko + 4);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) rb[st][p] = *reinterpret_cast<const u32x4_t*>(bp + p * plane + ko);
+  };
+  auto park = [&](auto st_c, int lds_stage) {                  // register stage -> (split) -> LDS stage
+    constexpr int st = decltype(st_c)::value;
+    u32x4_t p1, p2, p3;
+    uint32_t h1, h2, h3;
+    split2(ra[st][0].x, ra[st][0].y, h1, h2, h3), p1.x = h1, p2.x = h2, p3.x = h3;
+    split2(ra[st][0].z, ra[st][0].w, h1, h2, h3), p1.y = h1, p2.y = h2, p3.y = h3;
+    split2(ra[st][1].x, ra[st][1].y, h1, h2, h3), p1.z = h1, p2.z = h2, p3.z = h3;
+    split2(ra[st][1].z, ra[st][1].w, h1, h2, h3), p1.w = h1, p2.w = h2, p3.w = h3;
+    char* da = sA + lds_stage * STG + soff;
+    char* db = sB + lds_stage * STG + soff;
+    *reinterpret_cast<u32x4_t*>(da) = p1;
+    *reinterpret_cast<u32x4_t*>(da + PL) = p2;
+    *reinterpret_cast<u32x4_t*>(da + 2 * PL) = p3;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4_t*>(db + p * PL) = rb[st][p];
+  };
+  using I0 = std::integral_constant<int, 0>;
+  // register stage of tile t is t % D; LDS stage t & 1
+  fetch(I0{}, 0);
+  if constexpr (D > 1) fetch(std::integral_constant<int, 1 % D>{}, 1);
+  if constexpr (D > 2) fetch(std::integral_constant<int, 2 % D>{}, 2);
+  if constexpr (D > 3) fetch(std::integral_constant<int, 3 % D>{}, 3);
   float bias_v[1];
   {
     const int col = n0 + wn * 32 + (lane & 31);
@@ -915,47 +956,69 @@ __global__ __launch_bounds__(GM_T, 4) void k_gemm_f32_bsplit(const float* __rest
       blk_seg_end += ep.seg_len[blk_first];
     }
   }
-  for (int t = 0; t < nk; ++t) {
-    {                                                          // tile t: registers -> (split) -> LDS
-      uint4 p1, p2, p3;
-      split2(ra0.x, ra0.y, p1.x, p2.x, p3.x);
-      split2(ra0.z, ra0.w, p1.y, p2.y, p3.y);
-      split2(ra1.x, ra1.y, p1.z, p2.z, p3.z);
-      split2(ra1.z, ra1.w, p1.w, p2.w, p3.w);
-      *reinterpret_cast<uint4*>(sA[0] + soff) = p1;
-      *reinterpret_cast<uint4*>(sA[1] + soff) = p2;
-      *reinterpret_cast<uint4*>(sA[2] + soff) = p3;
-      *reinterpret_cast<uint4*>(sB[0] + soff) = rb0;
-      *reinterpret_cast<uint4*>(sB[1] + soff) = rb1;
-      *reinterpret_cast<uint4*>(sB[2] + soff) = rb2;
-    }
-    __syncthreads();
-    if (t + 1 < nk) {                                          // tile t+1 on its way while tile t is multiplied
-      ap += GM_BK;
-      bp += GM_BK;
-      ra0 = ld4(ap), ra1 = ld4(ap + 4);
-      rb0 = *reinterpret_cast<const uint4*>(bp), rb1 = *reinterpret_cast<const uint4*>(bp + plane), rb2 = *reinterpret_cast<const uint4*>(bp + 2 * plane);
+  park(I0{}, 0);
+  fetch(I0{}, D);
+  __syncthreads();
+  // step t: LDS stage t & 1 holds tile t; register stage (t+1) % D holds tile t+1, which is split into the other LDS stage under this
+  // step's MFMAs; its registers then take tile t+1+D
+  auto step = [&](auto lds_c, auto reg_c, int t) {
+    constexpr int P = decltype(lds_c)::value;                  // t & 1
+    using NX = std::integral_constant<int, (decltype(reg_c)::value + 1) % D>;      // register stage of tile t+1
+    const char* la = sA + P * STG + fa;
+    const char* lb = sB + P * STG + fb;
+    bf16x8_t a0[3], b0[3], a1[3], b1[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      a0[p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(la + p * PL + fc0));
+      b0[p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(lb + p * PL + fc0));
     }
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8_t a[3], b[3];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        a[p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sA[p] + fa + kk * 32));
-        b[p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sB[p] + fb + kk * 32));
-      }
-      // smallest terms first (a rounding of the running sum then sees the larger terms last)
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+    for (int p = 0; p < 3; ++p) {
+      a1[p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(la + p * PL + fc1));
+      b1[p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(lb + p * PL + fc1));
     }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[2], b0[0], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0], b0[2], acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[1], b0[1], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[1], b0[0], acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0], b0[1], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0], b0[0], acc2, 0, 0, 0);
+    park(NX{}, P ^ 1);                                         // tile t+1 -> the other LDS stage (its last readers passed the barrier of step t-1)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[2], b1[0], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], b1[2], acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[1], b1[1], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[1], b1[0], acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], b1[1], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], b1[0], acc2, 0, 0, 0);
+    fetch(NX{}, t + 1 + D);
     __syncthreads();
+  };
+  static_assert(D == 2 || D == 4, "register stages");
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  int t = 0;
+  if constexpr (D == 2) {
+    for (; t + 2 <= nk; t += 2) {
+      step(I0{}, I0{}, t);
+      step(I1{}, I1{}, t + 1);
+    }
+    if (t < nk) step(I0{}, I0{}, t);
+  } else {
+    for (; t + 4 <= nk; t += 4) {
+      step(I0{}, I0{}, t);
+      step(I1{}, I1{}, t + 1);
+      step(I0{}, I2{}, t + 2);
+      step(I1{}, I3{}, t + 3);
+    }
+    if (t < nk) step(I0{}, I0{}, t);
+    if (t + 1 < nk) step(I1{}, I1{}, t + 1);
+    if (t + 2 < nk) step(I0{}, I2{}, t + 2);
   }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
   floatx16 accs[1] = {acc};
-  gemm_epilogue<BM, BN, WM, WN, 1>(accs, C, M, N, m0, n0, m_tile, ep, bias_v, blk_first, blk_seg_start, blk_seg_end, wm, wn, lane);
+  gemm_epilogue<BM, BN, 2, 2, 1>(accs, C, M, N, m0, n0, m_tile, ep, bias_v, blk_first, blk_seg_start, blk_seg_end, wm, wn, lane);
 }
 
 // ---- stream-K form of the K-deep contractions ---------------------------------------------------------------------------
@@ -1372,7 +1435,7 @@ extern "C" int lcr_gemm_f32_bsplit(const float* A, const uint16_t* Bs, float* C,
   if (M == 0) return LCR_OK;
   GemmEpilogue ep{bias, rowdiv, seg_len, S, groups, stats};
   const int mt8 = (div_up(M, 64) + 7) / 8 * 8;
-  LCR_LAUNCH_TIMED((k_gemm_f32_bsplit<64, 64, 2, 2>), dim3(mt8 * div_up(N, 64)), dim3(GM_T), 0, st, A, Bs, C, M, N, K, ep);
+  LCR_LAUNCH_TIMED(k_gemm_f32_bsplit_p, dim3(mt8 * div_up(N, 64)), dim3(256), 0, st, A, Bs, C, M, N, K, ep);
   return check_launch("lcr_gemm_f32_bsplit");
 }
 

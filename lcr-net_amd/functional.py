@@ -1,6 +1,7 @@
 """Thin tensor-level wrappers over the C ABI (include/lcr_hip.h).  No arithmetic happens in Python: every function
 allocates the outputs with torch and launches HIP kernels on the current stream.  Inference only (no autograd)."""
 import ctypes
+import os
 import threading
 
 import numpy as np
@@ -132,6 +133,50 @@ def gemm(a, b, trans_b=False, trans_a=False, bias=None, rowdiv=None, seg_len=Non
         _lib.ptr(a), _lib.ptr(b), _lib.ptr(c), M, N, K, int(trans_a), int(trans_b), _lib.ptr(bias), _lib.ptr(rowdiv),
         _lib.ptr(seg_len) if groups else None, S, int(groups), _lib.ptr(stats), _lib.stream_ptr(a.device)), "lcr_gemm_f32"),
         meta=(M, N, K))
+    return c, stats
+
+
+# ---- split-bf16 form of the K-deep GEMMs (csrc/gemm_f32.hip): fp32 operands as three bf16 terms, six products on the bf16 matrix cores.
+# LCR_GEMM_SPLIT=1 turns it on for the K-deep shapes (K >= 288, K % 32 == 0, N >= 64); `set_gemm_split` is the run-time switch (tests, A/B).
+_GEMM_SPLIT = [os.environ.get("LCR_GEMM_SPLIT", "0") not in ("", "0")]
+
+
+def gemm_split_enabled():
+    return _GEMM_SPLIT[0]
+
+
+def set_gemm_split(on):
+    _GEMM_SPLIT[0] = bool(on)
+
+
+def gemm_split_ok(N, K):
+    return K >= 288 and K % 32 == 0 and N >= 64
+
+
+def split_bf16x3(w):
+    """The three bf16 terms of a constant fp32 operand [N,K] as planes int16 [3, N, K] (lcr_split_bf16x3; made once per weight)."""
+    w = w.detach().contiguous()
+    planes = torch.empty((3,) + tuple(w.shape), dtype=torch.int16, device=w.device)
+    _lib.check(_lib.lib().lcr_split_bf16x3(_lib.ptr(w), w.numel(), _lib.ptr(planes), _lib.stream_ptr(w.device)), "lcr_split_bf16x3")
+    return planes
+
+
+def gemm_bsplit(a, planes, bias=None, rowdiv=None, seg_len=None, groups=0):
+    """C = A[M,K] . B[N,K]^T with B given as the planes of split_bf16x3 (same epilogue and return value as gemm())."""
+    _lib.require_cuda(a, planes)
+    assert a.dtype == torch.float32 and a.is_contiguous() and planes.dtype == torch.int16 and planes.is_contiguous() and planes.dim() == 3
+    M, K = a.shape
+    N = planes.shape[1]
+    assert planes.shape[2] == K, "inner dimensions differ"
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    stats, S = None, 0
+    if groups:
+        seg_len = _seg(seg_len, M, a.device)
+        S = seg_len.numel()
+        stats = _zero_stats(S, groups, a.device)
+    _lib.check(_lib.lib().lcr_gemm_f32_bsplit(_lib.ptr(a), _lib.ptr(planes), _lib.ptr(c), M, N, K, _lib.ptr(bias), _lib.ptr(rowdiv),
+                                              _lib.ptr(seg_len) if groups else None, S, int(groups), _lib.ptr(stats), _lib.stream_ptr(a.device)),
+               "lcr_gemm_f32_bsplit")
     return c, stats
 
 

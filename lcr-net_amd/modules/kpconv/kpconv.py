@@ -51,6 +51,14 @@ class KPConv(nn.Module):
             self._wt_cache = (key, w.detach().reshape(self.kernel_size * self.in_channels, self.out_channels).t().contiguous())
         return self._wt_cache[1]
 
+    def weights_t_split(self):
+        """The three bf16 terms of weights_t() (functional.split_bf16x3), cached with it: the contraction on the bf16 matrix cores."""
+        wt = self.weights_t()
+        c = getattr(self, "_wts_cache", None)
+        if c is None or c[0] is not wt:
+            c = self._wts_cache = (wt, F.split_bf16x3(wt))
+        return c[1]
+
     def kernel_points_host(self):
         kp = self.kernel_points
         key = (kp.data_ptr(), kp._version)
@@ -74,7 +82,10 @@ class KPConv(nn.Module):
             return F.kpconv_fused(s_feats, s_pos, q_points, s_points, neighbor_indices, kp, self.sigma, self.weights, self.bias,
                                   seg_len=seg_len, groups=groups, order=order)
         A, nn_cnt = F.kpconv_aggregate(s_feats, s_pos, q_points, s_points, neighbor_indices, kp, self.sigma, order=order)
-        return F.gemm(A, self.weights_t(), trans_b=True, bias=self.bias, rowdiv=nn_cnt, seg_len=seg_len, groups=groups)
+        wt = self.weights_t()
+        if F.gemm_split_enabled() and F.gemm_split_ok(wt.shape[0], wt.shape[1]):
+            return F.gemm_bsplit(A, self.weights_t_split(), bias=self.bias, rowdiv=nn_cnt, seg_len=seg_len, groups=groups)
+        return F.gemm(A, wt, trans_b=True, bias=self.bias, rowdiv=nn_cnt, seg_len=seg_len, groups=groups)
 
     def forward(self, s_feats, q_points, s_points, neighbor_indices):
         return self.forward_raw(s_feats, q_points, s_points, neighbor_indices)[0]

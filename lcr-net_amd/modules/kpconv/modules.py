@@ -61,8 +61,18 @@ class UnaryBlock(nn.Module):
         self.norm = GroupNorm(group_norm, out_channels)
         self.leaky_relu = nn.LeakyReLU(0.1) if has_relu else None
 
+    def weight_split(self):
+        w = self.mlp.weight
+        key = (w.data_ptr(), w._version, w.device)
+        c = getattr(self, "_ws_cache", None)
+        if c is None or c[0] != key:
+            c = self._ws_cache = (key, F.split_bf16x3(w))
+        return c[1]
+
     def raw(self, x, ctx):
         """Linear + GroupNorm sums (no normalisation yet)."""
+        if F.gemm_split_enabled() and F.gemm_split_ok(self.out_channels, self.in_channels):
+            return F.gemm_bsplit(x.contiguous(), self.weight_split(), bias=self.mlp.bias, seg_len=ctx.seg_len, groups=self.group_norm)
         return F.gemm(x.contiguous(), self.mlp.weight, trans_b=True, bias=self.mlp.bias, seg_len=ctx.seg_len, groups=self.group_norm)
 
     def forward(self, x, ctx=_WHOLE, want_pos=False):

@@ -17,12 +17,13 @@ _fp = ctypes.c_void_p
 
 
 class UnaryW(ctypes.Structure):
-    _fields_ = [("w", _fp), ("b", _fp), ("gn_w", _fp), ("gn_b", _fp)]
+    _fields_ = [("w", _fp), ("b", _fp), ("gn_w", _fp), ("gn_b", _fp), ("w_split", _fp)]
 
 
 class BlockW(ctypes.Structure):
     _fields_ = [("cin", ctypes.c_int), ("cout", ctypes.c_int), ("strided", ctypes.c_int), ("sigma", ctypes.c_float),
-                ("kernel_points_host", _fp), ("kp_w", _fp), ("kp_b", _fp), ("kp_wt", _fp), ("normconv_w", _fp), ("normconv_b", _fp),
+                ("kernel_points_host", _fp), ("kp_w", _fp), ("kp_b", _fp), ("kp_wt", _fp), ("kp_wt_split", _fp), ("normconv_w", _fp),
+                ("normconv_b", _fp),
                 ("unary1", UnaryW), ("unary2", UnaryW), ("shortcut", UnaryW)]
 
 
@@ -35,11 +36,16 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-def _unary(u):
+def _unary(u, keep):
     import torch.nn as nn
     if isinstance(u, nn.Identity):
-        return UnaryW(None, None, None, None)
-    return UnaryW(_p(u.mlp.weight), _p(u.mlp.bias), _p(u.norm.norm.weight), _p(u.norm.norm.bias))
+        return UnaryW(None, None, None, None, None)
+    from . import functional as F
+    sp = None
+    if F.gemm_split_enabled() and F.gemm_split_ok(u.mlp.weight.shape[0], u.mlp.weight.shape[1]):
+        sp = F.split_bf16x3(u.mlp.weight)
+        keep.append(sp)
+    return UnaryW(_p(u.mlp.weight), _p(u.mlp.bias), _p(u.norm.norm.weight), _p(u.norm.norm.bias), _p(sp))
 
 
 class EncoderTable:
@@ -63,8 +69,11 @@ class EncoderTable:
             wt = b.KPConv.weights_t()                     # [mid, 15 mid] copy (cached by the module, rebuilt with the weights)
             self.keep.append(wt)
             blk.kp_wt = _p(wt)
+            from . import functional as F
+            if F.gemm_split_enabled() and F.gemm_split_ok(wt.shape[0], wt.shape[1]):
+                blk.kp_wt_split = _p(b.KPConv.weights_t_split())
             blk.normconv_w, blk.normconv_b = _p(b.norm_conv.norm.weight), _p(b.norm_conv.norm.bias)
-            blk.unary1, blk.unary2, blk.shortcut = _unary(b.unary1), _unary(b.unary2), _unary(b.unary_shortcut)
+            blk.unary1, blk.unary2, blk.shortcut = _unary(b.unary1, self.keep), _unary(b.unary2, self.keep), _unary(b.unary_shortcut, self.keep)
         self.w = w
         self.out_channels = [int(getattr(enc, n).out_channels) for n in ("encoder1_2", "encoder2_3", "encoder3_3", "encoder4_3")]
 
@@ -76,7 +85,8 @@ class EncoderTable:
 
 
 def _key(enc):
-    return tuple((t.data_ptr(), t._version) for t in list(enc.parameters()) + list(enc.buffers()))
+    from . import functional as F
+    return (F.gemm_split_enabled(),) + tuple((t.data_ptr(), t._version) for t in list(enc.parameters()) + list(enc.buffers()))
 
 
 def table_for(enc):

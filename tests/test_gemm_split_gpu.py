@@ -32,7 +32,7 @@ def test_three_bf16_terms_are_the_fp32_number():
 def test_split_gemm_against_fp64(M, N, K, rowdiv, groups):
     """Error vs fp64 of the split form is of the size of the fp32-MFMA kernel's own (both bounded here by 3e-6 of the largest output;
     measured ~1e-7): the six kept products carry every a.b to 2^-23, accumulation is fp32 in both.  Epilogue (count division, bias,
-    GroupNorm sums per segment) shared with lcr_gemm_f32: statistics agree to 1e-6 relative."""
+    GroupNorm sums per segment) shared with lcr_gemm_f32: statistics agree to 1e-6 (sums relative to sqrt(n * sum of squares))."""
     from lcrnet_amd import _lib
     L = _lib.lib()
     dev = torch.device("cuda")
@@ -69,8 +69,11 @@ def test_split_gemm_against_fp64(M, N, K, rowdiv, groups):
     assert torch.isfinite(outs[1]).all()
     assert e1 < 3e-6 and e1 < max(4 * e0, 4e-7)
     if groups:
-        rel = ((stats[0] - stats[1]).abs() / (stats[0].abs() + 1e-12)).max().item()
-        assert rel < 1e-5, rel
+        # sums against their Cauchy-Schwarz bound sqrt(n * sum of squares) (a group's sum can cancel to ~0), sums of squares relative
+        n_el = seg.double()[:, None] * (N // groups)
+        rel = max(((stats[0][..., 0] - stats[1][..., 0]).abs() / (n_el * stats[0][..., 1]).sqrt()).max().item(),
+                  ((stats[0][..., 1] - stats[1][..., 1]).abs() / stats[0][..., 1]).max().item())
+        assert rel < 1e-6, rel
 
 
 def test_split_gemm_rejects_bad_shapes():

@@ -42,11 +42,11 @@ def main():
         st0 = torch.zeros(8, 8, max(gr, 1), 2, dtype=torch.float64, device=dev)
         st1 = torch.zeros_like(st0)
 
-        def run0(c=c0, st=st0):
+        def run0(c=c0, st=st0, a=a, b=b, bias=bias, div=div, seg=seg, gr=gr, M=M, N=N, K=K, rd=rd):
             _lib.check(L.lcr_gemm_f32(_lib.ptr(a), _lib.ptr(b), _lib.ptr(c), M, N, K, 0, 1, _lib.ptr(bias), _lib.ptr(div) if rd else None,
                                       _lib.ptr(seg) if gr else None, 8, gr, _lib.ptr(st) if gr else None, sp(a)), "gemm")
 
-        def run1(c=c1, st=st1):
+        def run1(c=c1, st=st1, a=a, planes=planes, bias=bias, div=div, seg=seg, gr=gr, M=M, N=N, K=K, rd=rd):
             _lib.check(L.lcr_gemm_f32_bsplit(_lib.ptr(a), _lib.ptr(planes), _lib.ptr(c), M, N, K, _lib.ptr(bias), _lib.ptr(div) if rd else None,
                                              _lib.ptr(seg) if gr else None, 8, gr, _lib.ptr(st) if gr else None, sp(a)), "bsplit")
         run0()
@@ -60,9 +60,11 @@ def main():
         e0, e1 = ((c0.double() - ref).abs().max() / scale).item(), ((c1.double() - ref).abs().max() / scale).item()
         r0, r1 = (c0.double() - ref).pow(2).mean().sqrt().item(), (c1.double() - ref).pow(2).mean().sqrt().item()
         serr = 0.0
-        if gr:
+        if gr:                                              # sums relative to their Cauchy-Schwarz bound sqrt(n * sumsq), sums of squares relative
             s0, s1 = st0.sum(0), st1.sum(0)
-            serr = ((s0 - s1).abs() / (s0.abs() + 1e-30)).max().item()
+            n_el = seg.double()[:, None] * (N // gr)
+            serr = max(((s0[..., 0] - s1[..., 0]).abs() / (n_el * s0[..., 1]).sqrt()).max().item(),
+                       ((s0[..., 1] - s1[..., 1]).abs() / s0[..., 1]).max().item())
         items.append((tag, M, N, K, run0, run1))
         out.append({"shape": tag, "M": M, "N": N, "K": K, "max_err_fp32_mfma": e0, "max_err_split": e1, "rms_err_fp32_mfma": r0, "rms_err_split": r1,
                     "max_diff_between": (c0 - c1).abs().max().item() / scale.item(), "stats_rel_diff": serr})
