@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--repeats", type=int, default=5, help="the timed K-step block runs this many times back to back (each bracketed by "
                     "barrier + synchronize); the line reports the MEDIAN block, ms_per_step_min / _max the spread")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-split-ab", action="store_true", help="skip the secondary A/B block with the split-bf16 K-deep GEMMs")
     ap.add_argument("--no-h2d", action="store_true", help="skip the secondary `with_h2d` measurement (host [N,4] batches uploaded inside the pipeline)")
     ap.add_argument("--no-upsampling", action="store_true", help="skip the 3 decoder-only upsampling searches")
     ap.add_argument("--no-overlap", action="store_true", help="run pre-processing and encoder on one stream (no pipelining)")
@@ -422,6 +423,36 @@ def main():
                     "descriptors_max_abs_diff_vs_resident": same,
                     "what": "same steps, inputs as pinned host f32 [N,4] rows (x, y, z, intensity) uploaded on a copy stream inside the pipeline; "
                             "median of %d blocks of %d steps; NOT the headline (value = inputs resident in HBM)" % (len(dts), args.steps)}
+    # ---- A/B, not the headline: the same steps with the K-deep GEMMs (N >= 64, K >= 288) on the bf16 matrix cores with fp32-faithful operands
+    # (three bf16 terms per fp32 value, six cross products, fp32 accumulation: lcr_gemm_f32_bsplit).  Opt-in (LCR_GEMM_SPLIT=1):
+    # the headline above is true fp32 MFMA everywhere unless that switch was set by the caller, in which case `dtype` says so.
+    split_ab = None
+    if not args.no_split_ab and not F.gemm_split_enabled():
+        F.set_gemm_split(True)
+        run_steps(8)
+        dts = []
+        for rep in range(min(R, 3)):
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            desc_s = run_steps(args.steps)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            d = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([d], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                d = float(t.item())
+            dts.append(d)
+        F.set_gemm_split(False)
+        run_steps(2)                                                     # back on the fp32 tables before anything else is measured
+        dts_m = sorted(dts)[(len(dts) - 1) // 2]
+        split_ab = {"value": round(world * BATCH * args.steps / dts_m, 3), "unit": "scans/s", "ms_per_step": round(dts_m / args.steps * 1e3, 3),
+                    "over_headline": round(dt / dts_m, 4), "descriptors_max_abs_diff_vs_fp32_mfma": float((desc_s - desc).abs().max()),
+                    "what": "same steps with LCR_GEMM_SPLIT=1: K-deep GEMMs as 3 x bf16 terms / 6 products on the bf16 matrix cores (fp32-faithful, "
+                            "error vs fp64 below the fp32-MFMA kernel's own); opt-in, NOT the headline; median of %d blocks" % len(dts)}
     iso = None
     if rank == 0 and not os.environ.get("LCR_BENCH_NO_KTIMER"):
         # Every distinct batch once more with NOTHING else on the GPU (one stream, one batch in flight, outside the timed region) and
@@ -571,6 +602,10 @@ def main():
         }
         if with_h2d is not None:
             line["with_h2d"] = with_h2d
+        if split_ab is not None:
+            line["split_bf16_gemm_ab"] = split_ab
+        if F.gemm_split_enabled():
+            line["dtype"] = "f32 (K-deep GEMMs: fp32 operands as 3 bf16 terms, 6 products on the bf16 matrix cores, fp32 accumulation)"
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(scans)
         print(json.dumps(line), flush=True)

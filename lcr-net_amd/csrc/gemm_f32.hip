@@ -876,7 +876,9 @@ __global__ __launch_bounds__(256) void k_split_bf16x3(const float* __restrict__ 
 // fp32 kernel; larger tiles (128 x 64, 128 x 128) lose on the encoder's shapes (too few tiles) and win on 8192 x 1024 x 1024 (1.45x); A straight
 // from global memory into fragment registers (no LDS for A) 0.92x (32-B pieces of 32 different lines per load instruction); four register
 // stages: no change (not memory latency); 80-byte padded LDS rows: a third of the LDS cycles were bank conflicts of the 16-B WRITES
-// (rocprofv3 SQ_LDS_BANK_CONFLICT) — the XOR layout below: 1.07x -> 1.17x; two alternating accumulators: same speed, half the error.
+// (rocprofv3 SQ_LDS_BANK_CONFLICT) — the XOR layout below: 1.07x -> 1.17x; two alternating accumulators: same speed, half the error; a
+// producer / consumer split of the workgroup (512 threads: four wavefronts only fetch + split + park, four only read fragments + MFMA): the same
+// time to the microsecond on every shape.  After all of it the matrix pipe is 38 % busy, the LDS array 39 %, VALU ~35 %.
 constexpr int D = 2;
 __global__ __launch_bounds__(256, 2) void k_gemm_f32_bsplit_p(const float* __restrict__ A, const uint16_t* __restrict__ Bs, float* __restrict__ C,
                                                              int64_t M, int N, int K, GemmEpilogue ep) {
