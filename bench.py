@@ -148,7 +148,8 @@ def cpu_baseline(scans):
     kind = "reference" if impl == "ref" else "port"
     return {"value": round(eN, 4), "unit": "scans/s", "cores": cores, "kind": kind,
             "sample": "end to end (voxelise + collate + encoder + NetVLAD), all %d cores: %d processes x %d torch thread(s), one scan each, "
-                      "%.1f s wall.  native ops: %s; encoder+NetVLAD: torch fp32 restatement" %
+                      "%.1f s wall.  native ops: %s; encoder+NetVLAD: torch fp32 restatement.  Baseline only: the torch fp32 encoder is memory-bound "
+                      "(all cores reach only ~4.5x one core), this is the reference's own CPU shape, not a tuned CPU implementation" %
                       (cores, procs, thr, eN_wall, "reference C++ compiled from source (oracle/_ref)" if impl == "ref" else "oracle C++ restatement"),
             "end_to_end": {"one_core_scans_per_s": round(e1, 4), "all_cores_scans_per_s": round(eN, 4), "processes": procs, "threads_per_process": thr,
                            "one_core_s_per_scan": round(e1_wall, 3)},

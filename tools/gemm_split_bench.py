@@ -1,6 +1,7 @@
 """fp32-MFMA K-deep GEMM (lcr_gemm_f32, pre-transposed B) vs the split-bf16 form (lcr_gemm_f32_bsplit: fp32 operands as three bf16 terms, six
 cross products on the bf16 matrix cores) on the encoder's deep shapes: kernel begin-to-end times (interleaved rounds) and the error of BOTH
-against an fp64 product of the same fp32 inputs — max |c - ref| / max |ref| and the rms ratio.  One JSON line per shape + a summary."""
+against an fp64 product of the same fp32 inputs — max |c - ref| / max |ref| and the rms ratio.  One JSON line per shape + a summary
+(--table: one short text row per shape instead)."""
 import ctypes
 import json
 import os
@@ -92,7 +93,11 @@ def main():
         tot1 += t1
         o.update({"us_fp32_mfma": round(t0 * 1e6, 1), "us_split": round(t1 * 1e6, 1), "speedup": round(t0 / t1, 3),
                   "tflops_fp32_mfma": round(2.0 * M * N * K / t0 / 1e12, 1), "tflops_equiv_split": round(2.0 * M * N * K / t1 / 1e12, 1)})
-        print(json.dumps(o))
+        if "--table" in sys.argv:
+            print(tag, M, N, K, "fp32", o["us_fp32_mfma"], "split", o["us_split"], "x", o["speedup"], "TFeq", o["tflops_equiv_split"],
+                  "err %.1e %.1e" % (o["max_err_fp32_mfma"], o["max_err_split"]), "stats %.1e" % o["stats_rel_diff"])
+        else:
+            print(json.dumps(o))
     print(json.dumps({"sum_us_fp32_mfma": round(tot0 * 1e6, 1), "sum_us_split": round(tot1 * 1e6, 1), "speedup": round(tot0 / tot1, 3)}))
 
 
