@@ -880,6 +880,9 @@ __global__ __launch_bounds__(256) void k_split_bf16x3(const float* __restrict__ 
 // producer / consumer split of the workgroup (512 threads: four wavefronts only fetch + split + park, four only read fragments + MFMA): the same
 // time to the microsecond on every shape.  After all of it the matrix pipe is 38 % busy, the LDS array 39 %, VALU ~35 %.
 constexpr int D = 2;
+// ABL: timing ablations (tools/gemm_split_bench.py --abl): 1 no MFMAs, 2 no split arithmetic, 4 no plane stores, 8 no global loads in the
+// loop, 16 no fragment reads.  0 = the product; any other value computes garbage.
+template <int ABL>
 __global__ __launch_bounds__(256, 2) void k_gemm_f32_bsplit_p(const float* __restrict__ A, const uint16_t* __restrict__ Bs, float* __restrict__ C,
                                                              int64_t M, int N, int K, GemmEpilogue ep) {
   // LDS plane tile: 64 rows x 64 B (32 bf16), no padding; the four 16-B chunks of row r are XOR-ed with (r >> 2) & 3.  A ds_write_b128 is
@@ -925,17 +928,27 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32_bsplit_p(const float* __res
     constexpr int st = decltype(st_c)::value;
     u32x4_t p1, p2, p3;
     uint32_t h1, h2, h3;
-    split2(ra[st][0].x, ra[st][0].y, h1, h2, h3), p1.x = h1, p2.x = h2, p3.x = h3;
-    split2(ra[st][0].z, ra[st][0].w, h1, h2, h3), p1.y = h1, p2.y = h2, p3.y = h3;
-    split2(ra[st][1].x, ra[st][1].y, h1, h2, h3), p1.z = h1, p2.z = h2, p3.z = h3;
-    split2(ra[st][1].z, ra[st][1].w, h1, h2, h3), p1.w = h1, p2.w = h2, p3.w = h3;
+    if constexpr (ABL & 2) {
+      p1 = __builtin_bit_cast(u32x4_t, ra[st][0]), p2 = __builtin_bit_cast(u32x4_t, ra[st][1]), p3 = p1;
+      (void)h1, (void)h2, (void)h3;
+    } else {
+      split2(ra[st][0].x, ra[st][0].y, h1, h2, h3), p1.x = h1, p2.x = h2, p3.x = h3;
+      split2(ra[st][0].z, ra[st][0].w, h1, h2, h3), p1.y = h1, p2.y = h2, p3.y = h3;
+      split2(ra[st][1].x, ra[st][1].y, h1, h2, h3), p1.z = h1, p2.z = h2, p3.z = h3;
+      split2(ra[st][1].z, ra[st][1].w, h1, h2, h3), p1.w = h1, p2.w = h2, p3.w = h3;
+    }
     char* da = sA + lds_stage * STG + soff;
     char* db = sB + lds_stage * STG + soff;
-    *reinterpret_cast<u32x4_t*>(da) = p1;
-    *reinterpret_cast<u32x4_t*>(da + PL) = p2;
-    *reinterpret_cast<u32x4_t*>(da + 2 * PL) = p3;
+    if constexpr (ABL & 4) {                                      // keep the values alive without storing them
+      asm volatile("" ::"v"(p1), "v"(p2), "v"(p3), "v"(rb[st][0]), "v"(rb[st][1]), "v"(rb[st][2]));
+      (void)da, (void)db;
+    } else {
+      *reinterpret_cast<u32x4_t*>(da) = p1;
+      *reinterpret_cast<u32x4_t*>(da + PL) = p2;
+      *reinterpret_cast<u32x4_t*>(da + 2 * PL) = p3;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4_t*>(db + p * PL) = rb[st][p];
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4_t*>(db + p * PL) = rb[st][p];
+    }
   };
   using I0 = std::integral_constant<int, 0>;
   // register stage of tile t is t % D; LDS stage t & 1
@@ -969,30 +982,45 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32_bsplit_p(const float* __res
     const char* la = sA + P * STG + fa;
     const char* lb = sB + P * STG + fb;
     bf16x8_t a0[3], b0[3], a1[3], b1[3];
+    auto mm = [&](const bf16x8_t& x, const bf16x8_t& y, floatx16& c) {
+      if constexpr (ABL & 1) {
+        asm volatile("" ::"v"(x), "v"(y));                        // operands stay live (their loads are not dead), no matrix instruction
+      } else {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+      }
+    };
+    if constexpr (ABL & 16) {
+      u32x4_t z = {static_cast<uint32_t>(t), 0u, 0u, 0u};
+      asm volatile("" : "+v"(z));
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      a0[p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(la + p * PL + fc0));
-      b0[p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(lb + p * PL + fc0));
-    }
+      for (int p = 0; p < 3; ++p) a0[p] = b0[p] = a1[p] = b1[p] = __builtin_bit_cast(bf16x8_t, z);
+      (void)la, (void)lb;
+    } else {
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      a1[p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(la + p * PL + fc1));
-      b1[p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(lb + p * PL + fc1));
+      for (int p = 0; p < 3; ++p) {
+        a0[p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(la + p * PL + fc0));
+        b0[p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(lb + p * PL + fc0));
+      }
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        a1[p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(la + p * PL + fc1));
+        b1[p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(lb + p * PL + fc1));
+      }
     }
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[2], b0[0], acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0], b0[2], acc2, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[1], b0[1], acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[1], b0[0], acc2, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0], b0[1], acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0], b0[0], acc2, 0, 0, 0);
+    mm(a0[2], b0[0], acc);
+    mm(a0[0], b0[2], acc2);
+    mm(a0[1], b0[1], acc);
+    mm(a0[1], b0[0], acc2);
+    mm(a0[0], b0[1], acc);
+    mm(a0[0], b0[0], acc2);
     park(NX{}, P ^ 1);                                         // tile t+1 -> the other LDS stage (its last readers passed the barrier of step t-1)
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[2], b1[0], acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], b1[2], acc2, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[1], b1[1], acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[1], b1[0], acc2, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], b1[1], acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], b1[0], acc2, 0, 0, 0);
-    fetch(NX{}, t + 1 + D);
+    mm(a1[2], b1[0], acc);
+    mm(a1[0], b1[2], acc2);
+    mm(a1[1], b1[1], acc);
+    mm(a1[1], b1[0], acc2);
+    mm(a1[0], b1[1], acc);
+    mm(a1[0], b1[0], acc2);
+    if constexpr (!(ABL & 8)) fetch(NX{}, t + 1 + D);
     __syncthreads();
   };
   static_assert(D == 2 || D == 4, "register stages");
@@ -1437,7 +1465,20 @@ extern "C" int lcr_gemm_f32_bsplit(const float* A, const uint16_t* Bs, float* C,
   if (M == 0) return LCR_OK;
   GemmEpilogue ep{bias, rowdiv, seg_len, S, groups, stats};
   const int mt8 = (div_up(M, 64) + 7) / 8 * 8;
-  LCR_LAUNCH_TIMED(k_gemm_f32_bsplit_p, dim3(mt8 * div_up(N, 64)), dim3(256), 0, st, A, Bs, C, M, N, K, ep);
+  static const int abl = getenv("LCR_SPLIT_ABL") ? atoi(getenv("LCR_SPLIT_ABL")) : 0;      // timing ablations only (garbage results)
+  const dim3 grid(mt8 * div_up(N, 64)), block(256);
+  switch (abl) {
+    case 1: LCR_LAUNCH_TIMED(k_gemm_f32_bsplit_p<1>, grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
+    case 2: LCR_LAUNCH_TIMED(k_gemm_f32_bsplit_p<2>, grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
+    case 4: LCR_LAUNCH_TIMED(k_gemm_f32_bsplit_p<4>, grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
+    case 8: LCR_LAUNCH_TIMED(k_gemm_f32_bsplit_p<8>, grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
+    case 16: LCR_LAUNCH_TIMED(k_gemm_f32_bsplit_p<16>, grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
+    case 20: LCR_LAUNCH_TIMED(k_gemm_f32_bsplit_p<20>, grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
+    case 22: LCR_LAUNCH_TIMED(k_gemm_f32_bsplit_p<22>, grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
+    case 23: LCR_LAUNCH_TIMED(k_gemm_f32_bsplit_p<23>, grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
+    case 30: LCR_LAUNCH_TIMED(k_gemm_f32_bsplit_p<30>, grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
+    default: LCR_LAUNCH_TIMED(k_gemm_f32_bsplit_p<0>, grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
+  }
   return check_launch("lcr_gemm_f32_bsplit");
 }
 
