@@ -181,12 +181,14 @@ int lcr_precompute_batch_rows(const float* points0, int raw_row_floats, const in
 int lcr_gemm_f32(const float* A, const float* B, float* C, int64_t M, int N, int K, int transA, int transB,
                  const float* bias, const float* rowdiv, const int64_t* seg_len, int S, int groups, double* stats,
                  void* stream);
-/* The K-deep contractions on the bf16 matrix cores with fp32-faithful operands: an fp32 number is exactly the sum of three bf16 numbers;
- * lcr_split_bf16x3 writes those terms of a constant operand (weights [N,K]) as planes u16[3][N*K] once, lcr_gemm_f32_bsplit computes
- * C = A[M,K] . B[N,K]^T with A split on the fly and six of the nine cross products (the dropped ones are <= 2^-24 of a product), fp32
- * accumulation, same epilogue as lcr_gemm_f32.  K % 32 == 0.  Not bit-identical to lcr_gemm_f32 (other rounding points). */
+/* The K-deep contractions on the bf16 matrix cores with fp32-faithful operands: an fp32 number is exactly the sum of three bf16 numbers.
+ * lcr_split_bf16x3 writes those terms of an array as planes u16[3][n]; lcr_split_bf16x3_tiles writes them for a constant operand (weights
+ * [N,K], K % 32 == 0) in the layout the GEMM stages them in — u16[ceil(N/64)][K/32][3][64][32], i.e. ceil(N/64) * (K/32) * 12288 bytes — once;
+ * lcr_gemm_f32_bsplit computes C = A[M,K] . B[N,K]^T with A split on the fly and six of the nine cross products (the dropped ones are
+ * <= 2^-24 of a product), fp32 accumulation, same epilogue as lcr_gemm_f32.  Not bit-identical to lcr_gemm_f32 (other rounding points). */
 int lcr_split_bf16x3(const float* w, int64_t n, uint16_t* planes, void* stream);
-int lcr_gemm_f32_bsplit(const float* A, const uint16_t* Bs, float* C, int64_t M, int N, int K, const float* bias, const float* rowdiv,
+int lcr_split_bf16x3_tiles(const float* w, int N, int K, uint16_t* tiles, void* stream);
+int lcr_gemm_f32_bsplit(const float* A, const uint16_t* Bs_tiles, float* C, int64_t M, int N, int K, const float* bias, const float* rowdiv,
                         const int64_t* seg_len, int S, int groups, double* stats, void* stream);
 /* C = LeakyReLU(GroupNorm(A)) · B^T (+ bias, + statistics of C as above), A being the RAW [M,K] output of the layer whose sums are
  * a_stats[LCR_GN_REPLICAS,S,a_groups,2]: the normalisation happens while A's tiles are staged, the normalised tensor never
@@ -257,7 +259,7 @@ int lcr_groupnorm_apply(const float* x, const double* stats, const float* gamma,
 typedef struct LcrUnaryW {
   const float *w, *b;          /* nn.Linear weight [cout,cin], bias [cout] */
   const float *gn_w, *gn_b;    /* GroupNorm affine [cout] */
-  const uint16_t* w_split;     /* optional: lcr_split_bf16x3 planes of w (u16[3][cout*cin]); used for K-deep shapes (cin >= 288, cin % 32 == 0, cout >= 64) */
+  const uint16_t* w_split;     /* optional: lcr_split_bf16x3_tiles of w; used for K-deep shapes (cin >= 288, cin % 32 == 0, cout >= 64) */
 } LcrUnaryW;
 typedef struct LcrBlockW {     /* ResidualBlock (modules.py:148-225) */
   int   cin, cout, strided;
@@ -265,7 +267,7 @@ typedef struct LcrBlockW {     /* ResidualBlock (modules.py:148-225) */
   const float* kernel_points_host;
   const float *kp_w, *kp_b;    /* KPConv weights [15, cout/4, cout/4], bias [cout/4] */
   const float* kp_wt;          /* optional: the same weights as [cout/4, 15 * cout/4] (k-contiguous rows: the K-deep GEMM form); NULL = not provided */
-  const uint16_t* kp_wt_split; /* optional: lcr_split_bf16x3 planes of kp_wt: the contraction then runs on the bf16 matrix cores (lcr_gemm_f32_bsplit; cout/4 >= 64) */
+  const uint16_t* kp_wt_split; /* optional: lcr_split_bf16x3_tiles of kp_wt: the contraction then runs on the bf16 matrix cores (lcr_gemm_f32_bsplit; cout/4 >= 64) */
   const float *normconv_w, *normconv_b;
   LcrUnaryW unary1, unary2, shortcut;
 } LcrBlockW;

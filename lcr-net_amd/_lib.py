@@ -77,6 +77,7 @@ _SIGS = {
     "lcr_log_sinkhorn_ws_floats": (c_int, [c_i64, c_int, c_int, c_size_p]),
     "lcr_log_sinkhorn_form": (c_int, [c_i64, c_int, c_int, ctypes.POINTER(c_int)]),
     "lcr_split_bf16x3": (c_int, [c_vp, c_i64, c_vp, c_vp]),
+    "lcr_split_bf16x3_tiles": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "lcr_gemm_f32_bsplit": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "lcr_log_sinkhorn_ex": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_float, c_vp, ctypes.c_size_t, c_vp]),
     "lcr_top1_matching_ws_bytes": (c_int, [c_i64, c_int, c_int, c_size_p]),

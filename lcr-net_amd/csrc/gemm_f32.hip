@@ -869,28 +869,58 @@ __global__ __launch_bounds__(256) void k_split_bf16x3(const float* __restrict__ 
   }
 }
 
-// 64 x 64 tile, 2 x 2 wavefronts of 32 x 32 (the stage-3/4 contractions are 200-600 such tiles on 256 CUs: little but the workgroup itself
-// hides its latencies).  Both operands' planes in LDS, DOUBLE-buffered: the split + plane writes of tile t+1 run under the MFMAs of tile t and
-// a K-step has ONE barrier; A rows are fetched as full 128-B lines (4 lanes per row), tiles t+1 and t+2 in flight / parked in two register
-// stages.  What was measured on the way (tools/gemm_split_bench.py): single-buffered LDS with two barriers per step 1.00x the
-// fp32 kernel; larger tiles (128 x 64, 128 x 128) lose on the encoder's shapes (too few tiles) and win on 8192 x 1024 x 1024 (1.45x); A straight
-// from global memory into fragment registers (no LDS for A) 0.92x (32-B pieces of 32 different lines per load instruction); four register
-// stages: no change (not memory latency); 80-byte padded LDS rows: a third of the LDS cycles were bank conflicts of the 16-B WRITES
-// (rocprofv3 SQ_LDS_BANK_CONFLICT) — the XOR layout below: 1.07x -> 1.17x; two alternating accumulators: same speed, half the error; a
-// producer / consumer split of the workgroup (512 threads: four wavefronts only fetch + split + park, four only read fragments + MFMA): the same
-// time to the microsecond on every shape.  After all of it the matrix pipe is 38 % busy, the LDS array 39 %, VALU ~35 %.
-constexpr int D = 2;
+// The planes of a constant operand in the layout the GEMM stages them in: for every (64-column tile ct, K-step ks of 32) one contiguous
+// 12 KB block = [3 planes][64 rows][4 chunks of 8 bf16, chunk index XOR-ed with (row >> 2) & 3] — byte for byte the LDS image of the step,
+// so the kernel's B loads are full, consecutive 128-B lines (thread t of 256 fetches bytes [16 t, 16 t + 16) of each 4 KB plane block).
+// Rows beyond N are zero.  One thread per (row, chunk) pair of a block.
+__global__ __launch_bounds__(256) void k_split_bf16x3_tiles(const float* __restrict__ w, int N, int K, uint16_t* __restrict__ tiles) {
+  const int KS = K / GM_BK;
+  const int64_t blk = blockIdx.x;                               // ct * KS + ks
+  const int ct = static_cast<int>(blk / KS), ks = static_cast<int>(blk % KS);
+  const int row = threadIdx.x >> 2, kc = threadIdx.x & 3;
+  const int n = ct * 64 + row;
+  u32x4_t p1 = {0u, 0u, 0u, 0u}, p2 = p1, p3 = p1;
+  if (n < N) {
+    const float* src = w + static_cast<int64_t>(n) * K + ks * GM_BK + kc * 8;
+    const float4 x0 = ld4(src), x1 = ld4(src + 4);
+    uint32_t h1, h2, h3;
+    split2(x0.x, x0.y, h1, h2, h3), p1.x = h1, p2.x = h2, p3.x = h3;
+    split2(x0.z, x0.w, h1, h2, h3), p1.y = h1, p2.y = h2, p3.y = h3;
+    split2(x1.x, x1.y, h1, h2, h3), p1.z = h1, p2.z = h2, p3.z = h3;
+    split2(x1.z, x1.w, h1, h2, h3), p1.w = h1, p2.w = h2, p3.w = h3;
+  }
+  char* dst = reinterpret_cast<char*>(tiles) + blk * 12288 + row * 64 + ((kc ^ ((row >> 2) & 3)) << 4);
+  *reinterpret_cast<u32x4_t*>(dst) = p1;
+  *reinterpret_cast<u32x4_t*>(dst + 4096) = p2;
+  *reinterpret_cast<u32x4_t*>(dst + 8192) = p3;
+}
+
+// 64 x 64 tile, 2 x 2 wavefronts of 32 x 32 (the stage-3/4 contractions are 200-600 such tiles on 256 CUs).  Both operands' planes in LDS,
+// DOUBLE-buffered: the split + plane writes of tile t+1 run under the MFMAs of tile t and a K-step has ONE barrier; tiles t+1 and t+2 in flight /
+// parked in two register stages; every load instruction fetches full 128-B lines (A: 8 lanes per row; B: the pre-tiled planes, verbatim).
+// What was measured on the way (tools/gemm_split_bench.py), each against the fp32 K-deep kernel over the 13 bench shapes:
+// single-buffered LDS with two barriers per step 1.00x; larger tiles (128 x 64, 128 x 128 on 4 wavefronts; 128 x 64 on 8) lose on the encoder's
+// shapes (too few tiles) and win on 8192 x 1024 x 1024 (1.45x); A straight from global memory into fragment registers 0.92x; four register
+// stages: no change; 80-byte padded LDS rows: a third of the LDS cycles were bank conflicts of the 16-B WRITES (SQ_LDS_BANK_CONFLICT) — the XOR
+// layout: 1.07x -> 1.17x; two alternating accumulators: same speed, half the error; producer / consumer wavefronts (512 threads): same time;
+// ablations (LCR_SPLIT_ABL): loads alone 75 us and MFMAs alone 47 us of 4_2's 98 — the loads were bound by LINE REQUESTS (every A line asked
+// for twice, B rows half lines): full-line loads + tiled planes: loads alone 53 us — and the whole kernel still 100 (1.18x overall,
+// 1.23-1.28x on 2_2 / 3_2 / 4_2 / the stage-3/4 Linears): every ablation removes its own 10-25 %, i.e. the K-step is a latency chain
+// (arrival -> split -> park -> barrier -> fragment reads -> 12 MFMAs) that two to three workgroups per CU do not cover; matrix pipe 38 % busy.
 // ABL: timing ablations (tools/gemm_split_bench.py --abl): 1 no MFMAs, 2 no split arithmetic, 4 no plane stores, 8 no global loads in the
 // loop, 16 no fragment reads.  0 = the product; any other value computes garbage.
-template <int ABL>
-__global__ __launch_bounds__(256, 2) void k_gemm_f32_bsplit_p(const float* __restrict__ A, const uint16_t* __restrict__ Bs, float* __restrict__ C,
+// NWM: 32-row wavefront rows of the tile (2: 64 x 64, 256 threads — the product; 4: 128 x 64, 512 threads: measured 1.08x, not instantiated).
+template <int ABL, int NWM, int D = 2>
+__global__ __launch_bounds__(128 * NWM, 2) void k_gemm_f32_bsplit_p(const float* __restrict__ A, const uint16_t* __restrict__ Bs, float* __restrict__ C,
                                                              int64_t M, int N, int K, GemmEpilogue ep) {
   // LDS plane tile: 64 rows x 64 B (32 bf16), no padding; the four 16-B chunks of row r are XOR-ed with (r >> 2) & 3.  A ds_write_b128 is
   // serviced in groups of 8 consecutive lanes over 32 banks (two rows x four chunks: 128 distinct bytes), a ds_read_b128 in groups of 16 lanes
   // over 64 banks (16 different rows, one logical chunk: rows r, r+4, r+8, r+12 share a 64-B bank quadrant and get four different chunks).
   // (The 80-byte padded rows of the first version were conflict-free for the reads only: SQ_LDS_BANK_CONFLICT = a third of SQ_LDS_IDX_ACTIVE.)
-  constexpr int BM = 64, BN = 64, RS = 64, PL = 64 * RS, STG = 3 * PL;
-  __shared__ __attribute__((aligned(16))) char sA[2 * STG];
+  constexpr int BM = 32 * NWM, BN = 64, RS = 64, T = 128 * NWM, PLA = BM * RS, STGA = 3 * PLA, PL = 64 * RS;
+  constexpr int NPB = (768 + T - 1) / T;                        // 16-B pieces of the B planes per thread and K-step (3 planes x 64 rows x 4 chunks)
+  constexpr int STG = 3 * PL + (NPB * T - 768) * 16;            // a B stage + a dump area for the surplus pieces of the last round
+  __shared__ __attribute__((aligned(16))) char sA[2 * STGA];
   __shared__ __attribute__((aligned(16))) char sB[2 * STG];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = w >> 1, wn = w & 1;
@@ -900,54 +930,76 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32_bsplit_p(const float* __res
   const int64_t m0 = m_tile * BM;
   const int n0 = (slot % ntn) * BN;
   if (m0 >= M) return;
-  const int srow = threadIdx.x >> 2, skc = threadIdx.x & 3;
-  int64_t ga = m0 + srow;
-  ga = ga < M ? ga : M - 1;
-  int gb = n0 + srow;
-  gb = gb < N ? gb : N - 1;
-  const float* ap = A + ga * K + skc * 8;
-  const uint16_t* bp = Bs + static_cast<int64_t>(gb) * K + skc * 8;
-  const int64_t plane = static_cast<int64_t>(N) * K;
-  const int soff = srow * RS + ((skc ^ ((srow >> 2) & 3)) << 4);
+  // A staging: the tile is BM rows x eight 16-B pieces; thread t takes pieces t and t + T, i.e. (row t >> 3 (+ T/8), piece t & 7): the 8 lanes
+  // of a row fetch one full 128-B line per load instruction (with 4 lanes x two strided 16-B pieces per row, every line was requested twice,
+  // and the kernel is bound by line requests: see the ablations).  A piece = 4 floats -> 8 bytes per plane (ds_write_b64).
+  const int srow = threadIdx.x >> 3, spc = threadIdx.x & 7;
+  const float* ap[2];
+  int soff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = srow + j * (T / 8);
+    int64_t ga = m0 + r;
+    ga = ga < M ? ga : M - 1;                                  // duplicate rows only feed outputs that are never stored
+    ap[j] = A + ga * K + spc * 4;
+    soff[j] = r * RS + (((spc >> 1) ^ ((r >> 2) & 3)) << 4) + (spc & 1) * 8;
+  }
+  // B staging: the step's 12 KB block of the tiled planes, copied verbatim (it IS the LDS image): thread t takes bytes [16 (t + T j), + 16).
+  // 768 pieces over T threads: with T = 512 the second round has 256 surplus threads — they re-fetch piece t and park it in a dump area
+  // behind the stages instead of branching (a conditional load or store splits the K-step into basic blocks, and the compiler's s_waitcnt
+  // counting across blocks waits for the NEXT tile's loads too: the two-tile prefetch collapses to one).
+  const char* bp = reinterpret_cast<const char*>(Bs) + static_cast<int64_t>(n0 / 64) * (K / GM_BK) * 12288;
+  int bsrc[NPB], bdst[NPB];
+#pragma unroll
+  for (int j = 0; j < NPB; ++j) {
+    const int q = threadIdx.x + T * j;
+    bsrc[j] = (q < 768 ? q : threadIdx.x) * 16;
+    bdst[j] = q * 16;                                            // q >= 768 lands in the stage's dump area
+  }
   const int fsw = ((lane & 31) >> 2) & 3, fc0 = ((lane >> 5) ^ fsw) << 4, fc1 = (((lane >> 5) + 2) ^ fsw) << 4;     // chunks of K16 block 0 / 1
   const int fa = (wm * 32 + (lane & 31)) * RS, fb = (wn * 32 + (lane & 31)) * RS;
   floatx16 acc, acc2;                                          // two accumulators, alternating: consecutive MFMAs are independent
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f, acc2[r] = 0.f;
   const int nk = K / GM_BK;
-  f32x4_t ra[D][2];                                            // D register stages: tiles t+1 .. t+D in flight / parked
-  u32x4_t rb[D][3];
+  f32x4_t ra[D][2];                                            // D register stages: tiles t+1 .. t+D in flight / parked (two pieces each)
+  u32x4_t rb[D][NPB];
   auto fetch = [&](auto st_c, int t) {
     constexpr int st = decltype(st_c)::value;
-    const int ko = (t < nk ? t : nk - 1) * GM_BK;
-    ra[st][0] = *reinterpret_cast<const f32x4_t*>(ap + ko), ra[st][1] = *reinterpret_cast<const f32x4_t*>(ap + ko + 4);
+    const int tt = t < nk ? t : nk - 1;                         // the tail re-reads the last tile
+    ra[st][0] = *reinterpret_cast<const f32x4_t*>(ap[0] + tt * GM_BK), ra[st][1] = *reinterpret_cast<const f32x4_t*>(ap[1] + tt * GM_BK);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) rb[st][p] = *reinterpret_cast<const u32x4_t*>(bp + p * plane + ko);
+    for (int j = 0; j < NPB; ++j) rb[st][j] = *reinterpret_cast<const u32x4_t*>(bp + static_cast<int64_t>(tt) * 12288 + bsrc[j]);
   };
   auto park = [&](auto st_c, int lds_stage) {                  // register stage -> (split) -> LDS stage
     constexpr int st = decltype(st_c)::value;
-    u32x4_t p1, p2, p3;
-    uint32_t h1, h2, h3;
-    if constexpr (ABL & 2) {
-      p1 = __builtin_bit_cast(u32x4_t, ra[st][0]), p2 = __builtin_bit_cast(u32x4_t, ra[st][1]), p3 = p1;
-      (void)h1, (void)h2, (void)h3;
-    } else {
-      split2(ra[st][0].x, ra[st][0].y, h1, h2, h3), p1.x = h1, p2.x = h2, p3.x = h3;
-      split2(ra[st][0].z, ra[st][0].w, h1, h2, h3), p1.y = h1, p2.y = h2, p3.y = h3;
-      split2(ra[st][1].x, ra[st][1].y, h1, h2, h3), p1.z = h1, p2.z = h2, p3.z = h3;
-      split2(ra[st][1].z, ra[st][1].w, h1, h2, h3), p1.w = h1, p2.w = h2, p3.w = h3;
-    }
-    char* da = sA + lds_stage * STG + soff;
-    char* db = sB + lds_stage * STG + soff;
-    if constexpr (ABL & 4) {                                      // keep the values alive without storing them
-      asm volatile("" ::"v"(p1), "v"(p2), "v"(p3), "v"(rb[st][0]), "v"(rb[st][1]), "v"(rb[st][2]));
-      (void)da, (void)db;
-    } else {
-      *reinterpret_cast<u32x4_t*>(da) = p1;
-      *reinterpret_cast<u32x4_t*>(da + PL) = p2;
-      *reinterpret_cast<u32x4_t*>(da + 2 * PL) = p3;
+    char* da = sA + lds_stage * STGA;
+    char* db = sB + lds_stage * STG;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4_t*>(db + p * PL) = rb[st][p];
+    for (int j = 0; j < 2; ++j) {
+      uint32_t h1, h2, h3, g1, g2, g3;
+      if constexpr (ABL & 2) {
+        h1 = __float_as_uint(ra[st][j].x), h2 = __float_as_uint(ra[st][j].y), h3 = h1, g1 = __float_as_uint(ra[st][j].z), g2 = __float_as_uint(ra[st][j].w), g3 = g1;
+      } else {
+        split2(ra[st][j].x, ra[st][j].y, h1, h2, h3);
+        split2(ra[st][j].z, ra[st][j].w, g1, g2, g3);
+      }
+      if constexpr (ABL & 4) {
+        asm volatile("" ::"v"(h1), "v"(h2), "v"(h3), "v"(g1), "v"(g2), "v"(g3));
+      } else {
+        *reinterpret_cast<uint2*>(da + soff[j]) = make_uint2(h1, g1);
+        *reinterpret_cast<uint2*>(da + PLA + soff[j]) = make_uint2(h2, g2);
+        *reinterpret_cast<uint2*>(da + 2 * PLA + soff[j]) = make_uint2(h3, g3);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NPB; ++j) {
+      const u32x4_t v = rb[st][j];
+      if constexpr (ABL & 4) {
+        asm volatile("" ::"v"(v));
+      } else {
+        *reinterpret_cast<u32x4_t*>(db + bdst[j]) = v;
+      }
     }
   };
   using I0 = std::integral_constant<int, 0>;
@@ -979,7 +1031,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32_bsplit_p(const float* __res
   auto step = [&](auto lds_c, auto reg_c, int t) {
     constexpr int P = decltype(lds_c)::value;                  // t & 1
     using NX = std::integral_constant<int, (decltype(reg_c)::value + 1) % D>;      // register stage of tile t+1
-    const char* la = sA + P * STG + fa;
+    const char* la = sA + P * STGA + fa;
     const char* lb = sB + P * STG + fb;
     bf16x8_t a0[3], b0[3], a1[3], b1[3];
     auto mm = [&](const bf16x8_t& x, const bf16x8_t& y, floatx16& c) {
@@ -998,12 +1050,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32_bsplit_p(const float* __res
     } else {
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
-        a0[p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(la + p * PL + fc0));
+        a0[p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(la + p * PLA + fc0));
         b0[p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(lb + p * PL + fc0));
       }
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
-        a1[p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(la + p * PL + fc1));
+        a1[p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(la + p * PLA + fc1));
         b1[p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(lb + p * PL + fc1));
       }
     }
@@ -1048,7 +1100,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32_bsplit_p(const float* __res
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
   floatx16 accs[1] = {acc};
-  gemm_epilogue<BM, BN, 2, 2, 1>(accs, C, M, N, m0, n0, m_tile, ep, bias_v, blk_first, blk_seg_start, blk_seg_end, wm, wn, lane);
+  gemm_epilogue<BM, BN, NWM, 2, 1>(accs, C, M, N, m0, n0, m_tile, ep, bias_v, blk_first, blk_seg_start, blk_seg_end, wm, wn, lane);
 }
 
 // ---- stream-K form of the K-deep contractions ---------------------------------------------------------------------------
@@ -1448,11 +1500,21 @@ extern "C" int lcr_split_bf16x3(const float* w, int64_t n, uint16_t* planes, voi
   return check_launch("lcr_split_bf16x3");
 }
 
-// C = A[M,K] · B[N,K]^T with B given as the bf16 planes of lcr_split_bf16x3 ([3][N][K]); epilogue as lcr_gemm_f32.
+// weights [N,K] (K % 32 == 0) -> the tiled planes lcr_gemm_f32_bsplit takes: u16[ceil(N/64)][K/32][3][64][32] (12 KB per block)
+extern "C" int lcr_split_bf16x3_tiles(const float* w, int N, int K, uint16_t* tiles, void* stream) {
+  if (!w || !tiles || N < 1 || K < GM_BK || K % GM_BK != 0 || reinterpret_cast<uintptr_t>(w) % 16 != 0 || reinterpret_cast<uintptr_t>(tiles) % 16 != 0) {
+    set_error("lcr_split_bf16x3_tiles: needs K %% 32 == 0 and 16-byte aligned buffers");
+    return LCR_EARG;
+  }
+  hipLaunchKernelGGL(k_split_bf16x3_tiles, dim3(div_up(N, 64) * (K / GM_BK)), dim3(256), 0, static_cast<hipStream_t>(stream), w, N, K, tiles);
+  return check_launch("lcr_split_bf16x3_tiles");
+}
+
+// C = A[M,K] · B[N,K]^T with B given as the TILED bf16 planes of lcr_split_bf16x3_tiles; epilogue as lcr_gemm_f32.
 extern "C" int lcr_gemm_f32_bsplit(const float* A, const uint16_t* Bs, float* C, int64_t M, int N, int K, const float* bias, const float* rowdiv,
                                    const int64_t* seg_len, int S, int groups, double* stats, void* stream) {
   if (!A || !Bs || !C || M < 0 || N <= 0 || K <= 0 || K % GM_BK != 0 || reinterpret_cast<uintptr_t>(A) % 16 != 0 || reinterpret_cast<uintptr_t>(Bs) % 16 != 0 ||
-      (static_cast<int64_t>(N) * K) % 8 != 0) {
+      K < GM_BK) {
     set_error("lcr_gemm_f32_bsplit: needs K %% 32 == 0 and 16-byte aligned operands");
     return LCR_EARG;
   }
@@ -1468,16 +1530,14 @@ extern "C" int lcr_gemm_f32_bsplit(const float* A, const uint16_t* Bs, float* C,
   static const int abl = getenv("LCR_SPLIT_ABL") ? atoi(getenv("LCR_SPLIT_ABL")) : 0;      // timing ablations only (garbage results)
   const dim3 grid(mt8 * div_up(N, 64)), block(256);
   switch (abl) {
-    case 1: LCR_LAUNCH_TIMED(k_gemm_f32_bsplit_p<1>, grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
-    case 2: LCR_LAUNCH_TIMED(k_gemm_f32_bsplit_p<2>, grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
-    case 4: LCR_LAUNCH_TIMED(k_gemm_f32_bsplit_p<4>, grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
-    case 8: LCR_LAUNCH_TIMED(k_gemm_f32_bsplit_p<8>, grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
-    case 16: LCR_LAUNCH_TIMED(k_gemm_f32_bsplit_p<16>, grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
-    case 20: LCR_LAUNCH_TIMED(k_gemm_f32_bsplit_p<20>, grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
-    case 22: LCR_LAUNCH_TIMED(k_gemm_f32_bsplit_p<22>, grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
-    case 23: LCR_LAUNCH_TIMED(k_gemm_f32_bsplit_p<23>, grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
-    case 30: LCR_LAUNCH_TIMED(k_gemm_f32_bsplit_p<30>, grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
-    default: LCR_LAUNCH_TIMED(k_gemm_f32_bsplit_p<0>, grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
+    case 1: LCR_LAUNCH_TIMED((k_gemm_f32_bsplit_p<1, 2>), grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
+    case 2: LCR_LAUNCH_TIMED((k_gemm_f32_bsplit_p<2, 2>), grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
+    case 4: LCR_LAUNCH_TIMED((k_gemm_f32_bsplit_p<4, 2>), grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
+    case 8: LCR_LAUNCH_TIMED((k_gemm_f32_bsplit_p<8, 2>), grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
+    case 16: LCR_LAUNCH_TIMED((k_gemm_f32_bsplit_p<16, 2>), grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
+    case 23: LCR_LAUNCH_TIMED((k_gemm_f32_bsplit_p<23, 2>), grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
+    case 30: LCR_LAUNCH_TIMED((k_gemm_f32_bsplit_p<30, 2>), grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
+    default: LCR_LAUNCH_TIMED((k_gemm_f32_bsplit_p<0, 2>), grid, block, 0, st, A, Bs, C, M, N, K, ep); break;
   }
   return check_launch("lcr_gemm_f32_bsplit");
 }

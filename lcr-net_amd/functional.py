@@ -154,20 +154,35 @@ def gemm_split_ok(N, K):
 
 
 def split_bf16x3(w):
-    """The three bf16 terms of a constant fp32 operand [N,K] as planes int16 [3, N, K] (lcr_split_bf16x3; made once per weight)."""
+    """The three bf16 terms of a constant fp32 operand [N,K] (K % 32 == 0) in the tiled layout lcr_gemm_f32_bsplit stages them in:
+    int16 [ceil(N/64), K/32, 3, 64, 32] (lcr_split_bf16x3_tiles; made once per weight).  The tensor carries N as `.lcr_n`."""
     w = w.detach().contiguous()
-    planes = torch.empty((3,) + tuple(w.shape), dtype=torch.int16, device=w.device)
-    _lib.check(_lib.lib().lcr_split_bf16x3(_lib.ptr(w), w.numel(), _lib.ptr(planes), _lib.stream_ptr(w.device)), "lcr_split_bf16x3")
-    return planes
+    N, K = w.shape
+    assert K % 32 == 0
+    tiles = torch.empty(((N + 63) // 64, K // 32, 3, 64, 32), dtype=torch.int16, device=w.device)
+    _lib.check(_lib.lib().lcr_split_bf16x3_tiles(_lib.ptr(w), int(N), int(K), _lib.ptr(tiles), _lib.stream_ptr(w.device)), "lcr_split_bf16x3_tiles")
+    tiles.lcr_n = int(N)
+    return tiles
+
+
+def unsplit_bf16x3(tiles):
+    """Inverse view of split_bf16x3 for tests: the three terms as float32 [3, N, K] (un-tiled, un-swizzled)."""
+    CT, KS = tiles.shape[0], tiles.shape[1]
+    t = tiles.view(CT, KS, 3, 64, 4, 8)
+    row = torch.arange(64, device=tiles.device)
+    phys = torch.arange(4, device=tiles.device)[None, :] ^ ((row >> 2) & 3)[:, None]          # [row, logical chunk] -> physical chunk
+    t = torch.gather(t, 4, phys.view(1, 1, 1, 64, 4, 1).expand(CT, KS, 3, 64, 4, 8))
+    t = t.reshape(CT, KS, 3, 64, 32).permute(2, 0, 3, 1, 4).reshape(3, CT * 64, KS * 32)
+    return t[:, :tiles.lcr_n].contiguous().view(torch.bfloat16).float()
 
 
 def gemm_bsplit(a, planes, bias=None, rowdiv=None, seg_len=None, groups=0):
     """C = A[M,K] . B[N,K]^T with B given as the planes of split_bf16x3 (same epilogue and return value as gemm())."""
     _lib.require_cuda(a, planes)
-    assert a.dtype == torch.float32 and a.is_contiguous() and planes.dtype == torch.int16 and planes.is_contiguous() and planes.dim() == 3
+    assert a.dtype == torch.float32 and a.is_contiguous() and planes.dtype == torch.int16 and planes.is_contiguous() and planes.dim() == 5
     M, K = a.shape
-    N = planes.shape[1]
-    assert planes.shape[2] == K, "inner dimensions differ"
+    N = planes.lcr_n
+    assert planes.shape[1] * 32 == K and planes.shape[0] == (N + 63) // 64, "inner dimensions differ"
     c = torch.empty((M, N), dtype=torch.float32, device=a.device)
     stats, S = None, 0
     if groups:

@@ -8,10 +8,15 @@ pytestmark = pytest.mark.gpu
 
 
 def _split(b):
+    from lcrnet_amd import functional as F
+    return F.split_bf16x3(b)
+
+
+def _planar(x):
     from lcrnet_amd import _lib
-    n = b.numel()
-    planes = torch.empty(3 * n, dtype=torch.int16, device=b.device)
-    _lib.check(_lib.lib().lcr_split_bf16x3(_lib.ptr(b), n, _lib.ptr(planes), _lib.stream_ptr(b.device)), "lcr_split_bf16x3")
+    n = x.numel()
+    planes = torch.empty(3 * n, dtype=torch.int16, device=x.device)
+    _lib.check(_lib.lib().lcr_split_bf16x3(_lib.ptr(x), n, _lib.ptr(planes), _lib.stream_ptr(x.device)), "lcr_split_bf16x3")
     return planes
 
 
@@ -21,10 +26,15 @@ def test_three_bf16_terms_are_the_fp32_number():
     g = torch.Generator(device="cuda").manual_seed(1)
     x = torch.randn(100001, device="cuda", generator=g) * torch.exp(torch.randn(100001, device="cuda", generator=g) * 8)
     x[:6] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e38, 1.0e-30], device="cuda")
-    pl = _split(x).view(3, -1).view(torch.bfloat16).float()
+    pl = _planar(x).view(3, -1).view(torch.bfloat16).float()
     assert torch.equal(pl[0], x.to(torch.bfloat16).float())
     assert torch.equal((pl[0] + pl[1]) + pl[2], x)
     assert (pl[1].abs() <= pl[0].abs() * 2.0 ** -8 + 1e-45).all() and (pl[2].abs() <= pl[0].abs() * 2.0 ** -16 + 1e-45).all()
+    # the tiled form the GEMM takes (lcr_split_bf16x3_tiles) holds the same terms: [N,K] with N not a multiple of 64
+    from lcrnet_amd import functional as F
+    w = x[:100 * 352].view(100, 352).contiguous()
+    t = F.unsplit_bf16x3(F.split_bf16x3(w))
+    assert t.shape == (3, 100, 352) and torch.equal(t, _planar(w).view(3, 100, 352).view(torch.bfloat16).float())
 
 
 @pytest.mark.parametrize("M,N,K,rowdiv,groups", [(5000, 96, 352, True, 0), (6479, 256, 3840, True, 32), (19061, 128, 512, False, 32), (700, 64, 480, True, 32),
@@ -79,7 +89,7 @@ def test_split_gemm_against_fp64(M, N, K, rowdiv, groups):
 def test_split_gemm_rejects_bad_shapes():
     from lcrnet_amd import _lib
     a = torch.zeros(64, 40, device="cuda")
-    pl = torch.zeros(3 * 64 * 40, dtype=torch.int16, device="cuda")
+    pl = torch.zeros(3 * 64 * 64, dtype=torch.int16, device="cuda")
     c = torch.empty(64, 64, device="cuda")
     rc = _lib.lib().lcr_gemm_f32_bsplit(_lib.ptr(a), _lib.ptr(pl), _lib.ptr(c), 64, 64, 40, None, None, None, 0, 0, None, _lib.stream_ptr(a.device))
     assert rc != 0                                            # K % 32 != 0

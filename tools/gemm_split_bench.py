@@ -33,10 +33,9 @@ def main():
         div = (torch.rand(M, device=dev, generator=g) * 40 + 1).floor() if rd else None
         seg = torch.tensor([M // 8 - 3] * 7 + [M - 7 * (M // 8 - 3)], dtype=torch.int64, device=dev)
         gr = 32 if N % 32 == 0 and ((N // 32) & (N // 32 - 1)) == 0 else 0
-        planes = torch.empty(3 * N * K, dtype=torch.int16, device=dev)
-        _lib.check(L.lcr_split_bf16x3(_lib.ptr(b), N * K, _lib.ptr(planes), sp(b)), "split")
+        planes = F.split_bf16x3(b)
         # the planes really are an exact three-term split
-        pl = planes.view(3, N, K).view(torch.bfloat16).float()
+        pl = F.unsplit_bf16x3(planes)
         assert torch.equal(pl[0] + pl[1] + pl[2], b) and torch.equal(pl[0], b.to(torch.bfloat16).float())
         c0 = torch.empty(M, N, device=dev)
         c1 = torch.empty(M, N, device=dev)
