@@ -153,6 +153,18 @@ def gemm_split_ok(N, K):
     return K >= 288 and K % 32 == 0 and N >= 64
 
 
+# Derived weight tensors (transposed KPConv weights, bf16 planes, the native encoder's table) are built lazily by whichever host thread gets
+# there first, on ITS current stream, and then used by every thread on other streams: the builder holds this lock and drains its stream before
+# publishing, so a second worker (PairPipeline runs two) never launches a GEMM on a half-written operand.
+derived_lock = threading.RLock()
+
+
+def publish_derived(t):
+    """Call on a freshly built derived tensor before storing it where other threads / streams can see it."""
+    torch.cuda.current_stream(t.device).synchronize()
+    return t
+
+
 def split_bf16x3(w):
     """The three bf16 terms of a constant fp32 operand [N,K] (K % 32 == 0) in the tiled layout lcr_gemm_f32_bsplit stages them in:
     int16 [ceil(N/64), K/32, 3, 64, 32] (lcr_split_bf16x3_tiles; made once per weight).  The tensor carries N as `.lcr_n`."""

@@ -47,16 +47,24 @@ class KPConv(nn.Module):
         for both operands).  Same products, same summation order: the result does not change."""
         w = self.weights
         key = (w.data_ptr(), w._version, w.device)
-        if self._wt_cache is None or self._wt_cache[0] != key:
-            self._wt_cache = (key, w.detach().reshape(self.kernel_size * self.in_channels, self.out_channels).t().contiguous())
-        return self._wt_cache[1]
+        c = self._wt_cache
+        if c is None or c[0] != key:
+            with F.derived_lock:
+                c = self._wt_cache
+                if c is None or c[0] != key:
+                    wt = w.detach().reshape(self.kernel_size * self.in_channels, self.out_channels).t().contiguous()
+                    c = self._wt_cache = (key, F.publish_derived(wt) if wt.is_cuda else wt)
+        return c[1]
 
     def weights_t_split(self):
         """The three bf16 terms of weights_t() (functional.split_bf16x3), cached with it: the contraction on the bf16 matrix cores."""
         wt = self.weights_t()
         c = getattr(self, "_wts_cache", None)
         if c is None or c[0] is not wt:
-            c = self._wts_cache = (wt, F.split_bf16x3(wt))
+            with F.derived_lock:
+                c = getattr(self, "_wts_cache", None)
+                if c is None or c[0] is not wt:
+                    c = self._wts_cache = (wt, F.publish_derived(F.split_bf16x3(wt)))
         return c[1]
 
     def kernel_points_host(self):

@@ -66,7 +66,10 @@ class UnaryBlock(nn.Module):
         key = (w.data_ptr(), w._version, w.device)
         c = getattr(self, "_ws_cache", None)
         if c is None or c[0] != key:
-            c = self._ws_cache = (key, F.split_bf16x3(w))
+            with F.derived_lock:
+                c = getattr(self, "_ws_cache", None)
+                if c is None or c[0] != key:
+                    c = self._ws_cache = (key, F.publish_derived(F.split_bf16x3(w)))
         return c[1]
 
     def raw(self, x, ctx):

@@ -93,8 +93,16 @@ def table_for(enc):
     key = _key(enc)
     cached = getattr(enc, "_native_table", None)
     if cached is None or cached[0] != key:
-        cached = (key, EncoderTable(enc))
-        enc._native_table = cached
+        from . import functional as F
+        with F.derived_lock:                              # one builder; the table's derived tensors are complete before it is published
+            cached = getattr(enc, "_native_table", None)
+            if cached is None or cached[0] != key:
+                tab = EncoderTable(enc)
+                dev = next(enc.parameters()).device
+                if dev.type == "cuda":
+                    torch.cuda.current_stream(dev).synchronize()
+                cached = (key, tab)
+                enc._native_table = cached
     return cached[1]
 
 
