@@ -53,6 +53,7 @@ def parse():
                     "barrier + synchronize); the line reports the MEDIAN block, ms_per_step_min / _max the spread")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split-ab", action="store_true", help="skip the secondary A/B block with the split-bf16 K-deep GEMMs")
+    ap.add_argument("--no-lazy-ab", action="store_true", help="skip the secondary block without the 3 decoder-only upsampling searches")
     ap.add_argument("--no-h2d", action="store_true", help="skip the secondary `with_h2d` measurement (host [N,4] batches uploaded inside the pipeline)")
     ap.add_argument("--no-upsampling", action="store_true", help="skip the 3 decoder-only upsampling searches")
     ap.add_argument("--no-overlap", action="store_true", help="run pre-processing and encoder on one stream (no pipelining)")
@@ -454,6 +455,41 @@ def main():
                     "over_headline": round(dt / dts_m, 4), "descriptors_max_abs_diff_vs_fp32_mfma": float((desc_s - desc).abs().max()),
                     "what": "same steps with LCR_GEMM_SPLIT=1: K-deep GEMMs as 3 x bf16 terms / 6 products on the bf16 matrix cores (fp32-faithful, "
                             "error vs fp64 below the fp32-MFMA kernel's own); opt-in, NOT the headline; median of %d blocks" % len(dts)}
+    # ---- secondary, not the headline: the descriptor-only deployment.  The three upsampling lists are consumed by the KPDecoder of the pair model
+    # only (backbone4.py:347-367); loop detection (BASELINE configs 2-4) never reads them ("compute them lazily"), and
+    # DescriptorPipeline's default is not to build them.  The headline keeps all ten searches of the reference's collate (§8d); this block runs
+    # the same steps with the seven the descriptor path consumes.
+    lazy = None
+    if not args.no_upsampling and not args.no_lazy_ab and not (args.no_overlap or args.no_thread):
+        pipe_main, pipe = pipe, None
+        pipe7 = DescriptorPipeline(model, VOXEL, RADIUS, NUM_STAGES, LIMITS, upsampling=False, raw_voxel=VOXEL, overlap=True, producer_thread=True,
+                                   pre_workers=args.pre_workers, depth=args.depth)
+        pipe7.enable_dual_encoder(int(os.environ.get("LCR_ENC_STREAMS", "2")))
+        pipe = pipe7
+        run_steps(8)
+        dts = []
+        for rep in range(min(R, 3)):
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            desc_7 = run_steps(args.steps)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            d = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([d], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                d = float(t.item())
+            dts.append(d)
+        pipe = pipe_main
+        pipe7.close()
+        d7 = sorted(dts)[(len(dts) - 1) // 2]
+        lazy = {"value": round(world * BATCH * args.steps / d7, 3), "unit": "scans/s", "ms_per_step": round(d7 / args.steps * 1e3, 3),
+                "over_headline": round(dt / d7, 4), "descriptors_max_abs_diff_vs_headline": float((desc_7 - desc).abs().max()),
+                "what": "same steps with the 7 searches the descriptor path consumes (the 3 decoder-only upsampling lists not built: DescriptorPipeline's "
+                        "default for loop detection); NOT the headline, which keeps the reference collate's 10; median of %d blocks" % len(dts)}
     iso = None
     if rank == 0 and not os.environ.get("LCR_BENCH_NO_KTIMER"):
         # Every distinct batch once more with NOTHING else on the GPU (one stream, one batch in flight, outside the timed region) and
@@ -605,6 +641,8 @@ def main():
             line["with_h2d"] = with_h2d
         if split_ab is not None:
             line["split_bf16_gemm_ab"] = split_ab
+        if lazy is not None:
+            line["descriptor_only_7_searches"] = lazy
         if F.gemm_split_enabled():
             line["dtype"] = "f32 (K-deep GEMMs: fp32 operands as 3 bf16 terms, 6 products on the bf16 matrix cores, fp32 accumulation)"
         if not args.no_cpu_baseline and world == 1:

@@ -251,10 +251,10 @@ __device__ __forceinline__ void rq_chunks(const RqRuns R, const float4* __restri
   const int lane = threadIdx.x & 63;
   float4 P[U];
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    P[u] = sorted[rq_slot(R, min(t0 + 64 * u + lane, total - 1))];     // all loads of the trip in flight together
-    asm volatile("" : "+v"(P[u].x), "+v"(P[u].y), "+v"(P[u].z), "+v"(P[u].w));   // one 16-B load: keep .w out of the conditional store block
-  }
+  for (int u = 0; u < U; ++u) P[u] = sorted[rq_slot(R, min(t0 + 64 * u + lane, total - 1))];     // all loads of the trip in flight together
+#pragma unroll
+  for (int u = 0; u < U; ++u)      // one 16-B load each: keep .w out of the conditional store block.  AFTER the last load is issued: an asm
+    asm volatile("" : "+v"(P[u].x), "+v"(P[u].y), "+v"(P[u].z), "+v"(P[u].w));   // that "uses" P[u] right behind its load made every load wait for itself (vmcnt(0) per chunk)
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const float dx = fsub(qx, P[u].x), dy = fsub(qy, P[u].y), dz = fsub(qz, P[u].z);
