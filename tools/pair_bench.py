@@ -83,8 +83,9 @@ def main():
     results = {}
     for P in args.pairs_per_call:
         with PairPipeline(m, neighbor_limits=limits, workers=args.workers, pairs_per_call=P) as pp:
-            for _ in pp.run(work):                                 # warm-up: ONE FULL untimed pass — the timed passes then see exactly the stack
-                pass                                              # shapes the caching allocator already holds blocks for (a warm-up over a prefix
+            for _ in pp.run(work + work):                          # warm-up: TWO FULL untimed passes — the timed passes then see exactly the stack
+                pass                                              # shapes the caching allocator already holds blocks for (a warm-up over a prefix, or one
+                                                                  # pass only — two workers interleave differently the second time —
                                                                   # left the first timed pass growing the pool: round 3's 305 / 389 pairs/s minima)
             torch.cuda.synchronize()
             if dist is not None:
