@@ -6,6 +6,9 @@ consume this package's outputs unchanged.
     query frame 101..C-2 in ascending distance; queries whose database holds fewer than k frames are filled the way faiss
     fills them (j = -1, d = FLT_MAX)                                            — eval_loop_detection_overlap_dataset.py:183-219
   * demo text line        `pos anc L2 r11 … t3`                                 — demo/demo.py:80-81
+  * raw scans             KITTI velodyne `.bin` (little-endian f32 [N,4]: x, y, z, intensity — data/Kitti/downsample_pcd.py:21) and the
+    reference's down-sampled `.npy` ([N,4] xyzi, :29-38; dataset_overlap_online.py:245 slices [:, :3] on the host) as PINNED host rows for
+    the pipeline's ingest leg (pipeline.HostIngest), which consumes the four columns unsliced
 """
 import glob
 import os
@@ -13,6 +16,36 @@ import os
 import numpy as np
 
 FAISS_EMPTY_DISTANCE = np.float32(3.4028234663852886e38)
+
+
+def load_scan_rows(path, pin=True):
+    """A scan file -> contiguous float32 host rows [N, C] (C = 4 for velodyne `.bin` and xyzi `.npy`, 3 for xyz `.npy`) as a torch tensor,
+    pinned when `pin` and a GPU runtime is there: ready for `DescriptorPipeline.run` (host batches), no `[:, :3]` copy."""
+    import torch
+    if path.endswith(".bin"):
+        a = np.fromfile(path, dtype="<f4")
+        if a.size % 4:
+            raise ValueError("%s: %d floats is not a whole number of velodyne rows (x, y, z, intensity)" % (path, a.size))
+        a = a.reshape(-1, 4)
+    else:
+        a = np.load(path)
+        if a.ndim != 2 or a.shape[1] < 3:
+            raise ValueError("%s: expected [N, C >= 3] points, got %s" % (path, a.shape))
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    if pin and torch.cuda.is_available():
+        t = t.pin_memory()
+    return t
+
+
+def stack_scan_rows(rows):
+    """[t_0 [N_0,C], ...] -> (points [sum N, C], lengths i64 [B]) host batch for `DescriptorPipeline.run` (pinned if the inputs are)."""
+    import torch
+    if len({int(r.shape[1]) for r in rows}) != 1:
+        raise ValueError("scans of one batch must have the same number of columns")
+    pts = torch.cat(list(rows))
+    if all(r.is_pinned() for r in rows) and not pts.is_pinned():
+        pts = pts.pin_memory()
+    return pts, torch.tensor([int(r.shape[0]) for r in rows], dtype=torch.int64)
 
 
 def save_descriptor(output_dir, seq_id, idx, anc_global):

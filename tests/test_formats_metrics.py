@@ -1,5 +1,6 @@
 """CPU: on-disk formats and metric definitions (host logic) — round trips and hand-checkable cases."""
 import numpy as np
+import pytest
 
 from lcrnet_amd import evaluation as ev
 from lcrnet_amd import io_formats as io
@@ -70,3 +71,25 @@ def test_collates_mirror_the_reference_layout_without_precompute():
     a = {"anc_points": rng.random((6, 3)).astype(np.float32), "anc_feats": np.ones((6, 1), np.float32), "frame": 17}
     got = test_loop_detection_collate_fn_stack_mode_online([a], 4, 0.3, 1.275, [8, 8, 8, 8], precompute_data=False)
     assert got["lengths"].tolist() == [6] and got["features"].shape == (6, 1) and got["frame"] == 17 and got["batch_size"] == 1
+
+
+def test_scan_row_readers(tmp_path):
+    """KITTI velodyne .bin (f32 [N,4]) and xyzi / xyz .npy files -> contiguous float32 host rows, stacked into a host batch."""
+    import torch
+    from lcrnet_amd import io_formats as io
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((1234, 4)).astype(np.float32)
+    b = rng.standard_normal((77, 4)).astype(np.float32)
+    a.astype("<f4").tofile(tmp_path / "000000.bin")
+    np.save(tmp_path / "000001.npy", b)
+    ra, rb = io.load_scan_rows(str(tmp_path / "000000.bin"), pin=False), io.load_scan_rows(str(tmp_path / "000001.npy"), pin=False)
+    assert ra.dtype == torch.float32 and ra.is_contiguous() and np.array_equal(ra.numpy(), a) and np.array_equal(rb.numpy(), b)
+    pts, lens = io.stack_scan_rows([ra, rb])
+    assert pts.shape == (1311, 4) and lens.tolist() == [1234, 77] and lens.dtype == torch.int64
+    np.save(tmp_path / "xyz.npy", a[:, :3].astype(np.float64))             # other dtypes are converted, 3 columns pass through
+    assert io.load_scan_rows(str(tmp_path / "xyz.npy"), pin=False).shape == (1234, 3)
+    (tmp_path / "bad.bin").write_bytes(b"\0" * 20)
+    with pytest.raises(ValueError):
+        io.load_scan_rows(str(tmp_path / "bad.bin"))
+    with pytest.raises(ValueError):
+        io.stack_scan_rows([ra, io.load_scan_rows(str(tmp_path / "xyz.npy"), pin=False)])

@@ -1,7 +1,8 @@
 """Whole native collate (raw scans -> 0.3 m voxels -> 3 subsamples -> 10 searches, one native call) vs the C++ oracle on random
 stacks of decimated synthetic scans under random rigid motions (large translations stress the fp32 voxel arithmetic):
-    python tools/fuzz_collate.py FIRST_SEED LAST_SEED [dense]"""
-import sys, os, time
+    python tools/fuzz_collate.py FIRST_SEED LAST_SEED [dense] [--json FILE] [--max-seconds S]
+Odd seeds go in as KITTI velodyne rows f32[N,4] (x, y, z + a junk fourth column): the strided raw-scan ingest of round 4."""
+import sys, os, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 import numpy as np, torch
@@ -9,6 +10,7 @@ from oracle import ops as O
 import lcrnet_amd.synthetic as synthetic
 from lcrnet_amd.data import precompute_batch_native
 t0 = time.time(); bad = []; n = 0
+MAXS = float(sys.argv[sys.argv.index("--max-seconds") + 1]) if "--max-seconds" in sys.argv else 900.0
 base = {i: synthetic.synthetic_scan(i) for i in range(6)}
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     rng = np.random.default_rng(seed)
@@ -28,7 +30,8 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     try:
         p0, l0 = O.grid_subsample(xyz, lens, 0.3)
         want = O.precompute_data_stack_mode(p0, l0, 4, 0.3, 1.275, limits)
-        got = precompute_batch_native(torch.from_numpy(xyz).cuda(), torch.from_numpy(lens).cuda(), 4, 0.3, 1.275, limits, raw_voxel=0.3)
+        rows = np.concatenate([xyz, rng.standard_normal((len(xyz), 1)).astype(np.float32) * 1e3], axis=1) if seed % 2 else xyz
+        got = precompute_batch_native(torch.from_numpy(np.ascontiguousarray(rows)).cuda(), torch.from_numpy(lens).cuda(), 4, 0.3, 1.275, limits, raw_voxel=0.3)
         torch.cuda.synchronize()
         ok = True
         for key in ("points", "lengths", "neighbors", "subsampling", "upsampling"):
@@ -46,5 +49,9 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
             bad.append(seed); print("MISMATCH seed", seed)
     except Exception as e:
         bad.append(seed); print("EXC seed", seed, repr(e)[:300])
-    if len(bad) >= 5 or time.time() - t0 > 900: break
-print("collate fuzz: %d configs up to seed %d, bad %s, %.0f s" % (n, seed, bad, time.time() - t0))
+    if time.time() - t0 > MAXS: break
+rec = {"tool": "fuzz_collate", "mode": "dense" if (len(sys.argv) > 3 and sys.argv[3] == "dense") else "sparse", "first": int(sys.argv[1]), "last_done": seed,
+       "configs_exact": n - len(bad), "failures": bad, "odd_seeds_as_xyzi_rows": True, "seconds": round(time.time() - t0, 1)}
+print("collate fuzz: " + json.dumps(rec))
+if "--json" in sys.argv:
+    open(sys.argv[sys.argv.index("--json") + 1], "a").write(json.dumps(rec) + "\n")
