@@ -163,6 +163,7 @@ class HostIngest:
         self.dev = [None] * slots
         self.pin_len = [None] * slots
         self.dev_len = [None] * slots
+        self.src = [None] * slots            # the caller's pinned tensor while its copy may be in flight (kept alive until the slot is released)
         self.uploaded_bytes = 0
 
     def _room(self, slot, numel, B):
@@ -192,6 +193,11 @@ class HostIngest:
         if not points.is_pinned():
             self.pin[slot][:n * c].copy_(src)                 # pageable -> pinned (host memcpy in this thread)
             src = self.pin[slot][:n * c]
+        else:
+            # pinned input: copied from where it lies.  CONTRACT: the caller does not modify or re-use that tensor until the descriptors
+            # of its batch have been yielded (a loader that recycles one pinned buffer per batch must hand over pageable tensors or
+            # keep `depth + workers + 1` buffers in rotation)
+            self.src[slot] = points
         self.pin_len[slot][:B].copy_(lengths.to(torch.int64).reshape(-1))
         with torch.cuda.stream(self.stream):
             d = self.dev[slot][:n * c]
@@ -204,6 +210,7 @@ class HostIngest:
         return d.view(n, c), dl, ev, slot
 
     def release(self, slot):
+        self.src[slot] = None
         self.free.put(slot)
 
     def reset(self):
@@ -215,6 +222,7 @@ class HostIngest:
             except queue.Empty:
                 break
         for i in range(len(self.pin)):
+            self.src[i] = None
             self.free.put(i)
 
 
