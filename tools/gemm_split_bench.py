@@ -18,6 +18,13 @@ SHAPES = [("1_2 kpconv", 127812, 32, 480, 1), ("2_1 kpconv", 51547, 32, 480, 1),
           ("4_2 unary1", 6479, 256, 512, 0), ("square", 8192, 1024, 1024, 0), ("ragged", 5000, 96, 352, 1)]
 
 
+if "--splitk-proxy" in sys.argv:       # the same work as a split-K of the stage-3/4 contractions would launch: S x the rows, K / S deep (tiles x S, steps / S)
+    SHAPES = [("4_2", 6479, 256, 3840, 1), ("4_2 K/2", 12958, 256, 1920, 1), ("4_2 K/3", 19437, 256, 1280, 1), ("4_2 K/4", 25916, 256, 960, 1),
+              ("3_2", 19061, 128, 1920, 1), ("3_2 K/2", 38122, 128, 960, 1), ("3_2 K/3", 57183, 128, 640, 1),
+              ("4_1", 6479, 128, 1920, 1), ("4_1 K/2", 12958, 128, 960, 1), ("4_1 K/4", 25916, 128, 480, 1),
+              ("4_x unary1", 6479, 256, 1024, 0), ("4_x K/2", 12958, 256, 512, 0), ("3_1", 19061, 64, 960, 1), ("3_1 K/2", 38122, 64, 480, 1)]
+
+
 def main():
     dev = torch.device("cuda")
     L = _lib.lib()
