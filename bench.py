@@ -283,8 +283,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     dist = None
     backend = None
-    if world > 1:
+    # LCR_BENCH_FORCE_DIST=1: a ONE-rank process group, so that the N-rank code path (RCCL communicator, barriers, the all-gather issued on
+    # the encoder's external stream inside the timed region, the max-over-ranks reduction) runs against real RCCL on a single-GPU box
+    force_dist = world == 1 and bool(os.environ.get("LCR_BENCH_FORCE_DIST"))
+    if world > 1 or force_dist:
         import torch.distributed as dist
+        if force_dist:
+            os.environ.setdefault("MASTER_PORT", "29555")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         single = bool(os.environ.get("LCR_BENCH_SINGLE_DEVICE"))          # dry run of the N>1 code path on a 1-GPU box
         backend = os.environ.get("LCR_BENCH_BACKEND", "gloo" if single else "nccl")   # "nccl" is RCCL on ROCm
@@ -314,7 +321,7 @@ def main():
     nb_in = max(1, args.distinct_batches)
     inputs = rotated_inputs(scans, nb_in, dev)
     raw_pts, raw_lens = inputs[0]
-    gathered = torch.empty((world * BATCH, 256), dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty((world * BATCH, 256), dtype=torch.float32, device=dev) if dist is not None else None
 
     from lcrnet_amd.pipeline import DescriptorPipeline
     pipe = DescriptorPipeline(model, VOXEL, RADIUS, NUM_STAGES, LIMITS, upsampling=not args.no_upsampling, raw_voxel=VOXEL,
@@ -329,7 +336,7 @@ def main():
         dual = pipe.enc_streams is not None and not (args.no_overlap or args.no_thread)
         for item in pipe.run((inputs[k % nb_in] for k in range(n)), sync_to_caller=not dual):
             desc, es = (item[0], item[2]) if dual else (item, None)
-            if world > 1:
+            if dist is not None:
                 if es is not None:
                     with torch.cuda.stream(es):              # the collective follows the encoder on ITS stream: nothing is parked
                         dist.all_gather_into_tensor(gathered, desc.contiguous())   # on the caller's queue
@@ -362,7 +369,7 @@ def main():
     SAMPLE = max(1, int(os.environ.get("LCR_BENCH_KTIMER_SAMPLE", "9")))
     for rep in range(R):
         timer = F.KernelTimer({"kpconv_aggregate", "gemm", "radius_query"})
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         if not os.environ.get("LCR_BENCH_NO_KTIMER"):                  # A/B: what the per-launch events cost the timed region
@@ -370,11 +377,11 @@ def main():
         t0 = time.perf_counter()
         desc = run_steps(args.steps)
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         dt_r = time.perf_counter() - t0
         F.set_timer(None)
-        if world > 1:
+        if dist is not None:
             t = torch.tensor([dt_r], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_r = float(t.item())
@@ -402,16 +409,16 @@ def main():
         run_steps(8)
         dts = []
         for rep in range(min(R, 3)):
-            if world > 1:
+            if dist is not None:
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             desc_h = run_steps(args.steps)
             torch.cuda.synchronize()
-            if world > 1:
+            if dist is not None:
                 dist.barrier()
             d = time.perf_counter() - t0
-            if world > 1:
+            if dist is not None:
                 t = torch.tensor([d], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 d = float(t.item())
@@ -434,16 +441,16 @@ def main():
         run_steps(8)
         dts = []
         for rep in range(min(R, 3)):
-            if world > 1:
+            if dist is not None:
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             desc_s = run_steps(args.steps)
             torch.cuda.synchronize()
-            if world > 1:
+            if dist is not None:
                 dist.barrier()
             d = time.perf_counter() - t0
-            if world > 1:
+            if dist is not None:
                 t = torch.tensor([d], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 d = float(t.item())
@@ -469,16 +476,16 @@ def main():
         run_steps(8)
         dts = []
         for rep in range(min(R, 3)):
-            if world > 1:
+            if dist is not None:
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             desc_7 = run_steps(args.steps)
             torch.cuda.synchronize()
-            if world > 1:
+            if dist is not None:
                 dist.barrier()
             d = time.perf_counter() - t0
-            if world > 1:
+            if dist is not None:
                 t = torch.tensor([d], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 d = float(t.item())
@@ -625,7 +632,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "repeats": R, "ms_per_step_min": round(dt_min / args.steps * 1e3, 3), "ms_per_step_max": round(dt_max / args.steps * 1e3, 3),
             "timing": "median of %d back-to-back blocks of %d steps, each bracketed by barrier + synchronize (max over ranks)" % (R, args.steps),
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", **({"forced_one_rank_process_group": backend} if force_dist else {}),
             "config": {"workload": "configs[1]: batch of 8 synthetic 64-beam scans (~120k pts, 0.3 m voxel -> ~16k pts), "
                                    "voxelise + 3 subsamples + %d radius searches + KPConv encoder + NetVLAD, seeded random weights"
                                    % n_search,
@@ -649,7 +656,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(scans)
         print(json.dumps(line), flush=True)
     pipe.close()
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 
