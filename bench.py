@@ -497,6 +497,7 @@ def main():
                 "over_headline": round(dt / d7, 4), "descriptors_max_abs_diff_vs_headline": float((desc_7 - desc).abs().max()),
                 "what": "same steps with the 7 searches the descriptor path consumes (the 3 decoder-only upsampling lists not built: DescriptorPipeline's "
                         "default for loop detection); NOT the headline, which keeps the reference collate's 10; median of %d blocks" % len(dts)}
+    final_line = None
     iso = None
     if rank == 0 and not os.environ.get("LCR_BENCH_NO_KTIMER"):
         # Every distinct batch once more with NOTHING else on the GPU (one stream, one batch in flight, outside the timed region) and
@@ -654,10 +655,19 @@ def main():
             line["dtype"] = "f32 (K-deep GEMMs: fp32 operands as 3 bf16 terms, 6 products on the bf16 matrix cores, fp32 accumulation)"
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(scans)
-        print(json.dumps(line), flush=True)
+        final_line = json.dumps(line)
     pipe.close()
     if dist is not None:
-        dist.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()            # RCCL prints its version banner to stdout at teardown: the JSON line goes out after it
+    if rank == 0 and final_line is not None:
+        try:                                     # RCCL writes its version banner through C stdio, which a pipe buffers until exit: push it
+            import ctypes                        # out now, so that the JSON line is the LAST line of stdout
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(final_line, flush=True)
 
 
 if __name__ == "__main__":
