@@ -398,7 +398,8 @@ def main():
     # stream `depth` batches ahead (lcrnet_amd.pipeline.HostIngest) and consumed unsliced by the voxel-key kernels.  The reference:
     # `_load_point_cloud(...)[:, :3]` + to_cuda (dataset_overlap_online.py:245-253, utils/engine/single_tester.py:59).
     with_h2d = None
-    if not args.no_h2d and not (args.no_overlap or args.no_thread):
+    secondary = world == 1            # the A/B blocks belong to the single-GPU line; an N-rank run measures the headline only
+    if secondary and not args.no_h2d and not (args.no_overlap or args.no_thread):
         host_inputs = []
         g = torch.Generator().manual_seed(5)
         for pts_k, lens_k in inputs:
@@ -436,7 +437,7 @@ def main():
     # (three bf16 terms per fp32 value, six cross products, fp32 accumulation: lcr_gemm_f32_bsplit).  Opt-in (LCR_GEMM_SPLIT=1):
     # the headline above is true fp32 MFMA everywhere unless that switch was set by the caller, in which case `dtype` says so.
     split_ab = None
-    if not args.no_split_ab and not F.gemm_split_enabled():
+    if secondary and not args.no_split_ab and not F.gemm_split_enabled():
         F.set_gemm_split(True)
         run_steps(8)
         dts = []
@@ -467,7 +468,7 @@ def main():
     # DescriptorPipeline's default is not to build them.  The headline keeps all ten searches of the reference's collate (§8d); this block runs
     # the same steps with the seven the descriptor path consumes.
     lazy = None
-    if not args.no_upsampling and not args.no_lazy_ab and not (args.no_overlap or args.no_thread):
+    if secondary and not args.no_upsampling and not args.no_lazy_ab and not (args.no_overlap or args.no_thread):
         pipe_main, pipe = pipe, None
         pipe7 = DescriptorPipeline(model, VOXEL, RADIUS, NUM_STAGES, LIMITS, upsampling=False, raw_voxel=VOXEL, overlap=True, producer_thread=True,
                                    pre_workers=args.pre_workers, depth=args.depth)
