@@ -907,7 +907,9 @@ __global__ __launch_bounds__(256) void k_split_bf16x3_tiles(const float* __restr
 // for twice, B rows half lines): full-line loads + tiled planes: loads alone 53 us — and the whole kernel still 100 (1.18x overall,
 // 1.23-1.28x on 2_2 / 3_2 / 4_2 / the stage-3/4 Linears): every ablation removes its own 10-25 %, i.e. the K-step is a latency chain
 // (arrival -> split -> park -> barrier -> fragment reads -> 12 MFMAs) that two to three workgroups per CU do not cover; matrix pipe 38 % busy.
-// Raising the wavefront's priority over its MFMA section (s_setprio) 0.98x, parking the next tile before the MFMAs instead of between them 1.00x.
+// Raising the wavefront's priority over its MFMA section (s_setprio) 0.98x, parking the next tile before the MFMAs instead of between them 1.00x;
+// B planes global -> LDS directly (global_load_lds_dwordx4, three B stages, no staging registers / ds_write for B): 0.89x (60 KB of LDS: two
+// workgroups per CU instead of three).
 // ABL: timing ablations (tools/gemm_split_bench.py --abl): 1 no MFMAs, 2 no split arithmetic, 4 no plane stores, 8 no global loads in the
 // loop, 16 no fragment reads.  0 = the product; any other value computes garbage.
 // NWM: 32-row wavefront rows of the tile (2: 64 x 64, 256 threads — the product; 4: 128 x 64, 512 threads: measured 1.08x, not instantiated).
