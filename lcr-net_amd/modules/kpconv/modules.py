@@ -90,7 +90,17 @@ class LastUnaryBlock(nn.Module):
         self.mlp = nn.Linear(in_channels, out_channels, bias=bias)
 
     def forward(self, x):
-        return F.gemm(x.contiguous(), self.mlp.weight, trans_b=True, bias=self.mlp.bias)[0]
+        w = self.mlp.weight
+        if F.gemm_split_enabled() and F.gemm_split_ok(w.shape[0], w.shape[1]):
+            key = (w.data_ptr(), w._version, w.device)
+            c = getattr(self, "_ws_cache", None)
+            if c is None or c[0] != key:
+                with F.derived_lock:
+                    c = getattr(self, "_ws_cache", None)
+                    if c is None or c[0] != key:
+                        c = self._ws_cache = (key, F.publish_derived(F.split_bf16x3(w)))
+            return F.gemm_bsplit(x.contiguous(), c[1], bias=self.mlp.bias)[0]
+        return F.gemm(x.contiguous(), w, trans_b=True, bias=self.mlp.bias)[0]
 
 
 class ConvBlock(nn.Module):
