@@ -191,7 +191,9 @@ class HostIngest:
         self._room(slot, n * c, B)
         src = points.reshape(-1)
         if not points.is_pinned():
-            self.pin[slot][:n * c].copy_(src)                 # pageable -> pinned (host memcpy in this thread)
+            # pageable -> pinned: a plain memcpy in this thread through numpy (torch's CPU copy_ fans a 15 MB copy out over the whole
+            # intra-op pool — 256 threads on the GPU box — and took 12 ms per batch next to the pipeline's busy host threads)
+            self.pin[slot].numpy()[:n * c] = src.numpy()
             src = self.pin[slot][:n * c]
         else:
             # pinned input: copied from where it lies.  CONTRACT: the caller does not modify or re-use that tensor until the descriptors
