@@ -909,7 +909,10 @@ __global__ __launch_bounds__(256) void k_split_bf16x3_tiles(const float* __restr
 // (arrival -> split -> park -> barrier -> fragment reads -> 12 MFMAs) that two to three workgroups per CU do not cover; matrix pipe 38 % busy.
 // Raising the wavefront's priority over its MFMA section (s_setprio) 0.98x, parking the next tile before the MFMAs instead of between them 1.00x;
 // B planes global -> LDS directly (global_load_lds_dwordx4, three B stages, no staging registers / ds_write for B): 0.89x (60 KB of LDS: two
-// workgroups per CU instead of three).
+// workgroups per CU instead of three).  A 64 x 128 form of THIS pipeline (wavefront = 32 x 64, two accumulators; half the splits, 9 fragment
+// reads per 12 MFMAs instead of 6 per 6, 16 instead of 20 KB loaded per 64 x 64 x 32): 160 TFLOP/s-equivalent on 8192 x 1024 x 1024 against this
+// form's 146 (so instructions per flop ARE the bound once the chip is full) but 0.93x over the 13 shapes: 4_2 is 204 such tiles, 3_2 298 on
+// 512 workgroup slots (4_2 104 us against 97, 4_1 56 against 36) — removed.
 // ABL: timing ablations (tools/gemm_split_bench.py --abl): 1 no MFMAs, 2 no split arithmetic, 4 no plane stores, 8 no global loads in the
 // loop, 16 no fragment reads.  0 = the product; any other value computes garbage.
 // NWM: 32-row wavefront rows of the tile (2: 64 x 64, 256 threads — the product; 4: 128 x 64, 512 threads: measured 1.08x, not instantiated).
