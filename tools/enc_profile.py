@@ -18,7 +18,7 @@ m = create_model()
 m.load_state_dict(seeded_state_dict(m.state_dict(), 7351))
 m = m.eval().to(dev)
 pipe = DescriptorPipeline(m, voxel_size=bench.VOXEL, radius=bench.RADIUS, num_stages=bench.NUM_STAGES, neighbor_limits=bench.LIMITS,
-                          upsampling=False, raw_voxel=bench.VOXEL, overlap=False)
+                          upsampling=os.environ.get("LCR_ENC_PROFILE_UPSAMPLING", "0") != "0", raw_voxel=bench.VOXEL, overlap=False)
 dds = [pipe.preprocess(p, l) for p, l in inputs]
 torch.cuda.synchronize()
 for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 20):
