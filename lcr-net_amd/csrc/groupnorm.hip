@@ -9,6 +9,8 @@
 // Optionally emits pos[n] = (sum_c y[n][c] > 0), the flag KPConv's neighbour count is built from (kpconv.py:113-114).
 #include <algorithm>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace lcr {
@@ -105,68 +107,100 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, G
     }
   }
   const int64_t t_end = ((t_hi - t_lo + 63) & ~int64_t(63)) + t_lo;
-  for (int64_t tb = t_lo + threadIdx.x; tb < t_end; tb += static_cast<int64_t>(GU) * blockDim.x) {
-    float4 xv[GU], rv[GU];
-    int64_t nrow[GU];
-    int c0s[GU];
-    bool live[GU];
-#pragma unroll
-    for (int k = 0; k < GU; ++k) {
-      const int64_t t = tb + static_cast<int64_t>(k) * blockDim.x;
-      live[k] = t < t_hi;
-      nrow[k] = live[k] ? t / c4n : row_hi - 1;
-      c0s[k] = live[k] ? static_cast<int>(t - nrow[k] * c4n) * 4 : 0;
-      xv[k] = *reinterpret_cast<const float4*>(x + nrow[k] * C + c0s[k]);
-      rv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (res) rv[k] = *reinterpret_cast<const float4*>(res + nrow[k] * C + c0s[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < GU; ++k) {
-      const int64_t t = tb + static_cast<int64_t>(k) * blockDim.x;
-      if (t >= t_end) break;                       // wave-uniform: t_end - t_lo is a multiple of 64
-      const int64_t n = nrow[k];
-      const int c0 = c0s[k];
-      int s = seg_lo;
-      while (s < seg_hi && n >= s_start[s + 1]) ++s;
-      float4 gam = gam_f, bet = bet_f, rgam = rgam_f, rbet = rbet_f;
-      if (!fixed_c) {
-        gam = *reinterpret_cast<const float4*>(gx.gamma + c0);
-        bet = *reinterpret_cast<const float4*>(gx.beta + c0);
-        if (gr.stats) {
-          rgam = *reinterpret_cast<const float4*>(gr.gamma + c0);
-          rbet = *reinterpret_cast<const float4*>(gr.beta + c0);
-        }
-      }
-      const float xin[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w}, g4[4] = {gam.x, gam.y, gam.z, gam.w}, b4[4] = {bet.x, bet.y, bet.z, bet.w};
-      const float rin[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w}, rg4[4] = {rgam.x, rgam.y, rgam.z, rgam.w},
-                  rb4[4] = {rbet.x, rbet.y, rbet.z, rbet.w};
-      float out[4];
-      float rowsum = 0.f;
+  // FAST (block-uniform; every block of this model except the B - 1 that straddle a scan boundary): one segment in the range, C / 4 and the
+  // group size powers of two, fixed channel offset — the row is a shift of the element index, and the thread's four (mean, rstd) pairs sit in
+  // registers.  The general form spends ~170 VALU instructions per 16-B element on a 64-bit division (row = t / (C/4)), four 32-bit
+  // divisions (group = channel / gs), the segment walk and eight LDS reads (PMC: 97 M of a step's 601 M VALU instructions for 2 % of its
+  // flops); the arithmetic on the values is the same in both forms, operation for operation.
+  const bool fast = fixed_c && nseg == 1 && (c4n & (c4n - 1)) == 0 && (gs & (gs - 1)) == 0;
+  const int sh4 = 31 - __builtin_clz(c4n), shg = 31 - __builtin_clz(gs);
+  auto run = [&](auto fast_c) {
+    constexpr bool FAST = decltype(fast_c)::value;
+    float2 mx[4], mrs[4];
+    if (FAST) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int gi = (s - seg_lo) * groups + (c0 + u) / gs;
-        const float2 mr = s_x[gi];
-        float v = (xin[u] - mr.x) * mr.y * g4[u] + b4[u];
-        if (res) {
-          float r = rin[u];
-          if (gr.stats) {
-            const float2 rr = s_r[gi];
-            r = (r - rr.x) * rr.y * rg4[u] + rb4[u];
-          }
-          v += r;
-        }
-        if (act) v = v > 0.f ? v : v * slope;
-        out[u] = v;
-        rowsum += v;
-      }
-      if (live[k]) *reinterpret_cast<float4*>(y + n * C + c0) = make_float4(out[0], out[1], out[2], out[3]);
-      if (POS) {
-        // the c4n (<= 64, power of two) lanes of a row are consecutive and aligned inside the wavefront
-        for (int d = 1; d < c4n; d <<= 1) rowsum += __shfl_xor(rowsum, d);
-        if (live[k] && c0 == 0) pos[n] = rowsum > 0.f ? 1 : 0;
+        const int gi = (c0_f + u) >> shg;
+        mx[u] = s_x[gi];
+        mrs[u] = gr.stats ? s_r[gi] : make_float2(0.f, 1.f);
       }
     }
-  }
+    for (int64_t tb = t_lo + threadIdx.x; tb < t_end; tb += static_cast<int64_t>(GU) * blockDim.x) {
+      float4 xv[GU], rv[GU];
+      int64_t nrow[GU];
+      int c0s[GU];
+      bool live[GU];
+#pragma unroll
+      for (int k = 0; k < GU; ++k) {
+        const int64_t t = tb + static_cast<int64_t>(k) * blockDim.x;
+        live[k] = t < t_hi;
+        if (FAST) {
+          nrow[k] = live[k] ? (t >> sh4) : row_hi - 1;
+          c0s[k] = c0_f;
+        } else {
+          nrow[k] = live[k] ? t / c4n : row_hi - 1;
+          c0s[k] = live[k] ? static_cast<int>(t - nrow[k] * c4n) * 4 : 0;
+        }
+        xv[k] = *reinterpret_cast<const float4*>(x + nrow[k] * C + c0s[k]);
+        rv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (res) rv[k] = *reinterpret_cast<const float4*>(res + nrow[k] * C + c0s[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < GU; ++k) {
+        const int64_t t = tb + static_cast<int64_t>(k) * blockDim.x;
+        if (t >= t_end) break;                       // wave-uniform: t_end - t_lo is a multiple of 64
+        const int64_t n = nrow[k];
+        const int c0 = c0s[k];
+        int s = seg_lo;
+        if (!FAST) {
+          while (s < seg_hi && n >= s_start[s + 1]) ++s;
+        }
+        float4 gam = gam_f, bet = bet_f, rgam = rgam_f, rbet = rbet_f;
+        if (!FAST && !fixed_c) {
+          gam = *reinterpret_cast<const float4*>(gx.gamma + c0);
+          bet = *reinterpret_cast<const float4*>(gx.beta + c0);
+          if (gr.stats) {
+            rgam = *reinterpret_cast<const float4*>(gr.gamma + c0);
+            rbet = *reinterpret_cast<const float4*>(gr.beta + c0);
+          }
+        }
+        const float xin[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w}, g4[4] = {gam.x, gam.y, gam.z, gam.w}, b4[4] = {bet.x, bet.y, bet.z, bet.w};
+        const float rin[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w}, rg4[4] = {rgam.x, rgam.y, rgam.z, rgam.w},
+                    rb4[4] = {rbet.x, rbet.y, rbet.z, rbet.w};
+        float out[4];
+        float rowsum = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float2 mr, rr = make_float2(0.f, 1.f);
+          if (FAST) {
+            mr = mx[u];
+            rr = mrs[u];
+          } else {
+            const int gi = (s - seg_lo) * groups + (c0 + u) / gs;
+            mr = s_x[gi];
+            if (res && gr.stats) rr = s_r[gi];
+          }
+          float v = (xin[u] - mr.x) * mr.y * g4[u] + b4[u];
+          if (res) {
+            float r = rin[u];
+            if (gr.stats) r = (r - rr.x) * rr.y * rg4[u] + rb4[u];
+            v += r;
+          }
+          if (act) v = v > 0.f ? v : v * slope;
+          out[u] = v;
+          rowsum += v;
+        }
+        if (live[k]) *reinterpret_cast<float4*>(y + n * C + c0) = make_float4(out[0], out[1], out[2], out[3]);
+        if (POS) {
+          // the c4n (<= 64, power of two) lanes of a row are consecutive and aligned inside the wavefront
+          for (int d = 1; d < c4n; d <<= 1) rowsum += __shfl_xor(rowsum, d);
+          if (live[k] && c0 == 0) pos[n] = rowsum > 0.f ? 1 : 0;
+        }
+      }
+    }
+  };
+  if (fast) run(std::true_type{});
+  else run(std::false_type{});
 }
 
 // plain segmented statistics for tensors that do not come out of lcr_gemm_f32 (e.g. the fused C_in = 1 KPConv):
