@@ -112,38 +112,51 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, G
   // registers.  The general form spends ~170 VALU instructions per 16-B element on a 64-bit division (row = t / (C/4)), four 32-bit
   // divisions (group = channel / gs), the segment walk and eight LDS reads (PMC: 97 M of a step's 601 M VALU instructions for 2 % of its
   // flops); the arithmetic on the values is the same in both forms, operation for operation.
-  const bool fast = fixed_c && nseg == 1 && (c4n & (c4n - 1)) == 0 && (gs & (gs - 1)) == 0;
+  const bool fast = fixed_c && nseg == 1 && (c4n & (c4n - 1)) == 0 && (gs & (gs - 1)) == 0 && N * C < (int64_t(1) << 30);
   const int sh4 = 31 - __builtin_clz(c4n), shg = 31 - __builtin_clz(gs);
   auto run = [&](auto fast_c) {
     constexpr bool FAST = decltype(fast_c)::value;
     float2 mx[4], mrs[4];
     if (FAST) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 4; ++u) {                  // (scale, shift) of this thread's four channels
         const int gi = (c0_f + u) >> shg;
-        mx[u] = s_x[gi];
-        mrs[u] = gr.stats ? s_r[gi] : make_float2(0.f, 1.f);
+        const float g = u == 0 ? gam_f.x : u == 1 ? gam_f.y : u == 2 ? gam_f.z : gam_f.w, b = u == 0 ? bet_f.x : u == 1 ? bet_f.y : u == 2 ? bet_f.z : bet_f.w;
+        const float2 mr = s_x[gi];
+        const float a = mr.y * g;
+        mx[u] = make_float2(a, fmaf(-mr.x, a, b));
+        mrs[u] = make_float2(1.f, 0.f);
+        if (gr.stats) {
+          const float rg = u == 0 ? rgam_f.x : u == 1 ? rgam_f.y : u == 2 ? rgam_f.z : rgam_f.w, rbv = u == 0 ? rbet_f.x : u == 1 ? rbet_f.y : u == 2 ? rbet_f.z : rbet_f.w;
+          const float2 rr = s_r[gi];
+          const float a2 = rr.y * rg;
+          mrs[u] = make_float2(a2, fmaf(-rr.x, a2, rbv));
+        }
       }
     }
     for (int64_t tb = t_lo + threadIdx.x; tb < t_end; tb += static_cast<int64_t>(GU) * blockDim.x) {
       float4 xv[GU], rv[GU];
       int64_t nrow[GU];
+      typename std::conditional<FAST, unsigned, int64_t>::type eoff[GU];
       int c0s[GU];
       bool live[GU];
 #pragma unroll
       for (int k = 0; k < GU; ++k) {
         const int64_t t = tb + static_cast<int64_t>(k) * blockDim.x;
         live[k] = t < t_hi;
-        if (FAST) {
-          nrow[k] = live[k] ? (t >> sh4) : row_hi - 1;
+        if (FAST) {                                   // N * C < 2^30: element offsets are 32-bit (scalar base + vector offset addressing)
+          const unsigned r32 = live[k] ? static_cast<unsigned>(t) >> sh4 : static_cast<unsigned>(row_hi - 1);
+          nrow[k] = r32;
           c0s[k] = c0_f;
+          eoff[k] = r32 * static_cast<unsigned>(C) + static_cast<unsigned>(c0_f);
         } else {
           nrow[k] = live[k] ? t / c4n : row_hi - 1;
           c0s[k] = live[k] ? static_cast<int>(t - nrow[k] * c4n) * 4 : 0;
+          eoff[k] = nrow[k] * C + c0s[k];
         }
-        xv[k] = *reinterpret_cast<const float4*>(x + nrow[k] * C + c0s[k]);
+        xv[k] = *reinterpret_cast<const float4*>(x + eoff[k]);
         rv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (res) rv[k] = *reinterpret_cast<const float4*>(res + nrow[k] * C + c0s[k]);
+        if (res) rv[k] = *reinterpret_cast<const float4*>(res + eoff[k]);
       }
 #pragma unroll
       for (int k = 0; k < GU; ++k) {
@@ -171,26 +184,30 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, G
         float rowsum = 0.f;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          float2 mr, rr = make_float2(0.f, 1.f);
+          // y = x * (rstd * gamma) + (beta - mean * rstd * gamma): the scale / shift form of lcr_gemm_f32_anorm's table (and of torch's
+          // own GroupNorm kernels); FAST: the thread's four (scale, shift) pairs are loop constants
+          float xa, xb, ra = 1.f, rb = 0.f;
           if (FAST) {
-            mr = mx[u];
-            rr = mrs[u];
+            xa = mx[u].x, xb = mx[u].y;
+            ra = mrs[u].x, rb = mrs[u].y;
           } else {
             const int gi = (s - seg_lo) * groups + (c0 + u) / gs;
-            mr = s_x[gi];
-            if (res && gr.stats) rr = s_r[gi];
+            const float2 mr = s_x[gi];
+            xa = mr.y * g4[u];
+            xb = fmaf(-mr.x, xa, b4[u]);
+            if (res && gr.stats) {
+              const float2 rr = s_r[gi];
+              ra = rr.y * rg4[u];
+              rb = fmaf(-rr.x, ra, rb4[u]);
+            }
           }
-          float v = (xin[u] - mr.x) * mr.y * g4[u] + b4[u];
-          if (res) {
-            float r = rin[u];
-            if (gr.stats) r = (r - rr.x) * rr.y * rg4[u] + rb4[u];
-            v += r;
-          }
+          float v = fmaf(xin[u], xa, xb);
+          if (res) v += gr.stats ? fmaf(rin[u], ra, rb) : rin[u];
           if (act) v = v > 0.f ? v : v * slope;
           out[u] = v;
           rowsum += v;
         }
-        if (live[k]) *reinterpret_cast<float4*>(y + n * C + c0) = make_float4(out[0], out[1], out[2], out[3]);
+        if (live[k]) *reinterpret_cast<float4*>(y + eoff[k]) = make_float4(out[0], out[1], out[2], out[3]);
         if (POS) {
           // the c4n (<= 64, power of two) lanes of a row are consecutive and aligned inside the wavefront
           for (int d = 1; d < c4n; d <<= 1) rowsum += __shfl_xor(rowsum, d);
