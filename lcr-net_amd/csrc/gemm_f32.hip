@@ -195,6 +195,37 @@ __device__ __forceinline__ void gemm_epilogue(floatx16 (&acc)[NT], float* __rest
   const int64_t wrow0 = m0 + wm * 32;
 
   // store (and keep the final values in the accumulators for the statistics pass)
+  // Interior tiles (every row and column of the tile inside the matrix — all but the last row / column block; element offsets below 2^30):
+  // one 32-bit offset per lane and value, a compile-time multiple of N apart, on the scalar base — 2-3 VALU instructions per stored value.
+  // The general form below costs ~16 (64-bit row, bounds, 64-bit address) x 16 values x 4 wavefronts per tile: ~50 M of a step's 600 M VALU
+  // instructions (PMC, profiles/r04_pmc_insts*.md).  Same values, same order.
+  const bool interior = m0 + BM <= M && n0 + BN <= N && M * static_cast<int64_t>(N) < (int64_t(1) << 30);   // workgroup-uniform
+  if (interior) {
+    const unsigned row_l = static_cast<unsigned>(wrow0) + 4u * static_cast<unsigned>(lane >> 5);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const unsigned col = static_cast<unsigned>(n0 + wn * (32 * NT) + j * 32 + (lane & 31));
+      const float bv = bias_v[j];
+      const unsigned off0 = row_l * static_cast<unsigned>(N) + col;
+      if (ep.rowdiv) {                                 // uniform: the KPConv contractions
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned dr = static_cast<unsigned>((r & 3) + 8 * (r >> 2));
+          const float v = acc[j][r] / ep.rowdiv[row_l + dr] + bv;
+          C[off0 + dr * static_cast<unsigned>(N)] = v;
+          acc[j][r] = v;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned dr = static_cast<unsigned>((r & 3) + 8 * (r >> 2));
+          const float v = acc[j][r] + bv;
+          C[off0 + dr * static_cast<unsigned>(N)] = v;
+          acc[j][r] = v;
+        }
+      }
+    }
+  } else
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int col = n0 + wn * (32 * NT) + j * 32 + (lane & 31);
