@@ -21,6 +21,16 @@ LIB = os.path.join(PKG, "liblcr_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-munsafe-fp-atomics",
          "-Wno-unused-value", "-Wno-unused-result"]
+# Per-file additions.  -amdgpu-mfma-vgpr-form: MFMA accumulators in VGPRs instead of AGPRs.  With AGPR accumulators the register allocator
+# rotates the four small accumulators of the KPConv aggregation through overlapping AGPR ranges and repairs the rotation with 16
+# v_accvgpr_read / mov / write per four-neighbour trip (22 % of the loop's VALU instructions, the unit that kernel is short of), and the
+# wider layers hold 120 / 190 registers instead of 75 / 112 (4 -> 6 and 2 -> 4 wavefronts per SIMD).
+FILE_FLAGS = {"kpconv.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+if os.environ.get("LCR_BUILD_EXTRA"):       # experiments: "file.hip:-flag -flag;other.hip:-flag"
+    for part in os.environ["LCR_BUILD_EXTRA"].split(";"):
+        name, _, fl = part.partition(":")
+        FILE_FLAGS.setdefault(name.strip(), [])
+        FILE_FLAGS[name.strip()] = FILE_FLAGS[name.strip()] + fl.split()
 
 
 def _newer(src, dst, deps):
@@ -42,7 +52,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def cc(job):
         s, o = job
-        cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), r.stderr))
