@@ -24,8 +24,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 # Per-file additions.  -amdgpu-mfma-vgpr-form: MFMA accumulators in VGPRs instead of AGPRs.  With AGPR accumulators the register allocator
 # rotates the four small accumulators of the KPConv aggregation through overlapping AGPR ranges and repairs the rotation with 16
 # v_accvgpr_read / mov / write per four-neighbour trip (22 % of the loop's VALU instructions, the unit that kernel is short of), and the
-# wider layers hold 120 / 190 registers instead of 75 / 112 (4 -> 6 and 2 -> 4 wavefronts per SIMD).
-FILE_FLAGS = {"kpconv.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# wider layers hold 120 / 190 registers instead of 75 / 112 (4 -> 6 and 2 -> 4 wavefronts per SIMD).  The attention kernel loses 160
+# accumulator moves (99 vs 102-109 us per launch at 8 pairs per call).
+FILE_FLAGS = {"kpconv.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 if os.environ.get("LCR_BUILD_EXTRA"):       # experiments: "file.hip:-flag -flag;other.hip:-flag"
     for part in os.environ["LCR_BUILD_EXTRA"].split(";"):
         name, _, fl = part.partition(":")

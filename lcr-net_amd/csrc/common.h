@@ -96,6 +96,12 @@ __device__ __forceinline__ float fdiv(float a, float b) {
 }
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// ballot of a bool without the int round trip of HIP's __ballot(int) (v_cndmask 0/1 + v_cmp_ne: two VALU instructions per ballot), and the
+// number of set bits of a lane mask BELOW this lane on v_mbcnt_lo / v_mbcnt_hi (two instructions instead of and + and + bcnt + bcnt)
+__device__ __forceinline__ uint64_t wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ int mbcnt_lt(uint64_t m) {
+  return static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u)));
+}
 __device__ __forceinline__ uint64_t lanemask_lt() {
   return (1ull << (threadIdx.x & 63)) - 1ull;
 }

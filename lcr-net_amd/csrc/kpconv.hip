@@ -99,15 +99,15 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate_vec(const fl
       int64_t j = Ns;
       if (h < H) j = static_cast<int64_t>(idx[m * H + h]);
       const bool ok = j >= 0 && j < Ns;
-      const uint64_t mk = __ballot(ok);
+      const uint64_t mk = wave_ballot(ok);
       bool positive = false;
       if (ok) {
-        const int slot = n + __popcll(mk & lanemask_lt());
+        const int slot = n + mbcnt_lt(mk);
         s_rel[w][slot] = make_float4(s_pts[3 * j] - qx, s_pts[3 * j + 1] - qy, s_pts[3 * j + 2] - qz, __uint_as_float(static_cast<uint32_t>(j)));
         positive = s_pos[j] != 0;
       }
       n += __popcll(mk);
-      cnt += __popcll(__ballot(positive));      // scalar popcount of a lane mask instead of a six-step cross-lane sum
+      cnt += __popcll(wave_ballot(positive));      // scalar popcount of a lane mask instead of a six-step cross-lane sum
     }
     // The list is padded with far-away neighbours (relative position 1e6: linear influence exactly 0 for every kernel point; feature
     // row 0, multiplied by that 0): the steps then need neither an index clamp nor an in-range mask — 6 of ~19 VALU instructions per
@@ -271,15 +271,15 @@ __global__ __launch_bounds__(KP_WAVES * 64, 3) void k_kpconv_fused32(const float
         int64_t j = Ns;
         if (h < H) j = static_cast<int64_t>(idx[m * H + h]);
         const bool ok = j >= 0 && j < Ns;
-        const uint64_t mk = __ballot(ok);
+        const uint64_t mk = wave_ballot(ok);
         bool positive = false;
         if (ok) {
-          const int sl = n + __popcll(mk & lanemask_lt());
+          const int sl = n + mbcnt_lt(mk);
           s_rel[w][sl] = make_float4(s_pts[3 * j] - qx, s_pts[3 * j + 1] - qy, s_pts[3 * j + 2] - qz, __uint_as_float(static_cast<uint32_t>(j)));
           positive = s_pos[j] != 0;
         }
         n += __popcll(mk);
-        cnt += __popcll(__ballot(positive));
+        cnt += __popcll(wave_ballot(positive));
       }
       wave_lds_sync();
       floatx4 acc[V];
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(KP_WAVES * 64, 3) void k_kpconv_fused32(const float
     int mx = my_seg;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) mx = max(mx, __shfl_xor(mx, d));
-    const bool agree = __ballot(my_seg >= 0 && my_seg != mx) == 0ull;
+    const bool agree = wave_ballot(my_seg >= 0 && my_seg != mx) == 0ull;
     if (agree && mx >= 0) {
       double ds[2], dss[2];
 #pragma unroll
@@ -557,9 +557,9 @@ __global__ __launch_bounds__(256) void k_maxpool(const float* __restrict__ x, co
       int64_t j = Ns;
       if (h < H) j = static_cast<int64_t>(idx[m * H + h]);
       const bool ok = j >= 0 && j < Ns;
-      const uint64_t mk = __ballot(ok);
-      if (ok) s_idx[w][n + __popcll(mk & lanemask_lt())] = static_cast<int32_t>(j);
-      any_shadow |= (__ballot(h < H && !ok) != 0ull);
+      const uint64_t mk = wave_ballot(ok);
+      if (ok) s_idx[w][n + mbcnt_lt(mk)] = static_cast<int32_t>(j);
+      any_shadow |= (wave_ballot(h < H && !ok) != 0ull);
       n += __popcll(mk);
     }
     wave_lds_sync();

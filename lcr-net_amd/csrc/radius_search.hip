@@ -260,8 +260,8 @@ __device__ __forceinline__ void rq_chunks(const RqRuns R, const float4* __restri
     const float dx = fsub(qx, P[u].x), dy = fsub(qy, P[u].y), dz = fsub(qz, P[u].z);
     const float d2 = fadd(fadd(fmul(dx, dx), fmul(dy, dy)), fmul(dz, dz));
     const bool pass = (t0 + 64 * u + lane < total) && d2 < r2;
-    const uint64_t m = __ballot(pass);
-    const int off = n + __popcll(m & lanemask_lt());
+    const uint64_t m = wave_ballot(pass);
+    const int off = n + mbcnt_lt(m);
     if (pass && off < RQ_CAP) {
       const uint64_t key = (static_cast<uint64_t>(__float_as_uint(d2)) << 32) | __float_as_uint(P[u].w);
       keys[off] = key;
