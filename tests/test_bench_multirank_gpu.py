@@ -39,6 +39,9 @@ def test_one_rank_rccl_group_runs_the_n_rank_path():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["forced_one_rank_process_group"] == "nccl" and line["n_gpus"] == 1 and line["value"] > 0
     assert "nccl" in line["config"]["parallelism"]
-    for k in ("with_h2d", "split_bf16_gemm_ab", "descriptor_only_7_searches"):
+    blocks = ["with_h2d", "descriptor_only_7_searches"]
+    if os.environ.get("LCR_GEMM_SPLIT", "0") in ("", "0"):       # the A/B block is what the switch itself replaces
+        blocks.append("split_bf16_gemm_ab")
+    for k in blocks:
         assert line[k]["value"] > 0
     assert line["with_h2d"]["descriptors_max_abs_diff_vs_resident"] == 0.0
