@@ -66,7 +66,9 @@ __device__ __forceinline__ float vget(const float2& v, int i) { return i == 0 ? 
 __device__ __forceinline__ float4 vmake(const float (&a)[4]) { return make_float4(a[0], a[1], a[2], a[3]); }
 __device__ __forceinline__ float2 vmake(const float (&a)[2]) { return make_float2(a[0], a[1]); }
 
-template <typename IdxT, int C>
+// OFF32 (Ns * C * 4 < 2^32, chosen by the host): the list carries the BYTE offset of the neighbour's feature row instead of its index, and a
+// step's gather is scalar base + (offset + lane column): one 32-bit add instead of a 64-bit multiply-add per step.
+template <typename IdxT, int C, bool OFF32>
 __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate_vec(const float* __restrict__ s_feats, const uint8_t* __restrict__ s_pos,
                                                                         const float* __restrict__ q_pts, const float* __restrict__ s_pts,
                                                                         const IdxT* __restrict__ idx, int64_t M, int64_t Ns, int H, KPoints kp,
@@ -103,7 +105,8 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate_vec(const fl
       bool positive = false;
       if (ok) {
         const int slot = n + mbcnt_lt(mk);
-        s_rel[w][slot] = make_float4(s_pts[3 * j] - qx, s_pts[3 * j + 1] - qy, s_pts[3 * j + 2] - qz, __uint_as_float(static_cast<uint32_t>(j)));
+        s_rel[w][slot] = make_float4(s_pts[3 * j] - qx, s_pts[3 * j + 1] - qy, s_pts[3 * j + 2] - qz,
+                                     __uint_as_float(OFF32 ? static_cast<uint32_t>(j) * static_cast<uint32_t>(C * 4) : static_cast<uint32_t>(j)));
         positive = s_pos[j] != 0;
       }
       n += __popcll(mk);
@@ -126,9 +129,15 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate_vec(const fl
     VecT f[D][NL];
     auto fetch = [&](int s, float4& pp, VecT (&ff)[NL]) {
       pp = s_rel[w][4 * s + sub];
-      const float* r = s_feats + static_cast<int64_t>(__float_as_uint(pp.w)) * C + V * col;
+      if (OFF32) {
+        const uint32_t off = __float_as_uint(pp.w) + static_cast<uint32_t>(V * col * 4);
 #pragma unroll
-      for (int q = 0; q < NL; ++q) ff[q] = *reinterpret_cast<const VecT*>(r + q * 16 * V);
+        for (int q = 0; q < NL; ++q) ff[q] = *reinterpret_cast<const VecT*>(reinterpret_cast<const char*>(s_feats) + (off + static_cast<uint32_t>(q * 16 * V * 4)));
+      } else {
+        const float* r = s_feats + static_cast<int64_t>(__float_as_uint(pp.w)) * C + V * col;
+#pragma unroll
+        for (int q = 0; q < NL; ++q) ff[q] = *reinterpret_cast<const VecT*>(r + q * 16 * V);
+      }
     };
     // Branch-free steady state: steps are rounded up to a multiple of D and every fetch is issued unconditionally (beyond the
     // list's end it reads padding: row 0, a cache hit, with influence 0).  One basic block per
@@ -645,13 +654,19 @@ template <typename IdxT>
 static int launch_aggregate(const float* s_feats, const uint8_t* s_pos, const float* q_pts, const float* s_pts, const IdxT* idx, int64_t M,
                             int64_t Ns, int H, int C, const KPoints& kp, float sigma, float* A, float* nn, const int32_t* order, hipStream_t st) {
   dim3 grid(grid_for_xcd(M, KP_WAVES)), block(KP_WAVES * 64);
+  const bool off32 = Ns * C < (int64_t(1) << 30);          // feature rows addressable with 32-bit byte offsets
+#define LCR_AGG(CC)                                                                                                                          \
+  if (off32) LCR_LAUNCH_TIMED((k_kpconv_aggregate_vec<IdxT, CC, true>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); \
+  else LCR_LAUNCH_TIMED((k_kpconv_aggregate_vec<IdxT, CC, false>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order);      \
+  break
   switch (C) {
-    case 32: LCR_LAUNCH_TIMED((k_kpconv_aggregate_vec<IdxT, 32>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
-    case 64: LCR_LAUNCH_TIMED((k_kpconv_aggregate_vec<IdxT, 64>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
-    case 128: LCR_LAUNCH_TIMED((k_kpconv_aggregate_vec<IdxT, 128>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
-    case 256: LCR_LAUNCH_TIMED((k_kpconv_aggregate_vec<IdxT, 256>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); break;
+    case 32: LCR_AGG(32);
+    case 64: LCR_AGG(64);
+    case 128: LCR_AGG(128);
+    case 256: LCR_AGG(256);
     default: set_error("lcr_kpconv_aggregate: C must be 32, 64, 128 or 256 (got %d)", C); return LCR_EARG;
   }
+#undef LCR_AGG
   return check_launch("lcr_kpconv_aggregate");
 }
 
