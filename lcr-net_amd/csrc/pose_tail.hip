@@ -988,23 +988,6 @@ __global__ __launch_bounds__(SKC_T) void k_log_sinkhorn_coop(float* __restrict__
   }
 }
 
-// padded score matrix from raw products: S[b][i][j] = scale * raw[b][i][j]; dustbin row/col = alpha; masked -> -inf_val
-__global__ __launch_bounds__(256) void k_build_padded_scores(const float* __restrict__ raw, const uint8_t* __restrict__ row_mask,
-                                                             const uint8_t* __restrict__ col_mask, int64_t B, int M, int N, float scale,
-                                                             const float* __restrict__ alpha, float inf_val, float* __restrict__ S) {
-  const int M1 = M + 1, N1 = N + 1;
-  const int64_t total = B * M1 * N1;
-  const float a = alpha[0];
-  for (int64_t t = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; t < total; t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-    const int64_t b = t / (static_cast<int64_t>(M1) * N1);
-    const int r = static_cast<int>(t - b * M1 * N1);
-    const int i = r / N1, j = r - i * N1;
-    float val = (i < M && j < N) ? raw[(b * M + i) * N + j] * scale : a;
-    const bool masked = (i < M && !row_mask[b * M + i]) || (j < N && !col_mask[b * N + j]);
-    S[t] = masked ? -inf_val : val;
-  }
-}
-
 // ---- dustbin top-1 matching (exp domain): row / column maxima vs the dustbins -------------------------------------------------
 // rowarg[b][i] = argmax_j P[i][:], rowbeat = P[i][rowarg] > P[i][N];  colarg[b][j] = argmax_i P[:][j], colbeat = P[colarg][j] > P[M][j].
 __global__ __launch_bounds__(256) void k_top1_stats(const float* __restrict__ logS, int M, int N, int32_t* __restrict__ rowarg,
@@ -1120,6 +1103,72 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ s
     const int c = static_cast<int>(t - r * C);
     const int64_t j = idx[r];
     out[t] = (j >= 0 && j < pad) ? src[j * C + c] : 0.f;
+  }
+}
+
+// Row-wise forms of the two gathers above (C1, C2 / C multiples of 4, 16-byte aligned bases — every call of the pair model): one wavefront
+// per output row, 16-byte lanes, the row's index read once.  The element-wise forms spend a 64-bit division and a 4-byte access per
+// value (PMC: 6 % and 3 % of the pair model's VALU instructions for two copies).
+template <typename IdxT>
+__global__ __launch_bounds__(256) void k_upsample_concat_rows(const float* __restrict__ x, int64_t Nx, int C1, const IdxT* __restrict__ idx, int H,
+                                                              const float* __restrict__ skip, int C2, int64_t N, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int q1 = C1 >> 2, q = (C1 + C2) >> 2;
+  const int64_t wave = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6), nwaves = static_cast<int64_t>(gridDim.x) * 4;
+  for (int64_t n = wave; n < N; n += nwaves) {
+    const int64_t j = static_cast<int64_t>(idx[n * H]);
+    const bool ok = j >= 0 && j < Nx;
+    const float4* xr = reinterpret_cast<const float4*>(x + (ok ? j : 0) * C1);
+    const float4* sr = reinterpret_cast<const float4*>(skip + n * C2);
+    float4* o = reinterpret_cast<float4*>(out + n * (C1 + C2));
+    for (int c = lane; c < q; c += 64) {
+      float4 v;
+      if (c < q1) {
+        v = xr[c];
+        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        v = sr[c - q1];
+      }
+      o[c] = v;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_gather_rows_vec(const float* __restrict__ src, int64_t pad, int C, const int64_t* __restrict__ idx, int64_t R,
+                                                         float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int q = C >> 2;
+  const int64_t wave = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6), nwaves = static_cast<int64_t>(gridDim.x) * 4;
+  for (int64_t r = wave; r < R; r += nwaves) {
+    const int64_t j = idx[r];
+    const bool ok = j >= 0 && j < pad;
+    const float4* sr = reinterpret_cast<const float4*>(src + (ok ? j : 0) * C);
+    float4* o = reinterpret_cast<float4*>(out + r * C);
+    for (int c = lane; c < q; c += 64) o[c] = ok ? sr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+// padded score matrix from raw products: S[b][i][j] = scale * raw[b][i][j]; dustbin row / col = alpha; masked -> -inf_val.
+// One wavefront per (problem, row) of the padded matrix, lanes along the row (no division per value).
+__global__ __launch_bounds__(256) void k_build_padded_scores_rows(const float* __restrict__ raw, const uint8_t* __restrict__ row_mask,
+                                                                  const uint8_t* __restrict__ col_mask, int64_t B, int M, int N, float scale,
+                                                                  const float* __restrict__ alpha, float inf_val, float* __restrict__ S) {
+  const int lane = threadIdx.x & 63;
+  const int M1 = M + 1, N1 = N + 1;
+  const float a = alpha[0];
+  const int64_t rows = B * M1;
+  const int64_t wave = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6), nwaves = static_cast<int64_t>(gridDim.x) * 4;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const int64_t b = r / M1;
+    const int i = static_cast<int>(r - b * M1);
+    const bool row_in = i < M;
+    const bool row_dead = row_in && !row_mask[b * M + i];
+    const float* rr = raw + (b * M + (row_in ? i : 0)) * N;
+    float* o = S + r * N1;
+    for (int j = lane; j < N1; j += 64) {
+      const bool col_in = j < N;
+      const float val = (row_in && col_in) ? rr[j] * scale : a;
+      const bool masked = row_dead || (col_in && !col_mask[b * N + j]);
+      o[j] = masked ? -inf_val : val;
+    }
   }
 }
 
@@ -1509,8 +1558,8 @@ extern "C" int lcr_point_to_node_partition_stack(const float* points, const int6
 extern "C" int lcr_build_padded_scores(const float* raw, const uint8_t* row_mask, const uint8_t* col_mask, int64_t B, int M, int N, float scale,
                                        const float* alpha, float inf_val, float* S, void* stream) {
   if (!raw || !row_mask || !col_mask || !alpha || !S || B < 1 || M < 1 || N < 1) return LCR_EARG;
-  hipLaunchKernelGGL(k_build_padded_scores, dim3(blocks_for(B * (M + 1) * (N + 1), 256, 8192)), dim3(256), 0, ST(stream), raw, row_mask, col_mask, B, M, N,
-                     scale, alpha, inf_val, S);
+  hipLaunchKernelGGL(k_build_padded_scores_rows, dim3(blocks_for(B * (M + 1) * 64, 256, 8192)), dim3(256), 0, ST(stream), raw, row_mask, col_mask, B, M,
+                     N, scale, alpha, inf_val, S);
   return check_launch("lcr_build_padded_scores");
 }
 
@@ -1670,6 +1719,13 @@ extern "C" int lcr_upsample_concat(const float* x, int64_t Nx, int C1, const voi
                                    float* out, void* stream) {
   if (!x || !idx || !skip || !out || N < 0 || C1 < 1 || C2 < 1 || H < 1) return LCR_EARG;
   if (N == 0) return LCR_OK;
+  const bool vec = C1 % 4 == 0 && C2 % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(skip) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  if (vec) {
+    const int nbr = blocks_for(N * 64, 256, 8192);         // one wavefront per row
+    if (idx_is_64) hipLaunchKernelGGL((k_upsample_concat_rows<int64_t>), dim3(nbr), dim3(256), 0, ST(stream), x, Nx, C1, static_cast<const int64_t*>(idx), H, skip, C2, N, out);
+    else hipLaunchKernelGGL((k_upsample_concat_rows<int32_t>), dim3(nbr), dim3(256), 0, ST(stream), x, Nx, C1, static_cast<const int32_t*>(idx), H, skip, C2, N, out);
+    return check_launch("lcr_upsample_concat");
+  }
   const int nb = blocks_for(N * (C1 + C2), 256, 8192);
   if (idx_is_64) hipLaunchKernelGGL((k_upsample_concat<int64_t>), dim3(nb), dim3(256), 0, ST(stream), x, Nx, C1, static_cast<const int64_t*>(idx), H, skip, C2, N, out);
   else hipLaunchKernelGGL((k_upsample_concat<int32_t>), dim3(nb), dim3(256), 0, ST(stream), x, Nx, C1, static_cast<const int32_t*>(idx), H, skip, C2, N, out);
@@ -1679,6 +1735,10 @@ extern "C" int lcr_upsample_concat(const float* x, int64_t Nx, int C1, const voi
 extern "C" int lcr_gather_rows(const float* src, int64_t pad, int C, const int64_t* idx, int64_t R, float* out, void* stream) {
   if (!src || !idx || !out || R < 0 || C < 1) return LCR_EARG;
   if (R == 0) return LCR_OK;
+  if (C % 4 == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+    hipLaunchKernelGGL(k_gather_rows_vec, dim3(blocks_for(R * 64, 256, 8192)), dim3(256), 0, ST(stream), src, pad, C, idx, R, out);
+    return check_launch("lcr_gather_rows");
+  }
   hipLaunchKernelGGL(k_gather_rows, dim3(blocks_for(R * C, 256, 8192)), dim3(256), 0, ST(stream), src, pad, C, idx, R, out);
   return check_launch("lcr_gather_rows");
 }
