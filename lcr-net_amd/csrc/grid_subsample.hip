@@ -166,7 +166,10 @@ __global__ void k_gs_params(GsHeader* h, float voxel, float inv_voxel, int key_b
     h->NX[b] = NX;
     h->NY[b] = NY;
     // largest key of this cloud (if the product overflows 64 bits the key is not sortable together with a cloud id)
-    const unsigned __int128 top = static_cast<unsigned __int128>(NX) * NY * NZ;
+    // (an axis on which the WHOLE cloud sits one cell below the origin — a plane or line at a constant coordinate c with
+    // floor(c * fl(1/v)) * v > c — has extent 0 after the reference's (size_t) cast + 1; it still contributes the -1 index to every key, so it
+    // counts as one cell for the key range.  Found by the op fuzz at seed 63843 of ~90 000: the call reported a key overflow.)
+    const unsigned __int128 top = static_cast<unsigned __int128>(NX ? NX : 1) * (NY ? NY : 1) * (NZ ? NZ : 1);
     // A point can land one cell BELOW the origin: origin = floor(min * fl(1/v)) * v is rounded twice, so (min - origin) / v may come
     // out as -epsilon, its floor as -1, and the reference's (size_t) cast turns that into 2^64 - 1 (grid_subsampling_cpu.cpp:32-35;
     // the key then wraps mod 2^64 — a voxel of its own, found by the fuzz at 1 in ~2700 random stacks).  Such keys are -1 - NX - NX*NY

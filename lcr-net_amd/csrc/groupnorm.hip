@@ -37,7 +37,8 @@ __device__ __forceinline__ int seg_of(const int64_t* __restrict__ seg_len, int S
 constexpr int GN_TABLE = 2048;   // (segment, group) pairs whose mean / rstd fit the LDS table
 constexpr int GN_MAX_SEG = 256;  // segments per call
 
-template <bool POS>
+// RM: residual mode, compile-time (0 none, 1 plain residual, 2 GroupNorm-ed residual): no per-element branches on it
+template <bool POS, int RM>
 __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, GnSide gx, const float* __restrict__ res, GnSide gr,
                                                   float* __restrict__ y, int64_t N, int C, int groups, const int64_t* __restrict__ seg_len, int S,
                                                   float eps, float slope, int act, uint8_t* __restrict__ pos) {
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, G
       const int64_t o = ((static_cast<int64_t>(rep) * S + sg) * groups + g) * 2;
       sx += gx.stats[o];
       sxx += gx.stats[o + 1];
-      if (gr.stats) {
+      if (RM == 2) {
         rx += gr.stats[o];
         rxx += gr.stats[o + 1];
       }
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, G
     const double m = sx / cnt;
     const double var = fmax(sxx / cnt - m * m, 0.0);
     s_x[i] = make_float2(static_cast<float>(m), static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps))));
-    if (gr.stats) {
+    if (RM == 2) {
       const double rm = rx / cnt;
       const double rv = fmax(rxx / cnt - rm * rm, 0.0);
       s_r[i] = make_float2(static_cast<float>(rm), static_cast<float>(1.0 / sqrt(rv + static_cast<double>(eps))));
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, G
   if (fixed_c) {
     gam_f = *reinterpret_cast<const float4*>(gx.gamma + c0_f);
     bet_f = *reinterpret_cast<const float4*>(gx.beta + c0_f);
-    if (gr.stats) {
+    if (RM == 2) {
       rgam_f = *reinterpret_cast<const float4*>(gr.gamma + c0_f);
       rbet_f = *reinterpret_cast<const float4*>(gr.beta + c0_f);
     }
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, G
         const float a = mr.y * g;
         mx[u] = make_float2(a, fmaf(-mr.x, a, b));
         mrs[u] = make_float2(1.f, 0.f);
-        if (gr.stats) {
+        if (RM == 2) {
           const float rg = u == 0 ? rgam_f.x : u == 1 ? rgam_f.y : u == 2 ? rgam_f.z : rgam_f.w, rbv = u == 0 ? rbet_f.x : u == 1 ? rbet_f.y : u == 2 ? rbet_f.z : rbet_f.w;
           const float2 rr = s_r[gi];
           const float a2 = rr.y * rg;
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, G
         }
         xv[k] = *reinterpret_cast<const float4*>(x + eoff[k]);
         rv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (res) rv[k] = *reinterpret_cast<const float4*>(res + eoff[k]);
+        if (RM > 0) rv[k] = *reinterpret_cast<const float4*>(res + eoff[k]);
       }
 #pragma unroll
       for (int k = 0; k < GU; ++k) {
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, G
         if (!FAST && !fixed_c) {
           gam = *reinterpret_cast<const float4*>(gx.gamma + c0);
           bet = *reinterpret_cast<const float4*>(gx.beta + c0);
-          if (gr.stats) {
+          if (RM == 2) {
             rgam = *reinterpret_cast<const float4*>(gr.gamma + c0);
             rbet = *reinterpret_cast<const float4*>(gr.beta + c0);
           }
@@ -195,14 +196,15 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, G
             const float2 mr = s_x[gi];
             xa = mr.y * g4[u];
             xb = fmaf(-mr.x, xa, b4[u]);
-            if (res && gr.stats) {
+            if (RM == 2) {
               const float2 rr = s_r[gi];
               ra = rr.y * rg4[u];
               rb = fmaf(-rr.x, ra, rb4[u]);
             }
           }
           float v = fmaf(xin[u], xa, xb);
-          if (res) v += gr.stats ? fmaf(rin[u], ra, rb) : rin[u];
+          if (RM == 2) v += fmaf(rin[u], ra, rb);
+          else if (RM == 1) v += rin[u];
           if (act) v = v > 0.f ? v : v * slope;
           out[u] = v;
           rowsum += v;
@@ -305,12 +307,20 @@ extern "C" int lcr_groupnorm_apply(const float* x, const double* stats, const fl
   // contiguous row ranges per workgroup, >= 2048 float4 pieces each (the per-block statistics fold is amortised over them)
   const int nblk = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((N * c4n + 2047) / 2048, 256 * 8)));
   const size_t tab_bytes = sizeof(float2) * 2 * static_cast<size_t>(S) * groups;
-  if (pos)
-    hipLaunchKernelGGL((k_gn_apply<true>), dim3(nblk), dim3(256), tab_bytes, static_cast<hipStream_t>(stream), x, gx, res, gr, y, N, C, groups, seg_len,
-                       S, eps, slope, act, pos);
-  else
-    hipLaunchKernelGGL((k_gn_apply<false>), dim3(nblk), dim3(256), tab_bytes, static_cast<hipStream_t>(stream), x, gx, res, gr, y, N, C, groups, seg_len,
-                       S, eps, slope, act, pos);
+  const int rm = res ? (res_stats ? 2 : 1) : 0;
+#define LCR_GN(P, R)                                                                                                                       \
+  hipLaunchKernelGGL((k_gn_apply<P, R>), dim3(nblk), dim3(256), tab_bytes, static_cast<hipStream_t>(stream), x, gx, res, gr, y, N, C, groups, \
+                     seg_len, S, eps, slope, act, pos)
+  if (pos) {
+    if (rm == 2) LCR_GN(true, 2);
+    else if (rm == 1) LCR_GN(true, 1);
+    else LCR_GN(true, 0);
+  } else {
+    if (rm == 2) LCR_GN(false, 2);
+    else if (rm == 1) LCR_GN(false, 1);
+    else LCR_GN(false, 0);
+  }
+#undef LCR_GN
   return check_launch("lcr_groupnorm_apply");
 }
 

@@ -257,7 +257,7 @@ def test_output_order_at_every_rehash_boundary(seed):
     assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
 
 
-@pytest.mark.parametrize("seed", list(range(6)) + [1379])     # 1379: a point one cell below the voxel origin (wrapped 64-bit key)
+@pytest.mark.parametrize("seed", list(range(6)) + [1379, 63843])     # 1379: a point one cell below the voxel origin (wrapped 64-bit key); 63843: a whole plane one cell below it (extent 0 on that axis)
 def test_random_clouds_subsample_and_search(seed):
     """Randomised shapes the fixed fixtures do not have: duplicates, points exactly on voxel faces, a plane, a line, tight
     clusters, far-apart clouds in one stack; subsample and both kinds of search bit-exact against the oracle."""
