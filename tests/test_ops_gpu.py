@@ -257,6 +257,36 @@ def test_output_order_at_every_rehash_boundary(seed):
     assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("voxel,cs", [(0.3, [3.299999952316284, 5.099999904632568, 6.599999904632568]), (0.77, [-923.2300415039062, -922.4600219726562, -920.9200439453125])])
+def test_whole_clouds_one_cell_below_the_voxel_origin(voxel, cs):
+    """Coordinates c with floor(c * fl(1/v)) * v > c in fp32: a plane / line / point at such a constant coordinate sits, as a whole,
+    one cell BELOW its own voxel origin; the reference's extent on that axis is (size_t)(-1) + 1 = 0 and every key carries the wrapped
+    index 2^64 - 1 (a plane x = c even collapses into ONE voxel: the y and z strides are multiples of NX = 0).  Found by the op
+    fuzz (seed 63843); pinned here on all axis combinations, next to an ordinary cloud in the same stack."""
+    from lcrnet_amd.modules.ops import grid_subsample
+    c = [np.float32(x) for x in cs]
+    v32, inv = np.float32(voxel), np.float32(1.0) / np.float32(voxel)
+    for x in c:
+        assert np.float32(np.floor(np.float32(x * inv)) * v32) > x             # the premise, in the reference's own arithmetic
+    rng = np.random.default_rng(7)
+    a = (rng.random((500, 3)) * 20).astype(np.float32)
+    pl_z, pl_x, pl_y, ln, ln2 = a.copy(), a.copy(), a.copy(), a.copy(), a.copy()
+    pl_z[:, 2] = c[0]
+    pl_x[:, 0] = c[1]
+    pl_y[:, 1] = c[2]
+    ln[:, 1], ln[:, 2] = c[2], c[0]
+    ln2[:, 0], ln2[:, 1] = c[1], c[2]
+    pt = np.array([[c[0], c[1], c[2]]], np.float32)
+    clouds = [a, pl_z, pl_x, pl_y, ln, ln2, pt]
+    xyz = np.concatenate(clouds)
+    lens = np.array([len(x) for x in clouds], dtype=np.int64)
+    want, wl = oracle_ops.grid_subsample(xyz, lens, voxel)
+    got, gl = grid_subsample(dev(xyz), dev(lens), voxel)
+    assert np.array_equal(gl.cpu().numpy(), wl)
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    assert wl[2] == 1                                                            # the collapsed plane
+
+
 @pytest.mark.parametrize("seed", list(range(6)) + [1379, 63843])     # 1379: a point one cell below the voxel origin (wrapped 64-bit key); 63843: a whole plane one cell below it (extent 0 on that axis)
 def test_random_clouds_subsample_and_search(seed):
     """Randomised shapes the fixed fixtures do not have: duplicates, points exactly on voxel faces, a plane, a line, tight
