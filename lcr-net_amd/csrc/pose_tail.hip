@@ -1124,8 +1124,8 @@ __global__ __launch_bounds__(256) void k_upsample_concat_rows(const float* __res
     for (int c = lane; c < q; c += 64) {
       float4 v;
       if (c < q1) {
-        v = xr[c];
-        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = xr[c];                                   // the shadow index (and an empty x) read nothing
       } else {
         v = sr[c - q1];
       }
