@@ -4,6 +4,7 @@
 #   2. PMC FETCH_SIZE / WRITE_SIZE of the bench command, separate passes       -> pmc_traffic.{md,json}
 #   3. PMC MFMA / wave-state counters of the encoder alone                     -> pmc_mfma_encoder.md
 #   4. rocprofv3 --kernel-trace --stats of the encoder alone                   -> encoder_alone_kernel_summary.md
+#   5. PMC instruction counts per kernel family over a pass (10 searches)      -> pmc_insts.md
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof
@@ -22,9 +23,13 @@ python "$ROOT/tools/pmc_mfma_summary.py" "$(find /tmp/prof_m -name "m_counter_co
 rocprofv3 --kernel-trace --stats -d /tmp/prof_e -o enc -- python "$ROOT/tools/enc_profile.py" 20 > "$OUT/enc_alone.log" 2>&1
 python "$ROOT/tools/rocprof_summary.py" "$(find /tmp/prof_e -name "*.db" | head -1)" \
   --note "rocprofv3 --kernel-trace --stats -- python tools/enc_profile.py 20: 20 encoder passes over the bench batch on one stream, nothing else on the GPU (what roofline.achieved / frac / avg_launch_us of the bench line measure live)" > "$OUT/encoder_alone_kernel_summary.md"
+LCR_ENC_PROFILE_UPSAMPLING=1 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES \
+  --kernel-trace --output-format csv -d /tmp/prof_i -o i -- python "$ROOT/tools/enc_profile.py" 4 > "$OUT/insts_enc.log" 2>&1
+python "$ROOT/tools/pmc_insts_summary.py" "$(find /tmp/prof_i -name "i_counter_collection.csv" | head -1)" 4 4 > "$OUT/pmc_insts.md"
 cd "$ROOT"
 python tools/pmc_summary.py "$OUT/fetch_counter_collection.csv" "$OUT/write_counter_collection.csv" "$OUT/pmc_traffic" > /dev/null
 tail -1 "$OUT/stats_bench.log" | cut -c1-300
 head -24 "$OUT/kernel_summary.md" | cut -c1-170
 cat "$OUT/pmc_mfma_encoder.md" | head -16
 head -14 "$OUT/pmc_traffic.md"
+head -14 "$OUT/pmc_insts.md"
