@@ -650,11 +650,13 @@ static int grid_for_xcd(int64_t rows, int per_block) {
   return 8 * static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(per_xcd, 256 * 2)));
 }
 
+static int g_agg_force_off64 = 0;          // tests: run the 64-bit-offset form of the aggregation (tensors of 2^30 elements and more)
+
 template <typename IdxT>
 static int launch_aggregate(const float* s_feats, const uint8_t* s_pos, const float* q_pts, const float* s_pts, const IdxT* idx, int64_t M,
                             int64_t Ns, int H, int C, const KPoints& kp, float sigma, float* A, float* nn, const int32_t* order, hipStream_t st) {
   dim3 grid(grid_for_xcd(M, KP_WAVES)), block(KP_WAVES * 64);
-  const bool off32 = Ns * C < (int64_t(1) << 30);          // feature rows addressable with 32-bit byte offsets
+  const bool off32 = Ns * C < (int64_t(1) << 30) && !g_agg_force_off64;          // feature rows addressable with 32-bit byte offsets
 #define LCR_AGG(CC)                                                                                                                          \
   if (off32) LCR_LAUNCH_TIMED((k_kpconv_aggregate_vec<IdxT, CC, true>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); \
   else LCR_LAUNCH_TIMED((k_kpconv_aggregate_vec<IdxT, CC, false>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order);      \
@@ -673,6 +675,8 @@ static int launch_aggregate(const float* s_feats, const uint8_t* s_pos, const fl
 }  // namespace lcr
 
 using namespace lcr;
+
+extern "C" void lcr_kpconv_debug_off64(int on) { g_agg_force_off64 = on; }
 
 extern "C" int lcr_kpconv_aggregate(const float* s_feats, const uint8_t* s_pos, const float* q_pts, const float* s_pts, const void* idx,
                                     int idx_is_64, int64_t M, int64_t Ns, int H, int C, const float* kernel_points_host, float sigma,

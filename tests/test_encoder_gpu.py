@@ -207,6 +207,31 @@ def test_aggregate_rows_without_neighbours_and_single_column(C):
     assert (A1.cpu().view(M, 15, C) - want1).abs().max().item() < 1e-4 * max(1.0, want1.abs().max().item())
 
 
+@pytest.mark.parametrize("C", [32, 64, 128, 256])
+def test_aggregate_64bit_offset_form_is_bit_identical(C):
+    """Tensors below 2^30 elements gather through 32-bit byte offsets carried in the neighbour list; larger ones keep the 64-bit form.
+    Both forms on the same input (lcr_kpconv_debug_off64): identical bits."""
+    from lcrnet_amd import _lib, functional as F
+    from lcrnet_amd.weights import base_kernel_points
+    g = torch.Generator().manual_seed(100 + C)
+    Ns, M, H = 3000, 1700, 70
+    s_pts = (torch.rand(Ns, 3, generator=g) * 6).cuda()
+    q_pts = s_pts[:M].clone()
+    feats = torch.randn(Ns, C, generator=g).cuda()
+    idx = torch.randint(0, Ns + 1, (M, H), generator=g).int().cuda()
+    kp = base_kernel_points() * 1.5
+    pos = F.row_positive(feats)
+    order = torch.randperm(M, generator=g).int().cuda()
+    lib = _lib.lib()
+    try:
+        a32, n32 = F.kpconv_aggregate(feats, pos, q_pts, s_pts, idx, kp, 1.2, order=order)
+        lib.lcr_kpconv_debug_off64(1)
+        a64, n64 = F.kpconv_aggregate(feats, pos, q_pts, s_pts, idx, kp, 1.2, order=order)
+    finally:
+        lib.lcr_kpconv_debug_off64(0)
+    assert torch.equal(a32, a64) and torch.equal(n32, n64)
+
+
 def test_native_encoder_driver_is_bit_identical_to_the_module_tree(model, monkeypatch):
     """lcr_encoder_forward issues the same launches in the same order as the Python module tree: identical stage outputs,
     with and without per-scan GroupNorm segments / processing order."""
