@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, G
   // registers.  The general form spends ~170 VALU instructions per 16-B element on a 64-bit division (row = t / (C/4)), four 32-bit
   // divisions (group = channel / gs), the segment walk and eight LDS reads (PMC: 97 M of a step's 601 M VALU instructions for 2 % of its
   // flops); the arithmetic on the values is the same in both forms, operation for operation.
-  const bool fast = fixed_c && nseg == 1 && (c4n & (c4n - 1)) == 0 && (gs & (gs - 1)) == 0 && N * C < (int64_t(1) << 30);
+  const bool fast = fixed_c && nseg == 1 && (c4n & (c4n - 1)) == 0 && (gs & (gs - 1)) == 0 && N * C < (int64_t(1) << 30) && !(act & 256);   // act bit 8: tests force the general form
+  act &= 255;
   const int sh4 = 31 - __builtin_clz(c4n), shg = 31 - __builtin_clz(gs);
   auto run = [&](auto fast_c) {
     constexpr bool FAST = decltype(fast_c)::value;
@@ -285,6 +286,9 @@ __global__ __launch_bounds__(256) void k_gn_stats(const float* __restrict__ x, i
 
 using namespace lcr;
 
+static int g_gn_force_general = 0;          // tests: every block takes the general (division) form
+extern "C" void lcr_groupnorm_debug_general(int on) { g_gn_force_general = on; }
+
 extern "C" int lcr_groupnorm_apply(const float* x, const double* stats, const float* gamma, const float* beta, const float* res,
                                    const double* res_stats, const float* res_gamma, const float* res_beta, float* y, int64_t N, int C,
                                    int groups, const int64_t* seg_len, int S, float eps, float slope, int act, uint8_t* pos, void* stream) {
@@ -308,6 +312,7 @@ extern "C" int lcr_groupnorm_apply(const float* x, const double* stats, const fl
   const int nblk = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((N * c4n + 2047) / 2048, 256 * 8)));
   const size_t tab_bytes = sizeof(float2) * 2 * static_cast<size_t>(S) * groups;
   const int rm = res ? (res_stats ? 2 : 1) : 0;
+  act = (act & 255) | (g_gn_force_general ? 256 : 0);
 #define LCR_GN(P, R)                                                                                                                       \
   hipLaunchKernelGGL((k_gn_apply<P, R>), dim3(nblk), dim3(256), tab_bytes, static_cast<hipStream_t>(stream), x, gx, res, gr, y, N, C, groups, \
                      seg_len, S, eps, slope, act, pos)

@@ -232,6 +232,37 @@ def test_aggregate_64bit_offset_form_is_bit_identical(C):
     assert torch.equal(a32, a64) and torch.equal(n32, n64)
 
 
+@pytest.mark.parametrize("C,res_mode,want_pos", [(32, 0, True), (64, 1, False), (128, 2, False), (256, 2, True), (1024, 2, False)])
+def test_groupnorm_apply_fast_form_equals_the_general_form(C, res_mode, want_pos):
+    """Blocks with one segment in their row range take a division-free form (row = shift, per-thread scale / shift in registers, 32-bit
+    offsets); blocks that straddle a scan boundary, and every block under lcr_groupnorm_debug_general, take the general one: same bits."""
+    from lcrnet_amd import _lib, functional as F
+    g = torch.Generator().manual_seed(C + res_mode)
+    lens = torch.tensor([1500, 700, 2300, 64, 1111], dtype=torch.int64)
+    N = int(lens.sum())
+    x = torch.randn(N, C, generator=g).cuda()
+    r = torch.randn(N, C, generator=g).cuda()
+    gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    rg, rb = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    seg = lens.cuda()
+    st, rst = F.groupnorm_stats(x, 32, seg), F.groupnorm_stats(r, 32, seg)
+    kw = dict(seg_len=seg, want_pos=want_pos)
+    if res_mode == 1:
+        kw["res"] = r
+    elif res_mode == 2:
+        kw["res"], kw["res_norm"] = r, (rst, rg, rb)
+    lib = _lib.lib()
+    try:
+        a = F.groupnorm_apply(x, st, gam, bet, 32, **kw)
+        lib.lcr_groupnorm_debug_general(1)
+        b = F.groupnorm_apply(x, st, gam, bet, 32, **kw)
+    finally:
+        lib.lcr_groupnorm_debug_general(0)
+    a, b = (a if isinstance(a, tuple) else (a,)), (b if isinstance(b, tuple) else (b,))
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
 def test_native_encoder_driver_is_bit_identical_to_the_module_tree(model, monkeypatch):
     """lcr_encoder_forward issues the same launches in the same order as the Python module tree: identical stage outputs,
     with and without per-scan GroupNorm segments / processing order."""
