@@ -1717,8 +1717,8 @@ extern "C" int lcr_top1_matching(const float* logS, int64_t B, int M, int N, con
 
 extern "C" int lcr_upsample_concat(const float* x, int64_t Nx, int C1, const void* idx, int idx_is_64, int H, const float* skip, int C2, int64_t N,
                                    float* out, void* stream) {
-  if (!x || !idx || !skip || !out || N < 0 || C1 < 1 || C2 < 1 || H < 1) return LCR_EARG;
   if (N == 0) return LCR_OK;
+  if (!x || !idx || !skip || !out || N < 0 || C1 < 1 || C2 < 1 || H < 1) return LCR_EARG;
   const bool vec = C1 % 4 == 0 && C2 % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(skip) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
   if (vec) {
     const int nbr = blocks_for(N * 64, 256, 8192);         // one wavefront per row
@@ -1733,8 +1733,8 @@ extern "C" int lcr_upsample_concat(const float* x, int64_t Nx, int C1, const voi
 }
 
 extern "C" int lcr_gather_rows(const float* src, int64_t pad, int C, const int64_t* idx, int64_t R, float* out, void* stream) {
+  if (R == 0) return LCR_OK;                               // an empty selection: nothing to read, null pointers allowed
   if (!src || !idx || !out || R < 0 || C < 1) return LCR_EARG;
-  if (R == 0) return LCR_OK;
   if (C % 4 == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
     hipLaunchKernelGGL(k_gather_rows_vec, dim3(blocks_for(R * 64, 256, 8192)), dim3(256), 0, ST(stream), src, pad, C, idx, R, out);
     return check_launch("lcr_gather_rows");

@@ -37,6 +37,26 @@ def test_vote_shift_nms_and_neighbor_mean():
     assert (got[ok] - want[ok]).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("C1,C2,i64", [(256, 128, False), (1024, 512, True), (6, 3, False), (10, 7, True)])
+def test_upsample_concat_and_gather_rows(C1, C2, i64):
+    """The decoder's nearest-upsample + concat and the zero-padded row gather, row-wise 16-byte form (channel counts that are multiples of
+    4) and element-wise fallback, against plain indexing; the shadow index (= number of rows) gives zeros."""
+    from lcrnet_amd import functional as F
+    g = torch.Generator().manual_seed(C1 + C2)
+    Nx, N, H = 300, 700, 5
+    x = torch.randn(Nx, C1, generator=g)
+    skip = torch.randn(N, C2, generator=g)
+    idx = torch.randint(0, Nx + 1, (N, H), generator=g)                   # Nx = shadow
+    idx[::11, 0] = Nx
+    xp = torch.cat([x, torch.zeros(1, C1)])
+    want = torch.cat([xp[idx[:, 0]], skip], 1)
+    got = F.upsample_concat(x.cuda(), (idx if i64 else idx.int()).cuda(), skip.cuda())
+    assert torch.equal(got.cpu(), want)
+    sel = torch.randint(0, Nx + 1, (40, 9), generator=g)
+    assert torch.equal(F.gather_rows(x.cuda(), sel.cuda()).cpu(), xp[sel])
+    assert F.gather_rows(x.cuda(), sel[:0].cuda()).shape == (0, 9, C1)
+
+
 def test_point_to_node_partition():
     from lcrnet_amd import functional as F
     pts = torch.from_numpy(load_scan("004481"))
