@@ -32,6 +32,7 @@ def segment_min_rows(data_dict, stages=4):
 class KPEncoder(nn.Module):
     def __init__(self, input_dim, init_dim, kernel_size, init_radius, init_sigma, group_norm):
         super().__init__()
+        self._native_table = None        # native_encoder.table_for's cache (weights as raw pointers + derived tensors)
         d, k, r, s, g = init_dim, kernel_size, init_radius, init_sigma, group_norm
         self.encoder1_1 = ConvBlock(input_dim, d, k, r, s, g)
         self.encoder1_2 = ResidualBlock(d, d * 2, k, r, s, g)
@@ -46,6 +47,15 @@ class KPEncoder(nn.Module):
         self.encoder4_3 = ResidualBlock(d * 16, d * 16, k, r * 8, s * 8, g)
         # forward through lcr_encoder_forward (one native call) when the inputs allow it; LCR_NATIVE_ENCODER=0: the module tree below
         self.native = os.environ.get("LCR_NATIVE_ENCODER", "1") != "0"
+
+    def _apply(self, fn, *args, **kwargs):
+        self._native_table = None        # .to() / .cuda() / .cpu(): every tensor is replaced, possibly at its old address
+        return super()._apply(fn, *args, **kwargs)
+
+    def __getstate__(self):                     # the table holds raw device pointers: never pickled / deep-copied with the module
+        d = dict(self.__dict__)
+        d["_native_table"] = None
+        return d
 
     def forward(self, feats, data_dict):
         """data_dict: 'points'[4], 'neighbors'[4], 'subsampling'[3] (+ optional 'segment_lengths'[4]: per-stage device

@@ -159,6 +159,39 @@ def gemm_split_ok(N, K):
 derived_lock = threading.RLock()
 
 
+class WeightStamp:
+    """Identity of a weight tensor for the derived-tensor caches (transposed / split weights, host copies, the native encoder's table):
+    the tensor OBJECT (weak reference), its address, its version counter and its device.  Address + version alone are not an identity: a
+    buffer replaced by Module._apply (.cpu() / .cuda() / .to()) is a NEW tensor with version 0 that the caching allocator readily
+    places at the address of the one it replaces — found by tools/fuzz_float_parity_gpu.py, which reloads seeded weights through
+    .cpu() -> load_state_dict -> .cuda() and got the previous seed's kernel points in one case of eight."""
+    __slots__ = ("ref", "ptr", "ver", "dev")
+
+    def __init__(self, t):
+        import weakref
+        self.ref, self.ptr, self.ver, self.dev = weakref.ref(t), t.data_ptr(), t._version, t.device
+
+    def same(self, t):
+        return self.ref is not None and self.ref() is t and self.ptr == t.data_ptr() and self.ver == t._version and self.dev == t.device
+
+    def __reduce__(self):                                   # pickled / copied modules start with caches that match nothing
+        return (_dead_stamp, ())
+
+
+def _dead_stamp():
+    s = WeightStamp.__new__(WeightStamp)
+    s.ref, s.ptr, s.ver, s.dev = None, 0, -1, None
+    return s
+
+
+def drop_derived(module, *names):
+    """forget cached derived tensors of a module (called from its _apply override: every .to() / .cuda() / .cpu() / .float())"""
+    for n in names:
+        if n in module.__dict__:
+            module.__dict__[n] = None
+
+
+
 def publish_derived(t):
     """Call on a freshly built derived tensor before storing it where other threads / streams can see it."""
     torch.cuda.current_stream(t.device).synchronize()

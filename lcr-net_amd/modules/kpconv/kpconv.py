@@ -46,14 +46,13 @@ class KPConv(nn.Module):
         change: with both operands k-contiguous the contraction takes the K-deep GEMM form (LDS-direct loads, 16-B fragment reads
         for both operands).  Same products, same summation order: the result does not change."""
         w = self.weights
-        key = (w.data_ptr(), w._version, w.device)
         c = self._wt_cache
-        if c is None or c[0] != key:
+        if c is None or not c[0].same(w):
             with F.derived_lock:
                 c = self._wt_cache
-                if c is None or c[0] != key:
+                if c is None or not c[0].same(w):
                     wt = w.detach().reshape(self.kernel_size * self.in_channels, self.out_channels).t().contiguous()
-                    c = self._wt_cache = (key, F.publish_derived(wt) if wt.is_cuda else wt)
+                    c = self._wt_cache = (F.WeightStamp(w), F.publish_derived(wt) if wt.is_cuda else wt)
         return c[1]
 
     def weights_t_split(self):
@@ -69,10 +68,14 @@ class KPConv(nn.Module):
 
     def kernel_points_host(self):
         kp = self.kernel_points
-        key = (kp.data_ptr(), kp._version)
-        if self._kp_cache is None or self._kp_cache[0] != key:
-            self._kp_cache = (key, kp.detach().cpu().numpy().copy())   # one D2H per weight load, not per forward
-        return self._kp_cache[1]
+        c = self._kp_cache
+        if c is None or not c[0].same(kp):
+            c = self._kp_cache = (F.WeightStamp(kp), kp.detach().cpu().numpy().copy())   # one D2H per weight load, not per forward
+        return c[1]
+
+    def _apply(self, fn, *args, **kwargs):
+        F.drop_derived(self, "_kp_cache", "_wt_cache", "_wts_cache")      # .to() / .cuda() / .cpu(): new tensors, possibly at the old addresses
+        return super()._apply(fn, *args, **kwargs)
 
     def forward_raw(self, s_feats, q_points, s_points, neighbor_indices, s_pos=None, seg_len=None, groups=0, order=None):
         """Returns (q_feats (M,Cout), stats) — stats = GroupNorm sums of the output when groups > 0."""

@@ -63,14 +63,17 @@ class UnaryBlock(nn.Module):
 
     def weight_split(self):
         w = self.mlp.weight
-        key = (w.data_ptr(), w._version, w.device)
         c = getattr(self, "_ws_cache", None)
-        if c is None or c[0] != key:
+        if c is None or not c[0].same(w):
             with F.derived_lock:
                 c = getattr(self, "_ws_cache", None)
-                if c is None or c[0] != key:
-                    c = self._ws_cache = (key, F.publish_derived(F.split_bf16x3(w)))
+                if c is None or not c[0].same(w):
+                    c = self._ws_cache = (F.WeightStamp(w), F.publish_derived(F.split_bf16x3(w)))
         return c[1]
+
+    def _apply(self, fn, *args, **kwargs):
+        F.drop_derived(self, "_ws_cache")
+        return super()._apply(fn, *args, **kwargs)
 
     def raw(self, x, ctx):
         """Linear + GroupNorm sums (no normalisation yet)."""
@@ -92,15 +95,18 @@ class LastUnaryBlock(nn.Module):
     def forward(self, x):
         w = self.mlp.weight
         if F.gemm_split_enabled() and F.gemm_split_ok(w.shape[0], w.shape[1]):
-            key = (w.data_ptr(), w._version, w.device)
             c = getattr(self, "_ws_cache", None)
-            if c is None or c[0] != key:
+            if c is None or not c[0].same(w):
                 with F.derived_lock:
                     c = getattr(self, "_ws_cache", None)
-                    if c is None or c[0] != key:
-                        c = self._ws_cache = (key, F.publish_derived(F.split_bf16x3(w)))
+                    if c is None or not c[0].same(w):
+                        c = self._ws_cache = (F.WeightStamp(w), F.publish_derived(F.split_bf16x3(w)))
             return F.gemm_bsplit(x.contiguous(), c[1], bias=self.mlp.bias)[0]
         return F.gemm(x.contiguous(), w, trans_b=True, bias=self.mlp.bias)[0]
+
+    def _apply(self, fn, *args, **kwargs):
+        F.drop_derived(self, "_ws_cache")
+        return super()._apply(fn, *args, **kwargs)
 
 
 class ConvBlock(nn.Module):

@@ -1,7 +1,7 @@
 """ctypes side of lcr_encoder_forward (csrc/encoder.hip): the weight table of a KPEncoder and the one-call forward.
 
 The table holds raw device pointers into the module's own parameters (nothing is copied), so it is rebuilt whenever a parameter
-tensor is replaced or modified in place (load_state_dict, .to(device)): the cache key is (data_ptr, _version) of every tensor.
+tensor is replaced or modified in place (load_state_dict, .to(device)): the cache key is a functional.WeightStamp (object identity, data_ptr, _version, device) of every tensor.
 """
 import ctypes
 
@@ -84,19 +84,28 @@ class EncoderTable:
         return ctypes.c_void_p(a.ctypes.data)
 
 
-def _key(enc):
-    from . import functional as F
-    return (F.gemm_split_enabled(),) + tuple((t.data_ptr(), t._version) for t in list(enc.parameters()) + list(enc.buffers()))
+class _Key:
+    """the table's validity: the split switch and a WeightStamp of every parameter and buffer (object identity + address + version)"""
+
+    def __init__(self, enc):
+        from . import functional as F
+        self.split = F.gemm_split_enabled()
+        self.stamps = [F.WeightStamp(t) for t in list(enc.parameters()) + list(enc.buffers())]
+
+    def valid(self, enc):
+        from . import functional as F
+        ts = list(enc.parameters()) + list(enc.buffers())
+        return self.split == F.gemm_split_enabled() and len(ts) == len(self.stamps) and all(s.same(t) for s, t in zip(self.stamps, ts))
 
 
 def table_for(enc):
-    key = _key(enc)
     cached = getattr(enc, "_native_table", None)
-    if cached is None or cached[0] != key:
+    if cached is None or not cached[0].valid(enc):
         from . import functional as F
         with F.derived_lock:                              # one builder; the table's derived tensors are complete before it is published
             cached = getattr(enc, "_native_table", None)
-            if cached is None or cached[0] != key:
+            if cached is None or not cached[0].valid(enc):
+                key = _Key(enc)
                 tab = EncoderTable(enc)
                 dev = next(enc.parameters()).device
                 if dev.type == "cuda":

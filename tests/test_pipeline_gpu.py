@@ -260,3 +260,33 @@ def test_host_xyzi_batches_give_the_resident_descriptors_bit_for_bit():
     # four columns without the raw-scan step: stage-0 points must be [n,3]
     with pytest.raises(RuntimeError):
         list(DescriptorPipeline(m, neighbor_limits=limits, overlap=True).run(host_batches[:1]))
+
+
+def test_weights_reloaded_through_cpu_do_not_meet_stale_derived_tensors():
+    """model.cpu() -> load_state_dict(other seed) -> model.cuda(): every buffer is a NEW tensor with version 0, and the caching
+    allocator readily puts it at the address of the one it replaces — the derived-tensor caches (host copy of the kernel points,
+    transposed KPConv weights, the native encoder's table) must not take that for "unchanged" (found by tools/fuzz_float_parity_gpu.py:
+    one case of eight ran with the previous seed's kernel points).  Same model object, five seeds in a row, each against a fresh model."""
+    from lcrnet_amd.model_family import create_model
+    from lcrnet_amd.modules.kpconv.kpconv import KPConv
+    from lcrnet_amd.pipeline import DescriptorPipeline
+    from lcrnet_amd.weights import seeded_state_dict
+    limits = [74, 68, 70, 67]
+    scan = load_scan("004481")[::2].copy()
+    batch = [(torch.from_numpy(scan).cuda(), torch.tensor([len(scan)], dtype=torch.int64, device="cuda"))]
+
+    def describe(model):
+        with DescriptorPipeline(model, neighbor_limits=limits, overlap=False) as pipe:
+            return [d.clone() for d in pipe.run(batch)][0]
+
+    m = create_model().eval().cuda()
+    for seed in (11, 12, 13, 14, 15):
+        m = m.cpu()
+        m.load_state_dict(seeded_state_dict(m.state_dict(), seed))
+        m = m.cuda()
+        for mod in m.modules():
+            if isinstance(mod, KPConv):
+                assert np.array_equal(mod.kernel_points_host(), mod.kernel_points.cpu().numpy())
+        fresh = create_model().eval()
+        fresh.load_state_dict(seeded_state_dict(fresh.state_dict(), seed))
+        assert torch.equal(describe(m), describe(fresh.cuda()))
