@@ -6,9 +6,15 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless its name ends in `_host`; all memory is caller-owned;
- *   - `stream` is a hipStream_t passed as void*; every call is asynchronous and stream-ordered, never
- *     synchronises the host and never allocates;
- *   - scratch memory comes from the caller: ask `*_ws_bytes`, pass `ws`/`ws_bytes`;
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous and stream-ordered, does not
+ *     synchronise the host and does not allocate — with these stated exceptions:
+ *       lcr_precompute_batch[_rows] ends with ONE synchronisation of `stream` (it returns the per-stage
+ *       lengths of the batch on the host) and owns a small per-process pool of side streams, events and
+ *       pinned staging words, created on first use and kept until process exit;
+ *       lcr_ktimer_read synchronises on the events it logged (measurement harness only);
+ *       the opt-in stream-K GEMM and the lane-per-query radius search keep one library-owned device scratch
+ *       buffer per device, allocated on first use;
+ *   - all other scratch memory comes from the caller: ask `*_ws_bytes`, pass `ws`/`ws_bytes`;
  *   - stacked ("stack mode") clouds: points f32[N,3] row-major, lengths i64[B] (reference layout,
  *     utils/extensions/cpu/grid_subsampling/grid_subsampling.cpp:20-30);
  *   - return value: 0 ok, -1 bad argument, -2 workspace/output too small, -3 HIP launch error

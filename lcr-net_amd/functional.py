@@ -524,7 +524,7 @@ def check_transport_status():
     """Raise if a persistent optimal-transport launch issued by this thread reported a timed-out hand-off (its result is invalid).
     One host read; called where the caller synchronises anyway (top1_matching reads a count back right after the transport)."""
     items, _pending_ot_status.items = _pending_ot_status.items, []
-    if items and int(torch.stack([t.reshape(()) for t in items]).max().item()) != 0:
+    if items and any(int(t.reshape(()).item()) != 0 for t in items):       # one entry per device after folding; a handful otherwise
         raise RuntimeError("lcr_log_sinkhorn: a workgroup hand-off of the persistent form timed out (set LCR_SINKHORN_COOP=0)")
 
 
@@ -551,7 +551,17 @@ def log_optimal_transport(raw_scores, row_masks, col_masks, alpha, scale=1.0, it
         items = _pending_ot_status.items
         items.append(uv[-1:].view(torch.int32).clone())
         if len(items) > _PENDING_OT_MAX:              # callers that never reach top1_matching: fold on the device, no host sync
-            _pending_ot_status.items = [torch.stack([t.reshape(()) for t in items]).max().reshape(1)]
+            # bitwise OR per device (the word is a set of flags; one host thread may drive several GPUs)
+            by_dev = {}
+            for t in items:
+                by_dev.setdefault(t.device, []).append(t.reshape(()))
+            folded = []
+            for ts in by_dev.values():
+                acc = ts[0]
+                for t in ts[1:]:
+                    acc = torch.bitwise_or(acc, t)
+                folded.append(acc.reshape(1))
+            _pending_ot_status.items = folded
     return S
 
 

@@ -71,7 +71,9 @@ class EncoderTable:
             blk.kp_wt = _p(wt)
             from . import functional as F
             if F.gemm_split_enabled() and F.gemm_split_ok(wt.shape[0], wt.shape[1]):
-                blk.kp_wt_split = _p(b.KPConv.weights_t_split())
+                wts = b.KPConv.weights_t_split()           # owned by the module's cache: keep it alive with the table (a submodule-level
+                self.keep.append(wts)                      # _apply drops that cache without invalidating this table)
+                blk.kp_wt_split = _p(wts)
             blk.normconv_w, blk.normconv_b = _p(b.norm_conv.norm.weight), _p(b.norm_conv.norm.bias)
             blk.unary1, blk.unary2, blk.shortcut = _unary(b.unary1, self.keep), _unary(b.unary2, self.keep), _unary(b.unary_shortcut, self.keep)
         self.w = w

@@ -447,6 +447,12 @@ class DescriptorPipeline:
                             k, (pts, lens, up_ev, up_slot) = nxt
                             st.wait_event(up_ev)              # the H2D copy of this batch (copy stream)
                             try:
+                                if self.raw_voxel is None:
+                                    # pre-voxelised host batches: stage 0 of the data dictionary IS the input (points[0], lengths[0],
+                                    # segment_lengths[0] are the tensors handed in), so it must not live in the ring slot — the feeder
+                                    # overwrites the slot with batch k + slots as soon as it is released, long before the encoder of
+                                    # batch k has run.  Raw mode rebuilds stage 0 inside the arena and needs no copy.
+                                    pts, lens = pts.clone(), lens.clone()
                                 dd = self.preprocess_arena(pts, lens)     # returns after synchronising `st`: the slot is dead
                             finally:
                                 ingest.release(up_slot)

@@ -262,6 +262,37 @@ def test_host_xyzi_batches_give_the_resident_descriptors_bit_for_bit():
         list(DescriptorPipeline(m, neighbor_limits=limits, overlap=True).run(host_batches[:1]))
 
 
+def test_prevoxelised_host_batches_do_not_alias_the_upload_ring():
+    """Host batches of PRE-VOXELISED [n,3] points (raw_voxel=None): stage 0 of the data dictionary is the input itself, so the pipeline
+    must copy it out of the upload ring before the slot is handed back — with more batches than ring slots the feeder otherwise
+    overwrites points[0] / lengths[0] of batch k with batch k + slots before the encoder of batch k has run (advisor, round 4).
+    Batches of different scans and sizes, twice round the ring, against the resident path bit for bit."""
+    from lcrnet_amd.data import voxelize_raw_scans
+    from lcrnet_amd.pipeline import DescriptorPipeline
+    m = _ingest_model()
+    names = [["003854", "000958"], ["004481"], ["000026", "000560", "003528"], ["003854"], ["000958", "004481"], ["000560"], ["003528", "000026"]]
+    dev_batches, host_batches = [], []
+    for k, grp in enumerate(names * 3):                   # 21 batches through a ring of depth + W + 1 slots
+        scans = [load_scan(n) + np.float32(0.01 * (k // len(names))) for n in grp]
+        xyz = torch.from_numpy(np.concatenate(scans).astype(np.float32)).cuda()
+        lens = torch.tensor([len(s) for s in scans], dtype=torch.int64).cuda()
+        p, l, lh = voxelize_raw_scans(xyz, lens, 0.3)
+        p = p[:sum(lh)].contiguous()
+        dev_batches.append((p, l))
+        hp = p.cpu()
+        host_batches.append((hp.pin_memory() if k % 2 == 0 else hp, l.cpu()))
+    limits = [74, 68, 70, 67]
+    with DescriptorPipeline(m, neighbor_limits=limits, raw_voxel=None, overlap=True) as pipe:
+        pipe.enable_dual_encoder()
+        want = [d.clone() for d in pipe.run(dev_batches)]
+        for rep in range(2):
+            got = [d.clone() for d in pipe.run(host_batches)]
+            torch.cuda.synchronize()
+            assert len(got) == len(want)
+            for k, (a, b) in enumerate(zip(want, got)):
+                assert a.shape == b.shape and torch.equal(a, b), f"batch {k} (pass {rep})"
+
+
 def test_weights_reloaded_through_cpu_do_not_meet_stale_derived_tensors():
     """model.cpu() -> load_state_dict(other seed) -> model.cuda(): every buffer is a NEW tensor with version 0, and the caching
     allocator readily puts it at the address of the one it replaces — the derived-tensor caches (host copy of the kernel points,
