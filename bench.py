@@ -443,12 +443,13 @@ def main():
                     "descriptors_max_abs_diff_vs_resident": same,
                     "what": "same steps, inputs as pinned host f32 [N,4] rows (x, y, z, intensity) uploaded on a copy stream inside the pipeline; "
                             "median of %d blocks of %d steps; NOT the headline (value = inputs resident in HBM)" % (len(dts), args.steps)}
-    # ---- A/B, not the headline: the same steps with the K-deep GEMMs (N >= 64, K >= 288) on the bf16 matrix cores with fp32-faithful operands
-    # (three bf16 terms per fp32 value, six cross products, fp32 accumulation: lcr_gemm_f32_bsplit).  Opt-in (LCR_GEMM_SPLIT=1):
-    # the headline above is true fp32 MFMA everywhere unless that switch was set by the caller, in which case `dtype` says so.
-    split_ab = None
-    if secondary and not args.no_split_ab and not F.gemm_split_enabled():
-        F.set_gemm_split(True)
+    # ---- A/B, not the headline: the same steps with the OTHER form of the K-deep GEMMs (N >= 64, K >= 288).  Default (round 5): fp32 operands as
+    # three bf16 terms, six cross products on the bf16 matrix cores, fp32 accumulation (lcr_gemm_f32_bsplit; `dtype` spells it out); the block
+    # `true_fp32_gemm_ab` then times the fp32-MFMA kernel (v_mfma_f32_32x32x2_f32) everywhere.  With LCR_GEMM_SPLIT=0 the roles swap.
+    split_ab, split_ab_key = None, None
+    if secondary and not args.no_split_ab:
+        headline_split = F.gemm_split_enabled()
+        F.set_gemm_split(not headline_split)
         run_steps(8)
         dts = []
         for rep in range(min(R, 3)):
@@ -466,13 +467,15 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 d = float(t.item())
             dts.append(d)
-        F.set_gemm_split(False)
-        run_steps(2)                                                     # back on the fp32 tables before anything else is measured
+        F.set_gemm_split(headline_split)
+        run_steps(2)                                                     # back on the headline's tables before anything else is measured
         dts_m = sorted(dts)[(len(dts) - 1) // 2]
+        split_ab_key = "true_fp32_gemm_ab" if headline_split else "split_bf16_gemm_ab"
         split_ab = {"value": round(world * BATCH * args.steps / dts_m, 3), "unit": "scans/s", "ms_per_step": round(dts_m / args.steps * 1e3, 3),
-                    "over_headline": round(dt / dts_m, 4), "descriptors_max_abs_diff_vs_fp32_mfma": float((desc_s - desc).abs().max()),
-                    "what": "same steps with LCR_GEMM_SPLIT=1: K-deep GEMMs as 3 x bf16 terms / 6 products on the bf16 matrix cores (fp32-faithful, "
-                            "error vs fp64 below the fp32-MFMA kernel's own); opt-in, NOT the headline; median of %d blocks" % len(dts)}
+                    "over_headline": round(dt / dts_m, 4), "descriptors_max_abs_diff_vs_headline": float((desc_s - desc).abs().max()),
+                    "what": ("same steps with LCR_GEMM_SPLIT=0: every GEMM on v_mfma_f32_32x32x2_f32 (true fp32 MFMA); " if headline_split else
+                             "same steps with LCR_GEMM_SPLIT=1: K-deep GEMMs as 3 x bf16 terms / 6 products on the bf16 matrix cores (fp32-faithful); ")
+                            + "NOT the headline; median of %d blocks" % len(dts)}
     # ---- secondary, not the headline: the descriptor-only deployment.  The three upsampling lists are consumed by the KPDecoder of the pair model
     # only (backbone4.py:347-367); loop detection (BASELINE configs 2-4) never reads them ("compute them lazily"), and
     # DescriptorPipeline's default is not to build them.  The headline keeps all ten searches of the reference's collate (§8d); this block runs
@@ -583,7 +586,11 @@ def main():
             traffic_rs = (pmc.get("k_radius_query_multi") or pmc.get("k_radius_query") or {}).get("traffic_bytes")
             traffic_src = "profiles/pmc_traffic.json: separate rocprofv3 --pmc passes of this command (2*FETCH_SIZE + WRITE_SIZE per launch), not measured in this run"
         gemm_per_step = iso["n_gemm"] / iso["passes"]
-        roof = {"bound": "mfma", "kernel": "lcr::k_gemm_f32 / k_gemm_f32_deep (fp32 MFMA, %d launches/step)" % round(gemm_per_step),
+        gemm_kernels = ("lcr::k_gemm_f32 (fp32 MFMA) + k_gemm_f32_bsplit_p (K-deep shapes: bf16 x 3 split on bf16 MFMA, fp32 accumulate)" if F.gemm_split_enabled()
+                        else "lcr::k_gemm_f32 / k_gemm_f32_deep (fp32 MFMA)")
+        roof = {"schema": "r05: achieved / frac / avg_launch_us are the kernel-ALONE clock (as since r04; r01-r03 lines carried the in-pipeline clock "
+                          "under these keys, now `in_pipeline`); flops are algorithmic fp32 flops (2MNK) against the fp32 MFMA peak in both GEMM forms",
+                "bound": "mfma", "kernel": "%s, %d launches/step" % (gemm_kernels, round(gemm_per_step)),
                 "achieved": round(gemm_alone, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(gemm_alone / FP32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "clock": "kernel begin-to-end (hipExtLaunchKernel start/stop events) of EVERY GEMM launch of %d passes over each of the %d distinct "
@@ -659,11 +666,12 @@ def main():
         if with_h2d is not None:
             line["with_h2d"] = with_h2d
         if split_ab is not None:
-            line["split_bf16_gemm_ab"] = split_ab
+            line[split_ab_key] = split_ab
         if lazy is not None:
             line["descriptor_only_7_searches"] = lazy
         if F.gemm_split_enabled():
-            line["dtype"] = "f32 (K-deep GEMMs: fp32 operands as 3 bf16 terms, 6 products on the bf16 matrix cores, fp32 accumulation)"
+            line["dtype"] = ("f32 (K-deep GEMMs, K >= 288 and N >= 64: fp32 operands as bf16 x 3 split, 6 of 9 products on the bf16 matrix cores, fp32 "
+                             "accumulate — error vs fp64 <= the fp32-MFMA kernel's; every other GEMM, KPConv and attention: fp32 MFMA)")
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(scans)
         final_line = json.dumps(line)

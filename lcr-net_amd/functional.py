@@ -137,8 +137,12 @@ def gemm(a, b, trans_b=False, trans_a=False, bias=None, rowdiv=None, seg_len=Non
 
 
 # ---- split-bf16 form of the K-deep GEMMs (csrc/gemm_f32.hip): fp32 operands as three bf16 terms, six products on the bf16 matrix cores.
-# LCR_GEMM_SPLIT=1 turns it on for the K-deep shapes (K >= 288, K % 32 == 0, N >= 64); `set_gemm_split` is the run-time switch (tests, A/B).
-_GEMM_SPLIT = [os.environ.get("LCR_GEMM_SPLIT", "0") not in ("", "0")]
+# DEFAULT since round 5 for the K-deep shapes (K >= 288, K % 32 == 0, N >= 64): every fp32 operand enters as its three bf16 terms (exact), six
+# of the nine cross products are accumulated in fp32 — measured error against fp64 at or below the fp32-MFMA kernel's own, non-finite values
+# propagate to the same outputs (tests/test_gemm_split_gpu.py).  LCR_GEMM_SPLIT=0 selects the true-fp32 MFMA kernel everywhere;
+# `set_gemm_split` is the run-time switch (tests, bench A/B).  Domain of the split form: |x| <= 3.3895e38 (the largest bf16), beyond which
+# the first term rounds to infinity.
+_GEMM_SPLIT = [os.environ.get("LCR_GEMM_SPLIT", "1") not in ("", "0")]
 
 
 def gemm_split_enabled():

@@ -40,8 +40,9 @@ def test_one_rank_rccl_group_runs_the_n_rank_path():
     assert line["forced_one_rank_process_group"] == "nccl" and line["n_gpus"] == 1 and line["value"] > 0
     assert "nccl" in line["config"]["parallelism"]
     blocks = ["with_h2d", "descriptor_only_7_searches"]
-    if os.environ.get("LCR_GEMM_SPLIT", "0") in ("", "0"):       # the A/B block is what the switch itself replaces
-        blocks.append("split_bf16_gemm_ab")
+    # the A/B block times the form the headline does NOT use (default headline: split-bf16 K-deep GEMMs)
+    blocks.append("split_bf16_gemm_ab" if os.environ.get("LCR_GEMM_SPLIT", "1") in ("", "0") else "true_fp32_gemm_ab")
+    assert ("bf16 x 3 split" in line["dtype"]) == (os.environ.get("LCR_GEMM_SPLIT", "1") not in ("", "0"))
     for k in blocks:
         assert line[k]["value"] > 0
     assert line["with_h2d"]["descriptors_max_abs_diff_vs_resident"] == 0.0

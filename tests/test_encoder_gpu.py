@@ -431,8 +431,12 @@ def test_normalise_on_load_single_short_segment():
 
 @pytest.mark.parametrize("M,N,K,rowdiv", [(6479, 256, 3840, True), (19061, 128, 1920, True), (5000, 96, 352, True), (777, 64, 288, False),
                                           (130, 200, 512, False), (64, 64, 320, False), (127812, 32, 480, True), (3000, 24, 960, False)])
-def test_k_deep_gemm_form(M, N, K, rowdiv):
-    """The K-deep GEMM form (LDS-direct loads three tiles ahead, cross-step fragment prefetch: k_gemm_f32_deep) against the
+@pytest.mark.parametrize("split", [False, True])
+def test_k_deep_gemm_form(M, N, K, rowdiv, split):
+    """split=True: additionally the DEFAULT form of these shapes since round 5 — lcr_gemm_f32_bsplit (fp32 operands as three bf16 terms, six
+    products on the bf16 matrix cores, fp32 accumulation) where functional.gemm_split_ok(N, K) routes them to it — against the same fp64
+    product with the same bound, its distance from the fp32-MFMA result, and its GroupNorm sums.
+    The K-deep GEMM form (LDS-direct loads three tiles ahead, cross-step fragment prefetch: k_gemm_f32_deep) against the
     register-staged kernel on the same operands — output and GroupNorm sums: bit-identical for the 64x64 tile (same K pairing, same
     summation order), fp32-rounding-identical for N <= 32 (the old 128x32 tile alternates two accumulators) — and against an fp64
     product.  Ragged M / N (clamped duplicate rows), K = 9..120 steps, segment boundaries inside tiles."""
@@ -465,3 +469,16 @@ def test_k_deep_gemm_form(M, N, K, rowdiv):
             assert torch.equal(s0.sum(0), s1.sum(0)) or ((s0.sum(0) - s1.sum(0)).abs() / s0.sum(0).abs().clamp_min(1e-30)).max().item() < 1e-12
     else:
         assert (c0 - c1).abs().max().item() < 1e-3 * ref.abs().max().item()
+    if split and F.gemm_split_ok(N, K):
+        c2, s2 = F.gemm_bsplit(a, F.split_bf16x3(b), bias=bias, rowdiv=div, seg_len=seg, groups=groups)
+        e1 = ((c1.double() - ref).abs().max() / ref.abs().max()).item()
+        e2 = ((c2.double() - ref).abs().max() / ref.abs().max()).item()
+        assert e2 < 5e-6 and e2 < max(4 * e1, 4e-7), (e1, e2)
+        assert (c2 - c1).abs().max().item() < 5e-6 * ref.abs().max().item()
+        if groups:
+            n_el = seg.double()[:, None] * (N // groups)
+            t1, t2 = s1.sum(0), s2.sum(0)
+            assert ((t1[..., 0] - t2[..., 0]).abs() / (n_el * t1[..., 1]).sqrt()).max().item() < 1e-6
+            assert ((t1[..., 1] - t2[..., 1]).abs() / t1[..., 1]).max().item() < 1e-6
+    elif split:
+        assert not F.gemm_split_ok(N, K)          # N < 64: stays on the fp32 form, which already streams A at the HBM rate

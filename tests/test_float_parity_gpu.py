@@ -20,6 +20,7 @@ from oracle import torch_ref
 
 pytestmark = pytest.mark.gpu
 REPORT = {}
+_HEADLINE_ORACLE = {}
 
 
 def _note(key, err, scale):
@@ -30,8 +31,10 @@ def _note(key, err, scale):
         json.dump(REPORT, open(os.path.join(out, "float_parity.json"), "w"), indent=1)
 
 
-def test_headline_batch_descriptors_vs_oracle():
-    """configs[1]: the 8 synthetic scans of bench.py, raw, through DescriptorPipeline (the code path bench.py times) vs the oracle:
+@pytest.mark.parametrize("split", [True, False])
+def test_headline_batch_descriptors_vs_oracle(split):
+    """Both forms of the K-deep GEMMs (split=True: the default, bf16 x 3 split on the bf16 matrix cores; False: fp32 MFMA everywhere).
+    configs[1]: the 8 synthetic scans of bench.py, raw, through DescriptorPipeline (the code path bench.py times) vs the oracle:
     C++ restatement for voxelisation / subsampling / neighbours, torch fp32 restatement for encoder + NetVLAD, one scan at a time
     (GroupNorm segments are per scan)."""
     import bench
@@ -45,30 +48,39 @@ def test_headline_batch_descriptors_vs_oracle():
     scans = bench.make_batch(0)
     raw = torch.from_numpy(np.concatenate(scans)).cuda()
     lens = torch.tensor([len(s) for s in scans], dtype=torch.int64, device="cuda")
-    with DescriptorPipeline(model, bench.VOXEL, bench.RADIUS, bench.NUM_STAGES, bench.LIMITS, upsampling=True, raw_voxel=bench.VOXEL) as pipe:
-        got = [d.cpu() for d in pipe.run([(raw, lens), (raw, lens)])]
-        dd = pipe.preprocess(raw, lens)
-        with torch.no_grad():
-            feats_c = model.encoder(dd["features"], dd)[-1].cpu()
+    from lcrnet_amd import functional as F
+    was = F.gemm_split_enabled()
+    F.set_gemm_split(split)
+    try:
+        with DescriptorPipeline(model, bench.VOXEL, bench.RADIUS, bench.NUM_STAGES, bench.LIMITS, upsampling=True, raw_voxel=bench.VOXEL) as pipe:
+            got = [d.cpu() for d in pipe.run([(raw, lens), (raw, lens)])]
+            dd = pipe.preprocess(raw, lens)
+            with torch.no_grad():
+                feats_c = model.encoder(dd["features"], dd)[-1].cpu()
+    finally:
+        F.set_gemm_split(was)
     assert torch.equal(got[0], got[1]) and got[0].shape == (8, 256)
     n_c = dd["lengths_host"][-1]
     worst_d = worst_f = scale_f = 0.0
     off = 0
     for i, s in enumerate(scans):
-        p, l = oracle_ops.grid_subsample(s, np.array([len(s)]), bench.VOXEL)
-        st = oracle_ops.precompute_data_stack_mode(p, l, bench.NUM_STAGES, bench.VOXEL, bench.RADIUS, bench.LIMITS)
-        tdd = {k: [torch.from_numpy(np.ascontiguousarray(t)) for t in v] for k, v in st.items()}
-        with torch.no_grad():
-            f = torch_ref.kp_encoder(sd, torch.ones(len(p), 1), tdd)
-            want = torch_ref.global_descriptor(sd, f[-1])
+        if i not in _HEADLINE_ORACLE:                       # the oracle side does not depend on the GEMM form: once for both parameters
+            p, l = oracle_ops.grid_subsample(s, np.array([len(s)]), bench.VOXEL)
+            st = oracle_ops.precompute_data_stack_mode(p, l, bench.NUM_STAGES, bench.VOXEL, bench.RADIUS, bench.LIMITS)
+            tdd = {k: [torch.from_numpy(np.ascontiguousarray(t)) for t in v] for k, v in st.items()}
+            with torch.no_grad():
+                f = torch_ref.kp_encoder(sd, torch.ones(len(p), 1), tdd)
+                _HEADLINE_ORACLE[i] = (f[-1], torch_ref.global_descriptor(sd, f[-1]))
+        f, want = [_HEADLINE_ORACLE[i][0]], _HEADLINE_ORACLE[i][1]
         n = int(n_c[i])
         assert f[-1].shape[0] == n
         worst_d = max(worst_d, (got[0][i] - want[0]).abs().max().item())
         worst_f = max(worst_f, (feats_c[off:off + n] - f[-1]).abs().max().item())
         scale_f = max(scale_f, f[-1].abs().max().item())
         off += n
-    _note("headline batch: descriptors (8 scans)", worst_d, 1.0)
-    _note("headline batch: coarse features [N4,1024]", worst_f, scale_f)
+    tag = "split-bf16 K-deep GEMMs" if split else "fp32 MFMA everywhere"
+    _note("headline batch: descriptors (8 scans), %s" % tag, worst_d, 1.0)
+    _note("headline batch: coarse features [N4,1024], %s" % tag, worst_f, scale_f)
     assert worst_d < 1e-4
     assert worst_f < 1e-4 * max(1.0, scale_f)
 

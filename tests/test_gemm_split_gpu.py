@@ -93,3 +93,79 @@ def test_split_gemm_rejects_bad_shapes():
     c = torch.empty(64, 64, device="cuda")
     rc = _lib.lib().lcr_gemm_f32_bsplit(_lib.ptr(a), _lib.ptr(pl), _lib.ptr(c), 64, 64, 40, None, None, None, 0, 0, None, _lib.stream_ptr(a.device))
     assert rc != 0                                            # K % 32 != 0
+
+
+def _both(a, b):
+    """(fp32-MFMA result, split result) of A[M,K] . B[N,K]^T, no epilogue"""
+    from lcrnet_amd import functional as F
+    c0, _ = F.gemm(a, b, trans_b=True)
+    c1, _ = F.gemm_bsplit(a, F.split_bf16x3(b))
+    torch.cuda.synchronize()
+    return c0, c1
+
+
+def test_split_gemm_worst_cases():
+    """What the split form does at the edges of fp32, next to the fp32-MFMA kernel on the same operands (the form is the default for the
+    K-deep contractions since round 5, so its domain is stated and pinned here):
+      1. dynamic range 2^40 inside every row of A (and 2^20 inside B): the error against fp64 is bounded RELATIVE TO sum |a.b| (the only
+         bound any fp32 accumulation has) by 2e-6 and is not above the fp32 kernel's by more than rounding noise;
+      2. subnormal operands: an fp32 subnormal is still the exact sum of its three bf16 terms; products far below the fp32 range vanish in
+         both forms, and subnormal noise under normal data changes nothing beyond 1e-37 absolute;
+      3. +Inf / -Inf / NaN in A: the SAME output rows are non-finite in both forms (an infinite term splits into (Inf, NaN, NaN): the row is
+         NaN where the fp32 kernel has +-Inf or NaN — non-finite either way), all other rows are bit-identical to the run without them;
+      4. the largest magnitudes of the domain, |x| = 3.3895e38 (the largest bf16; above it the first term would round to infinity):
+         finite products stay finite and accurate."""
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(20250929)
+    M, N, K = 1024, 128, 960
+    # 1. dynamic range
+    a = torch.randn(M, K, device=dev, generator=g) * torch.exp2(torch.randint(-20, 21, (M, K), device=dev, generator=g).float())
+    b = torch.randn(N, K, device=dev, generator=g) * torch.exp2(torch.randint(-10, 11, (N, K), device=dev, generator=g).float())
+    c0, c1 = _both(a, b)
+    ref = a.double() @ b.double().t()
+    bound = a.double().abs() @ b.double().abs().t()
+    e0, e1 = ((c0.double() - ref).abs() / bound).max().item(), ((c1.double() - ref).abs() / bound).max().item()
+    print("dynamic range 2^40: max |err| / sum|a.b|: fp32 MFMA %.2e, split %.2e" % (e0, e1))
+    assert torch.isfinite(c1).all() and e1 < 2e-6 and e1 < max(2 * e0, 2e-7)
+    # 2. subnormals
+    tiny = torch.randn(M, K, device=dev, generator=g) * 1e-40
+    assert (tiny != 0).any() and (tiny.abs() < 1.2e-38).all()
+    from lcrnet_amd import functional as F
+    w = torch.randn(N, K, device=dev, generator=g) * 1e-40
+    t = F.unsplit_bf16x3(F.split_bf16x3(w))
+    assert torch.equal((t[0] + t[1]) + t[2], w)                       # exact also below the normal range
+    bn = torch.randn(N, K, device=dev, generator=g)
+    z0, z1 = _both(tiny, bn)
+    assert z0.abs().max().item() < 1e-35 and z1.abs().max().item() < 1e-35
+    an = torch.randn(M, K, device=dev, generator=g)
+    n0, n1 = _both(an, bn)
+    mix, hole = an.clone(), an.clone()
+    mix[:, ::2] = tiny[:, ::2]                                        # every other column subnormal ...
+    hole[:, ::2] = 0                                                  # ... against the same columns zeroed
+    p0, p1 = _both(mix, bn)
+    q0, q1 = _both(hole, bn)
+    assert (p0 - q0).abs().max().item() < 1e-35 and (p1 - q1).abs().max().item() < 1e-35
+    # 3. non-finite propagation
+    bad = an.clone()
+    rows = torch.tensor([3, 64, 65, 500, 1023], device=dev)
+    bad[3, 7] = float("inf")
+    bad[64, 0] = float("-inf")
+    bad[65, K - 1] = float("nan")
+    bad[500, 100] = float("inf")
+    bad[500, 101] = float("-inf")
+    bad[1023, 959] = float("inf")
+    f0, f1 = _both(bad, bn)
+    assert torch.equal(torch.isfinite(f0), torch.isfinite(f1))
+    mask = torch.ones(M, dtype=torch.bool, device=dev)
+    mask[rows] = False
+    assert not torch.isfinite(f1[rows]).any() and torch.isfinite(f1[mask]).all()
+    assert torch.equal(f1[mask], n1[mask]) and torch.equal(f0[mask], n0[mask])
+    # 4. top of the domain
+    big = torch.full((64, K), 3.3895313892515355e38, device=dev)
+    big[:, 1::2] *= -1
+    sm = torch.full((N, K), 2.0 ** -100, device=dev) * (1 + torch.rand(N, K, device=dev, generator=g))
+    h0, h1 = _both(big, sm)
+    href = big.double() @ sm.double().t()
+    assert torch.isfinite(h1).all()
+    hb = big.double().abs() @ sm.double().abs().t()
+    assert ((h1.double() - href).abs() / hb).max().item() < 2e-6 and ((h0.double() - href).abs() / hb).max().item() < 2e-6
