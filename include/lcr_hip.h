@@ -125,6 +125,9 @@ typedef struct LcrRadiusQuery {
 } LcrRadiusQuery;
 #define LCR_RADIUS_QUERY_MULTI_MAX 12   /* searches per lcr_radius_query_multi launch; longer lists: call it on slices */
 int lcr_radius_query_multi(const LcrRadiusQuery* list, int n, int B, void* stream);
+/* Sizing counters of the lane-per-query search kernel (environment LCR_RS_LPQ=2 only; measurement harness): out_host[0..4] = tiles,
+ * passes over tiles, staged candidates, queries served, queries redone by the wave form.  Synchronous; reset != 0 clears them. */
+int lcr_radius_lpq_stats(unsigned long long* out_host, int reset);
 /* Same build that also writes the cell-sorted processing order (what lcr_support_grid_order returns) into order i32[ns_cap]. */
 int lcr_support_grid_build_ex(const float* s, const int64_t* slen, int B, int64_t ns_cap, float radius,
                               uint32_t* status, void* grid_ws, size_t grid_ws_bytes, int32_t* order, void* stream);

@@ -92,11 +92,16 @@ def _check_pose(out, gold, tag):
     T, Tw = out["estimated_transform"].cpu().numpy(), gold[tag + "_estimated_transform"]
     assert T.shape == (4, 4) and abs(np.linalg.det(T[:3, :3]) - 1) < 1e-4
     assert np.abs(T[3] - np.array([0, 0, 0, 1.0])).max() == 0
-    cosang = (np.trace(T[:3, :3].T @ Tw[:3, :3]) - 1) / 2
-    rre, rte = np.degrees(np.arccos(np.clip(cosang, -1, 1))), np.linalg.norm(T[:3, 3] - Tw[:3, 3])
+    # small-angle form (acos((tr - 1) / 2) of fp32 matrices has a floor of ~0.03 degrees)
+    rre = np.degrees(np.linalg.norm(T[:3, :3].astype(np.float64).T @ Tw[:3, :3].astype(np.float64) - np.eye(3)) / np.sqrt(2.0))
+    rte = np.linalg.norm(T[:3, 3] - Tw[:3, 3])
     n, nw = out["corr_scores"].shape[0], int(gold[tag + "_num_corr"])
-    print("%s: pose vs the reference's %.3f deg / %.3f m, correspondences %d vs %d" % (tag, rre, rte, n, nw))
-    assert rre < 2.0 and rte < 0.5, (T, Tw)
+    # bound for THIS (unstable) pair: three times what the reference's own pose moves under one fp32 rounding of its inputs
+    # (pose_e2e_golden.npz, measured by tests/golden/make_golden_pose_e2e.py); the 1e-4 pose claim is held on the stable planted pair below
+    e2e = np.load(os.path.join(GOLDEN, "pose_e2e_golden.npz"))
+    tol_deg, tol_m = max(3 * float(e2e["demo_pair_reference_jitter_deg"]), 1e-4), max(3 * float(e2e["demo_pair_reference_jitter_m"]), 1e-4)
+    print("%s: pose vs the reference's %.4f deg / %.4f m (bound %.4f deg / %.4f m), correspondences %d vs %d" % (tag, rre, rte, tol_deg, tol_m, n, nw))
+    assert rre < tol_deg and rte < tol_m, (T, Tw)
     assert abs(n - nw) <= 0.05 * nw, (n, nw)
     sc = out["corr_scores"].cpu().numpy()
     assert np.isfinite(sc).all() and (sc >= 0).all() and (sc <= 1 + 1e-3).all()
@@ -146,3 +151,31 @@ def test_lcrnet_matching_infer_forward(gold):
         outs = m.forward_pairs(dd4)
     assert len(outs) == 2 and outs[0]["length"].cpu().tolist() == gold["infer_length"].tolist()
     assert np.abs(outs[0]["pos_points_c"].cpu().numpy() - gold["infer_pos_points_c"]).max() < TOL
+
+
+@pytest.mark.parametrize("which", ["eval", "infer"])
+def test_entry_points_on_the_stable_planted_pair(which):
+    """Both registration-model entry points on the planted-motion pair of tests/golden/make_golden_pose_e2e.py, where the reference's own pose
+    is stable (4e-6 under one fp32 rounding of the inputs): estimated_transform within 1e-4 / 1e-4 m, node correspondences equal as sets,
+    point correspondences equal up to threshold cases, scores within 1e-4; for the evaluation class also the node matching scores (the
+    whole (M+1, N+1) transport plan, valid entries) within 1e-4 and the overlap score."""
+    from test_pose_gpu import check_planted_pose, planted_pair_dict
+    from lcrnet_amd.model_family import LCRNet_Matching, LCRNet_Matching_infer
+    dd, gold = planted_pair_dict()
+    m = _model(LCRNet_Matching if which == "eval" else LCRNet_Matching_infer)
+    assert int(gold["model_seed"]) == json.load(open(os.path.join(GOLDEN, "model_manifest.json")))["seed"]
+    if which == "eval":
+        dd["transform"] = torch.from_numpy(gold["transform_gt"]).cuda()
+    with torch.no_grad():
+        out = m(dd)
+    check_planted_pose(out, gold, which)
+    if which == "eval":
+        ns, wns = out["node_matching_scores"].cpu().numpy(), gold["eval_node_matching_scores"]
+        assert ns.shape == wns.shape
+        v = np.ones(ns.shape, bool)
+        v[:-1, :] &= gold["eval_pos_node_masks"][:, None]
+        v[:, :-1] &= gold["eval_anc_node_masks"][None, :]
+        e_ns = np.abs(ns - wns)[v].max()
+        e_score = np.abs(out["score"].cpu().numpy() - gold["eval_score"]).max()
+        print("planted pair [eval]: node matching log-scores within %.2e, overlap score within %.2e" % (e_ns, e_score))
+        assert e_ns < TOL and e_score < TOL

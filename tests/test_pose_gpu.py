@@ -312,8 +312,73 @@ def test_pair_model_pose_tail_vs_reference_golden(pair_run):
     assert abs(out["corr_scores"].shape[0] - n) <= 0.05 * n
     T, Tw = out["estimated_transform"].numpy(), gold["estimated_transform"]
     assert abs(np.linalg.det(T[:3, :3]) - 1) < 1e-4
-    # the pose of a RANDOM-weight model is a consensus over ~4 k near-uniform matches: compare loosely (exact-weight parity is
-    # pinned op by op above); rotation within 2 degrees, translation within 0.5 m of the reference's
-    cosang = (np.trace(T[:3, :3].T @ Tw[:3, :3]) - 1) / 2
-    assert np.degrees(np.arccos(np.clip(cosang, -1, 1))) < 2.0, (T, Tw)
-    assert np.linalg.norm(T[:3, 3] - Tw[:3, 3]) < 0.5, (T, Tw)
+    # the pose of THIS pair under random weights is a consensus over ~4 k near-uniform matches, and it is not stable in the reference
+    # itself: under one fp32 rounding of the inputs the reference's own estimated_transform moves by demo_pair_reference_jitter_deg /
+    # _m (tests/golden/make_golden_pose_e2e.py).  The bound here is three times that measured spread (floor 1e-4) — the 1e-4 claim for
+    # the end-to-end pose rests on the stable planted-motion case below (test_planted_motion_pose_end_to_end_within_1e4).
+    e2e = np.load(os.path.join(GOLDEN, "pose_e2e_golden.npz"))
+    tol_deg = max(3 * float(e2e["demo_pair_reference_jitter_deg"]), 1e-4)
+    tol_m = max(3 * float(e2e["demo_pair_reference_jitter_m"]), 1e-4)
+    # small-angle form (acos((tr - 1) / 2) of fp32 matrices has a floor of ~0.03 degrees)
+    rre = np.degrees(np.linalg.norm(T[:3, :3].astype(np.float64).T @ Tw[:3, :3].astype(np.float64) - np.eye(3)) / np.sqrt(2.0))
+    rte = np.linalg.norm(T[:3, 3] - Tw[:3, 3])
+    print("demo pair pose vs the reference's: %.4f deg / %.4f m (bound: 3 x the reference's own jitter spread = %.4f deg / %.4f m)" % (rre, rte, tol_deg, tol_m))
+    assert rre < tol_deg and rte < tol_m, (T, Tw)
+
+
+# ---- a STABLE end-to-end pose case at the north star's 1e-4 ----------------------------------------------------
+def planted_pair_dict():
+    """demo scan 003854 and its planted rigid motion (3 degrees about z, (1.6, -0.9, 0.12) m, 5 mm noise, 12 % dropped), as stored in the
+    fixture of tests/golden/make_golden_pose_e2e.py: under seeded random weights the REFERENCE's own estimated_transform moves by 4e-6 under
+    one fp32 rounding of these inputs (fixture field jitter_transform_spread) and its node correspondences not at all."""
+    gold = np.load(os.path.join(GOLDEN, "pose_e2e_golden.npz"))
+    a, b = load_scan("003854"), gold["cloud_b"]
+    st = oracle_ops.precompute_data_stack_mode(np.concatenate([a, b]), np.array([len(a), len(b)]), NUM_STAGES, VOXEL, RADIUS, LIMITS)
+    dd = {k: [torch.from_numpy(np.ascontiguousarray(t)).cuda() for t in v] for k, v in st.items()}
+    dd["features"] = torch.ones(len(a) + len(b), 1, device="cuda")
+    return dd, gold
+
+
+def check_planted_pose(out, gold, tag=""):
+    """estimated_transform within 1e-4 (rotation entries) / 1e-4 m of the reference's, node correspondences equal as sets, point
+    correspondences equal as sets (up to the few whose matching score sits on the acceptance threshold: bounded by 0.2 % and reported),
+    scores of the shared ones within 1e-4."""
+    pre = (tag + "_") if tag else ""
+    T, Tw = out["estimated_transform"].cpu().numpy().astype(np.float64), gold[pre + "estimated_transform"].astype(np.float64)
+    assert float(gold["jitter_transform_spread"]) < 2e-5                    # the case IS stable in the reference
+    e_rot, e_t = np.abs(T[:3, :3] - Tw[:3, :3]).max(), np.abs(T[:3, 3] - Tw[:3, 3]).max()
+    if tag:
+        got_nodes = set(zip(out["pos_node_corr_indices"].cpu().tolist(), out["anc_node_corr_indices"].cpu().tolist()))
+        want_nodes = set(map(tuple, gold[pre + "node_corr"].tolist()))
+    else:
+        got_nodes = set(zip(out["pos_node_corr_indices"].cpu().tolist(), out["anc_node_corr_indices"].cpu().tolist()))
+        want_nodes = set(zip(gold["pos_node_corr_indices"].tolist(), gold["anc_node_corr_indices"].tolist()))
+    key = lambda p, q: list(map(tuple, np.concatenate([p, q], axis=1).astype(np.float32).view(np.uint32).tolist()))
+    gk = key(out["pos_corr_points"].cpu().numpy(), out["anc_corr_points"].cpu().numpy())
+    wk = key(gold[pre + "pos_corr_points"], gold[pre + "anc_corr_points"])
+    gs, ws = dict(zip(gk, out["corr_scores"].cpu().numpy().tolist())), dict(zip(wk, gold[pre + "corr_scores"].tolist()))
+    shared = set(gs) & set(ws)
+    e_sc = max(abs(gs[k] - ws[k]) for k in shared)
+    sym = len(set(gs) ^ set(ws))
+    print("planted pair%s: |dR| %.2e |dt| %.2e m; node pairs %d == %d (sym. diff %d); correspondences %d vs %d (sym. diff %d), shared scores within %.2e; "
+          "residual to the planted motion %.1e" % (" [" + tag + "]" if tag else "", e_rot, e_t, len(got_nodes), len(want_nodes), len(got_nodes ^ want_nodes),
+                                                   len(gs), len(ws), sym, e_sc, np.abs(T - np.linalg.inv(gold["planted_transform"])).max()))
+    assert e_rot < 1e-4 and e_t < 1e-4, (T, Tw)
+    assert got_nodes == want_nodes
+    assert sym <= 0.002 * len(ws) and e_sc < 1e-4
+    assert abs(np.linalg.det(T[:3, :3]) - 1) < 1e-5 and np.abs(T[3] - np.array([0, 0, 0, 1.0])).max() == 0
+
+
+def test_planted_motion_pose_end_to_end_within_1e4():
+    from lcrnet_amd.config import make_cfg
+    from lcrnet_amd.model_family import LCRNet
+    from lcrnet_amd.weights import seeded_state_dict
+    dd, gold = planted_pair_dict()
+    cfg = make_cfg()
+    cfg["neighbor_limits"] = LIMITS
+    m = LCRNet(cfg).eval()
+    m.load_state_dict(seeded_state_dict(m.state_dict(), int(gold["model_seed"])), strict=True)
+    m = m.cuda()
+    with torch.no_grad():
+        out = m(dd)
+    check_planted_pose(out, gold)

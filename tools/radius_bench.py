@@ -61,6 +61,40 @@ def main():
             timed("subsampling[%d]" % i, lambda: grids[i].query(P[i + 1], L[i + 1], bench.LIMITS[i]))
             timed("upsampling[%d]" % i, lambda: grids[i + 1].query(P[i], L[i], bench.LIMITS[i + 1]))
     print("total %.1f us" % total)
+    # the production configuration (csrc/precompute.hip): every search walks its queries in the QUERY set's own cell order (q_order)
+    total = 0.0
+    orders = [g.order() for g in grids]
+    outs = {}
+
+    def timed_o(tag, fn):
+        timed(tag, fn)
+        outs[tag] = fn()
+    for i in range(bench.NUM_STAGES):
+        timed_o("ordered neighbors[%d]" % i, lambda: grids[i].query(P[i], L[i], bench.LIMITS[i], q_order=orders[i]))
+        if i < bench.NUM_STAGES - 1:
+            timed_o("ordered subsampling[%d]" % i, lambda: grids[i].query(P[i + 1], L[i + 1], bench.LIMITS[i], q_order=orders[i + 1]))
+            timed_o("ordered upsampling[%d]" % i, lambda: grids[i + 1].query(P[i], L[i], bench.LIMITS[i + 1], q_order=orders[i]))
+    print("total with q_order (production) %.1f us" % total)
+    if os.environ.get("LCR_RB_CHECK"):
+        # rows against the un-ordered call (always the wave form) — bit-identical whatever kernel served the ordered call
+        bad = 0
+        for i in range(bench.NUM_STAGES):
+            ref = {"ordered neighbors[%d]" % i: lambda: grids[i].query(P[i], L[i], bench.LIMITS[i])}
+            if i < bench.NUM_STAGES - 1:
+                ref["ordered subsampling[%d]" % i] = lambda: grids[i].query(P[i + 1], L[i + 1], bench.LIMITS[i])
+                ref["ordered upsampling[%d]" % i] = lambda: grids[i + 1].query(P[i], L[i], bench.LIMITS[i + 1])
+            for tag, fn in ref.items():
+                want = fn()
+                same = torch.equal(want, outs[tag])
+                nbad = int((want != outs[tag]).any(dim=1).sum())
+                print("check %-24s rows equal: %s (%d of %d rows differ)" % (tag, same, nbad, want.shape[0]))
+                bad += nbad
+        print("CHECK", "OK" if bad == 0 else "FAILED (%d rows)" % bad)
+        import ctypes
+        from lcrnet_amd import _lib
+        st = (ctypes.c_ulonglong * 8)()
+        if hasattr(_lib.lib(), "lcr_radius_lpq_stats") and _lib.lib().lcr_radius_lpq_stats(st, 1) == 0:
+            print("lpq stats: tiles %d passes %d staged candidates %d queries %d fallback queries %d" % tuple(st[:5]))
     if os.environ.get("LCR_RB_NO_CELL_ORDER"):
         return
     # the same searches with the QUERIES permuted into their own grid's cell order (spatially coherent wavefronts)
