@@ -41,6 +41,39 @@ def shard_range(n_frames, world, rank):
     return lo, min(lo + per, n_frames)
 
 
+def search_range(n_frames, world, rank, start=START_DEFAULT, exclude=EXCLUDE_DEFAULT):
+    """Query rows [q_lo, q_hi) that `rank` SEARCHES (the descriptors stay owned by shard_range's frame ranges).  The mask j < i - exclude is
+    causal: query i costs (i - exclude) columns, so with the queries split like the frames rank 0 would have almost nothing to do and the
+    last rank 15/64 of the whole search at 8 ranks.  Here the contiguous query range [start, n_frames - 1) is cut where the
+    cumulative work sum(i - exclude) reaches r/world of the total — still contiguous blocks in rank order (the reference's row order is the
+    concatenation, and the kernel keeps its plain global-index compare), equal work per rank to within one row."""
+    a = min(start, n_frames - 1)
+    b = max(n_frames - 1, a)
+    if b <= a:
+        return (a, a)
+
+    def cum(i):
+        """work of rows [a, i): row j costs max(j - exclude, 1) columns (an arithmetic series beyond row exclude + 1)"""
+        k = min(max(exclude + 1, a), i)                            # rows [a, k) cost 1 each
+        flat = k - a
+        return flat + ((k - exclude) + (i - 1 - exclude)) * (i - k) // 2 if i > k else flat
+
+    tot = cum(b)
+    cuts = [a]
+    for r in range(1, world):                                      # exact integer bisection; every rank runs the same arithmetic
+        target = tot * r // world
+        lo, hi = cuts[-1], b
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if cum(mid) < target:
+                lo = mid + 1
+            else:
+                hi = mid
+        cuts.append(lo)
+    cuts.append(b)
+    return cuts[rank], cuts[rank + 1]
+
+
 def all_gather_descriptors(local, n_frames, group=None):
     """local [n_r, D] (this rank's contiguous frame range per shard_range) -> [n_frames, D] on every rank.
     One all_gather_into_tensor of ceil(C/world)-row padded blocks (RCCL over xGMI on GPUs; gloo in the CPU tests)."""
@@ -55,7 +88,7 @@ def all_gather_descriptors(local, n_frames, group=None):
 
 
 def distributed_retrieval(local_desc, n_frames, k=K_DEFAULT, exclude=EXCLUDE_DEFAULT, start=START_DEFAULT, group=None, topk_fn=None):
-    """Every rank: all-gather the descriptors, search the query rows it owns (global frames max(lo,start) .. min(hi, C-1)).
+    """Every rank: all-gather the descriptors, search its share of the query rows (search_range: contiguous, work-balanced).
     Returns (query frame ids [Q_r], idx [Q_r,k], d2 [Q_r,k]).  topk_fn defaults to the HIP kernel; the CPU (gloo) tests pass
     the oracle so that the sharding / exchange logic is exercised without a GPU."""
     import torch.distributed as dist
@@ -63,7 +96,7 @@ def distributed_retrieval(local_desc, n_frames, k=K_DEFAULT, exclude=EXCLUDE_DEF
     lo, hi = shard_range(n_frames, world, rank)
     assert local_desc.shape[0] == hi - lo, "local descriptors must cover exactly this rank's frame range"
     full = all_gather_descriptors(local_desc, n_frames, group)
-    q_lo, q_hi = max(lo, start), min(hi, n_frames - 1)
+    q_lo, q_hi = search_range(n_frames, world, rank, start, exclude)     # equal causal work per rank (not the frame ranges)
     fn = topk_fn or retrieval_topk
     if q_hi <= q_lo:
         e = torch.empty((0, k), device=local_desc.device)

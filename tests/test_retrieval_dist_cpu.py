@@ -61,3 +61,21 @@ def test_shard_range_covers_everything():
             r = [shard_range(n, w, k) for k in range(w)]
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+
+
+def test_search_range_is_contiguous_and_work_balanced():
+    """Query rows are cut by cumulative causal work (row i costs i - exclude columns): contiguous blocks in rank order that tile
+    [start, C - 1) exactly, each within 2 % (or one row) of 1/world of the work; the frame-range split it replaces left rank 0 of 8 idle."""
+    from lcrnet_amd.retrieval import search_range
+    for n in (102, 103, 150, 701, 4541, 23201):
+        for w in (1, 2, 3, 4, 8):
+            r = [search_range(n, w, k, 101, 100) for k in range(w)]
+            assert r[0][0] == 101 and r[-1][1] == n - 1, (n, w, r)
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:])) and all(a <= b for a, b in r)
+            work = [sum(max(i - 100, 1) for i in range(a, b)) for a, b in r]
+            tot = sum(work)
+            if n >= 4541:
+                assert max(work) <= tot / w * 1.02 + n, (n, w, work)
+    old = [(max(k * 2901, 101), min((k + 1) * 2901, 23200)) for k in range(8)]          # frame ranges of 23 201 frames on 8 ranks
+    old_work = [sum(i - 100 for i in range(a, b)) for a, b in old]
+    assert max(old_work) / (sum(old_work) / 8) > 1.8                                       # what the balanced cut removes

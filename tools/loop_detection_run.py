@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--revisit-every", type=int, default=1500)
     ap.add_argument("--host-rows", action="store_true", help="feed the scans as host [N,4] velodyne rows through the ingest leg (upload inside the timed region)")
     ap.add_argument("--out", default=None, help="directory for the npz files (default: a temporary one, removed afterwards)")
+    ap.add_argument("--dump", default=None, help="rank 0 writes the gathered descriptors and the rows to this .npz (strong-scaling identity check of tools/scale_run.sh; small corpora only)")
     return ap.parse_args()
 
 
@@ -90,7 +91,7 @@ def main():
     from lcrnet_amd import io_formats as io
     from lcrnet_amd.model_family import create_model
     from lcrnet_amd.pipeline import DescriptorPipeline
-    from lcrnet_amd.retrieval import all_gather_descriptors, retrieval_topk, shard_range
+    from lcrnet_amd.retrieval import all_gather_descriptors, retrieval_topk, search_range, shard_range
     from lcrnet_amd.weights import seeded_state_dict
 
     C = args.frames
@@ -138,7 +139,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     full = all_gather_descriptors(desc, C) if world > 1 else desc
-    q_lo, q_hi = max(lo, 101), min(hi, C - 1)
+    q_lo, q_hi = search_range(C, world, rank, 101, 100)      # contiguous, equal causal work per rank
     idx, d2 = retrieval_topk(full[q_lo:q_hi], q_lo, full, 50, 100) if q_hi > q_lo else (torch.empty((0, 50), dtype=torch.int32, device=dev),
                                                                                          torch.empty((0, 50), device=dev))
     torch.cuda.synchronize()
@@ -148,10 +149,20 @@ def main():
         blocks = [None] * world
         dist.gather_object(rows, blocks if rank == 0 else None, dst=0)
         rows = np.concatenate(blocks) if rank == 0 else rows
+        per = [None] * world
+        dist.all_gather_object(per, (round(t_ret * 1e3, 2), int(q_hi - q_lo)))
+        t_ret_all, q_rows_all = [p[0] for p in per], [p[1] for p in per]
         t = torch.tensor([t_desc, t_ret], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_desc, t_ret = float(t[0]), float(t[1])
+    else:
+        t_ret_all, q_rows_all = [round(t_ret * 1e3, 2)], [int(q_hi - q_lo)]
     if rank == 0:
+        import hashlib
+        full_host = full.cpu().numpy()
+        desc_sha1, rows_sha1 = hashlib.sha1(full_host.tobytes()).hexdigest(), hashlib.sha1(np.ascontiguousarray(rows).tobytes()).hexdigest()
+        if args.dump:
+            np.savez(args.dump, desc=full_host, rows=rows)
         io.save_pair_dist(out_dir, rows)
         back = np.load(os.path.join(out_dir, "predicted_des_L2_dis.npz"))["arr_0"]
         assert back.shape == ((C - 102) * 50, 1, 3)
@@ -170,7 +181,9 @@ def main():
         f1, _ = ev.compute_F1(P, R)
         print(json.dumps({"metric": "loop detection over a sequence, end to end", "frames": C, "n_gpus": world,
                           "descriptor_scans_per_s": round(C / t_desc, 1), "descriptor_s": round(t_desc, 3), "inputs": "host [N,4] rows through the ingest leg" if args.host_rows else "resident in HBM",
-                          "retrieval_ms_slowest_rank": round(t_ret * 1e3, 2), "npz_write_s_rank0": round(t_write, 2),
+                          "retrieval_ms_slowest_rank": round(t_ret * 1e3, 2), "retrieval_ms_per_rank": t_ret_all, "query_rows_per_rank": q_rows_all,
+                          "wall_s_descriptors_plus_retrieval": round(t_desc + t_ret, 3), "gathered_descriptors_sha1": desc_sha1, "rows_sha1": rows_sha1,
+                          "npz_write_s_rank0": round(t_write, 2),
                           "rows": int(pair.shape[0]), "ground_truth": gt_name, "recall_at_1": round(float(top1), 4),
                           "recall_at_45": round(float(top45), 4), "f1_max": round(float(f1), 4), "ap": round(float(ev.compute_AP(P, R)), 4),
                           "auc": round(ev.auc(P, R), 3), "files": "%d x {seq}_{idx}.npz + predicted_des_L2_dis.npz in %s" % (hi - lo, "a temporary directory" if not args.out else out_dir),

@@ -42,7 +42,13 @@ for n in 1 2 4 8; do [ "$n" -le "$MAXG" ] && NS="$NS $n"; done
 for n in $NS; do
   run bench_$n python bench.py --gpus "$n" --steps "$STEPS" --warmup 3 --repeats "$REPEATS" --no-cpu-baseline
 done
-run loop_$MAXG python tools/loop_detection_run.py --frames "$FRAMES" --gpus "$MAXG"
+# BASELINE configs[3] as a STRONG-scaling run: the same fixed corpus at every N (wall time of descriptors + exchange + retrieval, per-rank
+# retrieval time with the work-balanced query split of lcrnet_amd.retrieval.search_range); the gathered descriptors and the top-k rows must
+# be the bytes N = 1 produced (sha1 in every line; the dry run also dumps the arrays and compares them value by value)
+for n in $NS; do
+  DUMP=""; [ "$DRY" = "1" ] && DUMP="--dump $LOGD/loop_$n.npz"
+  run loop_$n python tools/loop_detection_run.py --frames "$FRAMES" --gpus "$n" $DUMP
+done
 run pairs_$MAXG python tools/pair_bench.py --gpus "$MAXG" --pairs "$PAIRS" --pairs-per-call 8 --repeats 3
 python - "$OUT" "$LOGD" "$MAXG" "$DRY" $NS <<'PY'
 import json, os, re, sys
@@ -81,8 +87,30 @@ for n in ns:
     rec["curve"].append(e)
 lj, pj = last_json("loop_%d" % maxg), last_json("pairs_%d" % maxg)
 rec["loop_detection"] = {"rc": rc("loop_%d" % maxg), "line": lj, "rccl": None if dry or maxg == 1 else rccl_ranks("loop_%d" % maxg, maxg)}
+strong, l1 = [], last_json("loop_1")
+for n in ns:
+    j = last_json("loop_%d" % n)
+    e = {"n_gpus": n, "rc": rc("loop_%d" % n), "frames": j and j.get("frames"), "wall_s": j and j.get("wall_s_descriptors_plus_retrieval"),
+         "descriptor_s": j and j.get("descriptor_s"), "retrieval_ms_per_rank": j and j.get("retrieval_ms_per_rank"),
+         "query_rows_per_rank": j and j.get("query_rows_per_rank"),
+         "descriptors_identical_to_1gpu": bool(j and l1 and j.get("gathered_descriptors_sha1") == l1.get("gathered_descriptors_sha1")),
+         "rows_identical_to_1gpu": bool(j and l1 and j.get("rows_sha1") == l1.get("rows_sha1"))}
+    if l1 and j and l1.get("wall_s_descriptors_plus_retrieval"):
+        e["speedup_over_1gpu"] = round(l1["wall_s_descriptors_plus_retrieval"] / j["wall_s_descriptors_plus_retrieval"], 3)
+    if dry and n > 1:
+        try:
+            import numpy as np
+            a, b = np.load(os.path.join(logd, "loop_1.npz")), np.load(os.path.join(logd, "loop_%d.npz" % n))
+            e["dump_descriptors_max_abs_diff"] = float(np.abs(a["desc"] - b["desc"]).max())
+            e["dump_rows_equal"] = bool(a["rows"].shape == b["rows"].shape and np.array_equal(a["rows"][..., :2], b["rows"][..., :2]))
+        except Exception as ex:
+            e["dump_error"] = str(ex)
+    strong.append(e)
+rec["strong_scaling_configs3"] = strong
 rec["pairs"] = {"rc": rc("pairs_%d" % maxg), "line": pj, "rccl": None if dry or maxg == 1 else rccl_ranks("pairs_%d" % maxg, maxg)}
-rec["checks"]["all_rc_zero"] = all(e["rc"] == 0 for e in rec["curve"]) and rec["loop_detection"]["rc"] == 0 and rec["pairs"]["rc"] == 0
+rec["checks"]["all_rc_zero"] = all(e["rc"] == 0 for e in rec["curve"]) and all(e["rc"] == 0 for e in strong) and rec["pairs"]["rc"] == 0
+rec["checks"]["strong_scaling_rows_identical_to_1gpu"] = all(e["rows_identical_to_1gpu"] for e in strong)
+rec["checks"]["strong_scaling_descriptors_identical_to_1gpu"] = all(e["descriptors_identical_to_1gpu"] for e in strong)
 rec["checks"]["rccl_saw_all_ranks"] = None if dry else all((e.get("rccl") or {"ok": True})["ok"] for e in rec["curve"])
 json.dump(rec, open(out, "w"), indent=1)
 print(json.dumps({"scale_run": out, "curve": [(e["n_gpus"], e["value"]) for e in rec["curve"]], "checks": rec["checks"]}))
