@@ -628,7 +628,13 @@ def main():
                              "instruction_floor": {"valu_cycles_per_query_per_cu": RS_VALU_PER_QUERY, "queries_per_step": int(n_queries),
                                                    "ms_per_step": round(n_queries * RS_VALU_PER_QUERY / 256 / 2.4e9 * 1e3, 4),
                                                    "alone_over_floor": round(iso_rs / (n_queries * RS_VALU_PER_QUERY / 256 / 2.4e9), 3),
-                                                   "source": RS_VALU_SOURCE}},
+                                                   "source": RS_VALU_SOURCE},
+                             # the bound the stage is actually on (kill-criterion branch): achieved / VALU-issue roofline =
+                             # time the kernel's own VALU wavefront-instructions need at one issue per SIMD per 4 cycles / its time alone
+                             "issue_bound": {"bound": "valu-issue", "frac": round((n_queries * RS_VALU_PER_QUERY / 256 / 2.4e9) / iso_rs, 4),
+                                             "roofline_ms_per_step": round(n_queries * RS_VALU_PER_QUERY / 256 / 2.4e9 * 1e3, 4),
+                                             "note": "lane-per-query form built and measured in round 5 (16-query tiles, LDS lists, per-query counting sort): "
+                                                     "rows bit-identical, 344 vs 112 us on neighbors[0] -> removed (profiles/r05_lpq_radius_bench.md)"}},
                 "aggregation": {"kernel": "lcr::k_kpconv_aggregate (fp32 MFMA 16x16x4, %d launches/step)" % round(iso["n_agg"] / iso["passes"]), "bound": "mfma",
                                 "achieved": round(agg_alone, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(agg_alone / FP32_PEAK_TFLOPS, 4), "gflop_per_step": round(flops_agg_step / 1e9, 2),

@@ -12,8 +12,7 @@
  *       lengths of the batch on the host) and owns a small per-process pool of side streams, events and
  *       pinned staging words, created on first use and kept until process exit;
  *       lcr_ktimer_read synchronises on the events it logged (measurement harness only);
- *       the opt-in stream-K GEMM and the lane-per-query radius search keep one library-owned device scratch
- *       buffer per device, allocated on first use;
+ *       the opt-in stream-K GEMM keeps one library-owned device scratch buffer per (device, stream), allocated on first use;
  *   - all other scratch memory comes from the caller: ask `*_ws_bytes`, pass `ws`/`ws_bytes`;
  *   - stacked ("stack mode") clouds: points f32[N,3] row-major, lengths i64[B] (reference layout,
  *     utils/extensions/cpu/grid_subsampling/grid_subsampling.cpp:20-30);
@@ -125,9 +124,6 @@ typedef struct LcrRadiusQuery {
 } LcrRadiusQuery;
 #define LCR_RADIUS_QUERY_MULTI_MAX 12   /* searches per lcr_radius_query_multi launch; longer lists: call it on slices */
 int lcr_radius_query_multi(const LcrRadiusQuery* list, int n, int B, void* stream);
-/* Sizing counters of the lane-per-query search kernel (environment LCR_RS_LPQ=2 only; measurement harness): out_host[0..4] = tiles,
- * passes over tiles, staged candidates, queries served, queries redone by the wave form.  Synchronous; reset != 0 clears them. */
-int lcr_radius_lpq_stats(unsigned long long* out_host, int reset);
 /* Same build that also writes the cell-sorted processing order (what lcr_support_grid_order returns) into order i32[ns_cap]. */
 int lcr_support_grid_build_ex(const float* s, const int64_t* slen, int B, int64_t ns_cap, float radius,
                               uint32_t* status, void* grid_ws, size_t grid_ws_bytes, int32_t* order, void* stream);

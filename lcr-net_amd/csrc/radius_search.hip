@@ -306,7 +306,7 @@ __device__ __forceinline__ int rq_cloud_of(const int32_t* off, int B, int i) {
 
 // One wavefront turn: `nj` (1..4) CONSECUTIVE queries of the processing order starting at position t_blk, set up at once (query j in DPP
 // row j) and then ranked one after the other.  b / off_b / off_b1: the lane's cached cloud lookup, carried from turn to turn.
-// Wave-private LDS as for rq_search.  Also the exact fallback of the lane-per-query kernel below (nj = 1).
+// Wave-private LDS as for rq_search.
 template <bool HAS64, bool HAS32>
 __device__ __forceinline__ void rq_turn(const RqSearch& A, int B, const int32_t* s_qoff, uint64_t* keys, uint16_t* perm, int* cnt, int* fill, int* base,
                                         int64_t t_blk, int nj, int64_t ns_total, float bin_scale, int& b, int& off_b, int& off_b1) {
@@ -529,320 +529,6 @@ __device__ __forceinline__ void rq_search(const RqSearch& A, int B, const int32_
   }
 }
 
-// ---- lane-per-query form (round 5) ---------------------------------------------------------------------------
-// The wave-per-query form above pays its per-query scaffolding (set-up, run table, compaction, the rank's scans) at wavefront
-// granularity: ~354 VALU + ~180 SALU wavefront instructions per query for ~98 distance tests and ~51 sorted indices.  Here a wavefront
-// takes a TILE of 16 consecutive queries of the processing order and every lane owns (query t = lane & 15, candidate stream g = lane >> 4):
-//   1. set-up once per tile: the nine cell rows of every query (three per lane) go into a direct-mapped 7 x 7 table of (y, z) rows around
-//      the tile's first query — LDS atomicMin / atomicMax of the x range — so the UNION of the 16 neighbourhoods comes out as at most 49
-//      disjoint runs of the cell-sorted support array (no duplicates: a run is one row's x interval).  Queries of another cloud or outside
-//      the table's window wait for the next pass over the same tile (cloud boundaries, row wrap-arounds: rare in cell order);
-//   2. the runs' supports are staged into LDS (flat copy, owner run by binary search over the run prefix);
-//   3. candidate phase: step s tests candidate 4s + g against query t in every lane — one LDS read, the same un-fused fp32 distance,
-//      one compare, and a per-lane append of (d² bits, index) to lists[slot][lane]: ~14 VALU per step of 64 tests, no ballot, no run select;
-//   4. sort, per query by its four lanes: keys to registers, 128-bin counting sort (LDS histogram [bin][query]; prefix by the query's
-//      lanes, 32 bins each; scatter into sorted[query][pos]), then wave-per-query: lane = position, rank inside its own bin by comparing
-//      with the bin mates (all LDS-resident), row written coalesced with the padding.
-// Same keys, same arithmetic, same (d², index) order as the wave form: rows are bit-identical.  Queries that do not fit the fixed LDS
-// capacities (a lane with more than LQ_CAPL hits, a ball with more than LQ_CAPQ) are redone exactly by rq_turn (the wave form's turn).
-constexpr int LQ_T = 16;          // queries per tile
-constexpr int LQ_CAPL = 32;       // stored hits per lane (a query has four lanes)
-constexpr int LQ_CAPQ = 112;      // sorted keys per query
-constexpr int LQ_NB = 128;        // bins of d²
-constexpr int LQ_CMAX = 256;      // staged candidates per chunk
-
-struct LqSetup {
-  int    tx0[64], tx1[64];        // x range of table row (z, y) -> slot
-  int    run_start[64];
-  int    run_pre[68];             // exclusive prefix of the run lengths (+ sentinel)
-  float4 cand[LQ_CMAX + 4];
-};
-union LqR1 {
-  LqSetup  s;
-  uint32_t hist[LQ_NB * LQ_T];    // [bin][query]: count, then (start << 16 | cursor)
-};
-struct LqOld {                    // the wave form's buffers (exact fallback)
-  uint64_t keys[RQ_CAP];
-  uint16_t perm[RQ_CAP];
-  int      cnt[RQ_BINS], fill[RQ_BINS], base[RQ_BINS + 1];
-};
-union LqR2 {
-  uint64_t lists[LQ_CAPL * 64];   // [slot][lane]
-  uint64_t sorted[LQ_T * LQ_CAPQ];
-  LqOld    old;
-};
-
-__device__ __forceinline__ void wsync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-__device__ __forceinline__ int wave_max_nonneg(int v) {
-  v = max(v, dpp0<DPP_QUAD_1032>(v));
-  v = max(v, dpp0<DPP_QUAD_2301>(v));
-  v = max(v, dpp0<DPP_ROW_HALF_MIRROR>(v));
-  v = max(v, dpp0<DPP_ROW_MIRROR>(v));
-  return max(max(rdlane(v, 0), rdlane(v, 16)), max(rdlane(v, 32), rdlane(v, 48)));
-}
-__device__ __forceinline__ int lq_bin(uint64_t key, float scale) {
-  const float d2 = __uint_as_float(static_cast<uint32_t>(key >> 32));
-  const int b = static_cast<int>(fmul(d2, scale));          // monotone non-decreasing in d2
-  return b < LQ_NB - 1 ? b : LQ_NB - 1;
-}
-
-// debug / sizing counters (lcr_radius_lpq_stats): tiles, passes over tiles, staged candidates, queries, fallback queries
-__device__ unsigned long long g_lq_stats[8];
-
-template <bool HAS64, bool HAS32, bool STATS>
-__device__ __forceinline__ void lq_search(const RqSearch& A, int B, const int32_t* s_qoff, LqR1& R1, LqR2& R2) {
-  const float* __restrict__ q = A.q;
-  const GridHeader* __restrict__ h = A.h;
-  const int32_t* __restrict__ cell_start = A.cell_start;
-  const float4* __restrict__ sorted = A.sorted;
-  const int32_t* __restrict__ q_order = A.q_order;
-  int64_t* __restrict__ out64 = A.out64;
-  int32_t* __restrict__ out32 = A.out32;
-  int32_t* __restrict__ out_cnt = A.out_cnt;
-  const float r2 = A.r2;
-  const int limit = A.limit;
-  const int lane = threadIdx.x & 63, t = lane & 15, g = lane >> 4;
-  const int64_t nq = min(static_cast<int64_t>(s_qoff[B]), A.nq_cap);
-  const int64_t ns_total = h->ns_total;
-  const float bscale = fdiv(static_cast<float>(LQ_NB), r2);
-  const float bscale_old = fdiv(static_cast<float>(RQ_BINS), r2);
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-  const int64_t per_xcd = (nq + 7) / 8;
-  const int64_t x_lo = xcd * per_xcd, x_hi = min(nq, (xcd + 1) * per_xcd);
-  int b = 0, off_b = 0, off_b1 = 0;              // cloud of this lane's previous query, its [first, last) rows
-  int fb = 0, foff = 0, foff1 = 0;               // the same cache for the fallback's own lookups
-  for (int64_t tb = x_lo + static_cast<int64_t>(slot) * LQ_T; tb < x_hi; tb += static_cast<int64_t>(nslots) * LQ_T) {
-    const int nt = static_cast<int>(min(static_cast<int64_t>(LQ_T), x_hi - tb));
-    const bool qvalid = t < nt;
-    const int64_t tq = tb + (qvalid ? t : 0);
-    const int64_t qi64 = q_order ? static_cast<int64_t>(q_order[tq]) : tq;
-    const int qi = static_cast<int>(qi64);
-    if (qi < off_b || qi >= off_b1) {
-      b = rq_cloud_of(s_qoff, B, qi);
-      off_b = s_qoff[b];
-      off_b1 = s_qoff[b + 1];
-    }
-    const float mx = q[3 * qi64 + 0], my = q[3 * qi64 + 1], mz = q[3 * qi64 + 2];
-    int cx, cy, cz;
-    {
-      const GridCloud& c = h->cloud[b];
-      const double inv = c.inv_cell;
-      const double fx = floor((static_cast<double>(mx) - c.org[0]) * inv), fy = floor((static_cast<double>(my) - c.org[1]) * inv),
-                   fz = floor((static_cast<double>(mz) - c.org[2]) * inv);
-      cx = static_cast<int>(fmin(fmax(fx, -2.0), static_cast<double>(c.dim[0]) + 1.0));      // == cell_coord()
-      cy = static_cast<int>(fmin(fmax(fy, -2.0), static_cast<double>(c.dim[1]) + 1.0));
-      cz = static_cast<int>(fmin(fmax(fz, -2.0), static_cast<double>(c.dim[2]) + 1.0));
-    }
-    if (STATS && lane == 0) atomicAdd(&g_lq_stats[0], 1ull);
-    bool pending = qvalid;
-    for (;;) {
-      const uint64_t pm = wave_ballot(pending);
-      if (pm == 0) break;
-      // ---- this pass's queries: those of the first pending query's cloud whose cell row lies in the 7 x 7 table around it
-      const int l0 = __builtin_ctzll(pm);
-      const int b0 = rdlane(b, l0), cy0 = rdlane(cy, l0), cz0 = rdlane(cz, l0);
-      const bool act = pending && b == b0 && static_cast<unsigned>(cy - cy0 + 1) <= 4u && static_cast<unsigned>(cz - cz0 + 1) <= 4u;
-      pending = pending && !act;
-      const GridCloud& c0 = h->cloud[b0];
-      const int dimx = c0.dim[0], dimy = c0.dim[1], dimz = c0.dim[2], cbase = c0.cell_base;
-      R1.s.tx0[lane] = 0x7fffffff;
-      R1.s.tx1[lane] = static_cast<int>(0x80000000u);
-      wsync();
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int k = g + 4 * i;                                   // row k of the query's nine (three per lane)
-        const int ry = cy + (k % 3) - 1, rz = cz + (k / 3) - 1;
-        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, dimx - 1);
-        if (act && k < 9 && ry >= 0 && ry < dimy && rz >= 0 && rz < dimz && x0 <= x1) {
-          const int sl = (rz - cz0 + 2) * 7 + (ry - cy0 + 2);
-          atomicMin(&R1.s.tx0[sl], x0);
-          atomicMax(&R1.s.tx1[sl], x1);
-        }
-      }
-      wsync();
-      int a0 = 0, len = 0;
-      if (lane < 49) {
-        const int x0 = R1.s.tx0[lane], x1 = R1.s.tx1[lane];
-        if (x0 <= x1) {
-          const int ry = lane % 7 + cy0 - 2, rz = lane / 7 + cz0 - 2;
-          const int crow = cbase + (rz * dimy + ry) * dimx;
-          a0 = cell_start[crow + x0];
-          len = cell_start[crow + x1 + 1] - a0;
-        }
-      }
-      const int inc = wave_incl_scan(len);
-      const int U = rdlane(inc, 63);
-      const uint64_t hm = wave_ballot(len > 0);
-      const int nruns = __popcll(hm);
-      if (len > 0) {
-        const int p = mbcnt_lt(hm);
-        R1.s.run_start[p] = a0;
-        R1.s.run_pre[p] = inc - len;
-      }
-      if (lane == 0) R1.s.run_pre[nruns] = U;
-      wsync();
-      if (STATS) {
-        const unsigned long long nact = static_cast<unsigned long long>(__popcll(wave_ballot(act)) / 4);
-        if (lane == 0) {
-          atomicAdd(&g_lq_stats[1], 1ull);
-          atomicAdd(&g_lq_stats[2], static_cast<unsigned long long>(U));
-          atomicAdd(&g_lq_stats[3], nact);
-        }
-      }
-
-      // ---- candidate phase
-      int n = 0;                                                   // in-radius supports this lane has seen (stored while n < LQ_CAPL)
-      for (int cb0 = 0; cb0 < U; cb0 += LQ_CMAX) {
-        const int cnt = min(LQ_CMAX, U - cb0);
-        if (cb0 > 0) wsync();
-        for (int j = lane; j < cnt; j += 64) {
-          const int cg = cb0 + j;
-          int lo = 0;
-#pragma unroll
-          for (int st = 32; st >= 1; st >>= 1) {
-            const int m = lo + st;
-            if (m < nruns && R1.s.run_pre[m] <= cg) lo = m;
-          }
-          R1.s.cand[j] = sorted[R1.s.run_start[lo] + (cg - R1.s.run_pre[lo])];
-        }
-        wsync();
-#pragma unroll 2
-        for (int s0 = 0; s0 < cnt; s0 += 4) {
-          const int cc = s0 + g;
-          const float4 P = R1.s.cand[cc];                          // beyond cnt: stale LDS, masked by `live`
-          const float dx = fsub(mx, P.x), dy = fsub(my, P.y), dz = fsub(mz, P.z);
-          const float d2 = fadd(fadd(fmul(dx, dx), fmul(dy, dy)), fmul(dz, dz));
-          if (cc < cnt && act && d2 < r2) {
-            if (n < LQ_CAPL) R2.lists[n * 64 + lane] = (static_cast<uint64_t>(__float_as_uint(d2)) << 32) | __float_as_uint(P.w);
-            ++n;
-          }
-        }
-      }
-      wsync();
-
-      // ---- per-query totals (the four lanes of a query sit 16 lanes apart)
-      int v = n | (n > LQ_CAPL ? (1 << 24) : 0);
-      v += __shfl_xor(v, 16);
-      v += __shfl_xor(v, 32);
-      const int tot = v & 0xffffff;
-      const bool fits = (v >> 24) == 0 && tot <= LQ_CAPQ;
-      if (out_cnt && act && g == 0) out_cnt[qi64] = tot;
-      if (limit <= 0) continue;                                    // count-only mode
-      const bool part = act && fits;
-      const uint64_t part_m = wave_ballot(part) & 0xffffull;       // bit t: query t takes the fast path
-      const uint64_t slow_m = wave_ballot(act && !fits) & 0xffffull;
-
-      if (part_m) {
-        // ---- keys to registers, histogram
-        uint64_t k[LQ_CAPL];
-#pragma unroll
-        for (int i = 0; i < LQ_CAPL; ++i) k[i] = R2.lists[i * 64 + lane];
-        const int ns = part ? n : 0;
-        {
-          uint4* h4 = reinterpret_cast<uint4*>(R1.hist);
-#pragma unroll
-          for (int i = 0; i < (LQ_NB * LQ_T * 4) / (64 * 16); ++i) h4[i * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
-        }
-        wsync();
-        const int nmax = wave_max_nonneg(ns);
-#pragma unroll
-        for (int i = 0; i < LQ_CAPL; ++i) {
-          if (i < nmax) {                                          // wave-uniform
-            if (i < ns) atomicAdd(&R1.hist[lq_bin(k[i], bscale) * LQ_T + t], 1u);
-          }
-        }
-        wsync();
-        // ---- prefix: the query's lane g owns bins [32 g, 32 g + 32)
-        uint32_t cbin[32];
-        int sum = 0;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-          cbin[i] = R1.hist[(32 * g + i) * LQ_T + t];
-          sum += static_cast<int>(cbin[i]);
-        }
-        int run = 0;
-        {
-          const int s1 = __shfl_up(sum, 16), s2 = __shfl_up(sum, 32), s3 = __shfl_up(sum, 48);
-          run = (g >= 1 ? s1 : 0) + (g >= 2 ? s2 : 0) + (g >= 3 ? s3 : 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-          R1.hist[(32 * g + i) * LQ_T + t] = (static_cast<uint32_t>(run) << 16) | static_cast<uint32_t>(run);
-          run += static_cast<int>(cbin[i]);
-        }
-        wsync();
-        // ---- scatter into bin order
-#pragma unroll
-        for (int i = 0; i < LQ_CAPL; ++i) {
-          if (i < nmax) {                                          // wave-uniform
-            if (i < ns) {
-              const uint32_t old = atomicAdd(&R1.hist[lq_bin(k[i], bscale) * LQ_T + t], 1u);
-              R2.sorted[t * LQ_CAPQ + (old & 0xffffu)] = k[i];
-            }
-          }
-        }
-        wsync();
-        // ---- rank inside the bin + row, one query at a time (lane = position in bin order)
-        uint64_t pmq = part_m;
-        while (pmq) {
-          const int tt = __builtin_ctzll(pmq);
-          pmq &= pmq - 1;
-          const int nqt = rdlane(tot, tt);
-          const int64_t qit = static_cast<int64_t>(rdlane(qi, tt));
-          int64_t* row64 = HAS64 ? out64 + qit * static_cast<int64_t>(limit) : nullptr;
-          int32_t* row32 = HAS32 ? out32 + qit * static_cast<int64_t>(limit) : nullptr;
-          const uint64_t* srt = R2.sorted + tt * LQ_CAPQ;
-          for (int r = lane; r < nqt; r += 64) {
-            const uint64_t key = srt[r];
-            const uint32_t wd = R1.hist[lq_bin(key, bscale) * LQ_T + tt];
-            const int lo = static_cast<int>(wd >> 16), hi = static_cast<int>(wd & 0xffffu);
-            if (lo < limit) {
-              int rank = lo;
-              for (int j = lo; j < hi; ++j) rank += srt[j] < key;
-              if (rank < limit) {
-                const int64_t vv = static_cast<int64_t>(static_cast<uint32_t>(key));
-                if (HAS64) row64[rank] = vv;
-                if (HAS32) row32[rank] = static_cast<int32_t>(vv);
-              }
-            }
-          }
-          for (int col = nqt + lane; col < limit; col += 64) {
-            if (HAS64) row64[col] = ns_total;
-            if (HAS32) row32[col] = static_cast<int32_t>(ns_total);
-          }
-        }
-        wsync();
-      }
-      // ---- queries beyond the fixed capacities: the wave form, exactly
-      uint64_t sm = slow_m;
-      while (sm) {
-        const int tt = __builtin_ctzll(sm);
-        sm &= sm - 1;
-        R2.old.cnt[lane] = 0;
-        wsync();
-        if (STATS && lane == 0) atomicAdd(&g_lq_stats[4], 1ull);
-        rq_turn<HAS64, HAS32>(A, B, s_qoff, R2.old.keys, R2.old.perm, R2.old.cnt, R2.old.fill, R2.old.base, tb + tt, 1, ns_total, bscale_old, fb,
-                              foff, foff1);
-        wsync();
-      }
-    }
-  }
-}
-
-template <bool HAS64, bool HAS32, bool STATS>
-__global__ __launch_bounds__(64) void k_radius_query_lpq(RqSearch A, int B) {
-  __shared__ __attribute__((aligned(16))) LqR1 s_r1;
-  __shared__ __attribute__((aligned(16))) LqR2 s_r2;
-  __shared__ int32_t s_qoff[GRID_MAX_B + 1];
-  rq_offsets(A.qlen, B, s_qoff);
-  wsync();
-  lq_search<HAS64, HAS32, STATS>(A, B, s_qoff, s_r1, s_r2);
-}
-
 template <bool HAS64, bool HAS32>
 __global__ __launch_bounds__(RS_WAVES * 64) void k_radius_query(RqSearch A, int B) {
   __shared__ __attribute__((aligned(16))) uint64_t s_keys[RS_WAVES][RQ_CAP];
@@ -957,23 +643,6 @@ static int rq_n_cu() {
   }();
   return v;
 }
-// lane-per-query form: LCR_RS_LPQ = 0 off, 1 on, 2 on with the sizing counters of lcr_radius_lpq_stats
-static int rq_lpq_mode() {
-  static const int v = getenv("LCR_RS_LPQ") ? atoi(getenv("LCR_RS_LPQ")) : 0;
-  return v;
-}
-static int rq_lpq_wg_per_cu() {                  // one-wavefront workgroups, LDS-bound (~24.5 KB each)
-  static const int v = getenv("LCR_RS_LPQ_WG") ? atoi(getenv("LCR_RS_LPQ_WG")) : 6;
-  return v;
-}
-extern "C" int lcr_radius_lpq_stats(unsigned long long* out_host, int reset) {
-  if (out_host && hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_lq_stats), sizeof(unsigned long long) * 8) != hipSuccess) return LCR_EHIP;
-  if (reset) {
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_lq_stats), z, sizeof(z)) != hipSuccess) return LCR_EHIP;
-  }
-  return LCR_OK;
-}
 // queries per wavefront turn: four (one per DPP row) when the search is large enough to fill the chip anyway, fewer for the small
 // coarse-stage searches, which are latency-bound and want as many wavefronts as they have queries
 static int rq_qb(int64_t nq_cap) {
@@ -1011,22 +680,6 @@ extern "C" int lcr_radius_query_ordered(const float* q, const int64_t* qlen, int
   A.limit = limit, A.out64 = out_idx64, A.out32 = out_idx32, A.out_cnt = out_cnt, A.q_order = q_order, A.qb = rq_qb(nq_cap);
   const dim3 block(RS_WAVES * 64);
   KernelTimerScope timed(KT_RADIUS, st, nq_cap, ns_cap, limit, out_idx64 ? 8 : 4, B);
-  static const bool lpq_any = getenv("LCR_RS_LPQ_ANY") != nullptr;       // tests: also for queries in their stored order
-  if (rq_lpq_mode() && (q_order || lpq_any)) {   // lane-per-query form: tiles of 16 consecutive queries of a spatially coherent order
-    const int cap = rq_n_cu() * rq_lpq_wg_per_cu();
-    const int nblk = (min(div_up(nq_cap, LQ_T), cap) + 7) / 8 * 8;
-    const dim3 g1(nblk), b1(64);
-    if (rq_lpq_mode() == 2) {
-      if (out_idx64 && out_idx32) LCR_LAUNCH_TIMED((k_radius_query_lpq<true, true, true>), g1, b1, 0, st, A, B);
-      else if (out_idx64) LCR_LAUNCH_TIMED((k_radius_query_lpq<true, false, true>), g1, b1, 0, st, A, B);
-      else LCR_LAUNCH_TIMED((k_radius_query_lpq<false, true, true>), g1, b1, 0, st, A, B);
-    } else {
-      if (out_idx64 && out_idx32) LCR_LAUNCH_TIMED((k_radius_query_lpq<true, true, false>), g1, b1, 0, st, A, B);
-      else if (out_idx64) LCR_LAUNCH_TIMED((k_radius_query_lpq<true, false, false>), g1, b1, 0, st, A, B);
-      else LCR_LAUNCH_TIMED((k_radius_query_lpq<false, true, false>), g1, b1, 0, st, A, B);
-    }
-    return check_launch("lcr_radius_query (lane-per-query)");
-  }
   const int nblk = (min(div_up(nq_cap, RS_WAVES * A.qb), getenv("LCR_RS_NBLK") ? atoi(getenv("LCR_RS_NBLK")) : rq_n_cu() * rq_wg_per_cu()) + 7) / 8 * 8;
   const dim3 grid(nblk);
   if (out_idx64 && out_idx32) LCR_LAUNCH_TIMED((k_radius_query<true, true>), grid, block, 0, st, A, B);

@@ -109,8 +109,8 @@ def test_split_gemm_worst_cases():
     K-deep contractions since round 5, so its domain is stated and pinned here):
       1. dynamic range 2^40 inside every row of A (and 2^20 inside B): the error against fp64 is bounded RELATIVE TO sum |a.b| (the only
          bound any fp32 accumulation has) by 2e-6 and is not above the fp32 kernel's by more than rounding noise;
-      2. subnormal operands: an fp32 subnormal is still the exact sum of its three bf16 terms; products far below the fp32 range vanish in
-         both forms, and subnormal noise under normal data changes nothing beyond 1e-37 absolute;
+      2. subnormal operands: the split flushes them (reconstruction error below 2^-126 per element, measured); products far below the fp32
+         range vanish in both forms, and subnormal entries under normal data change nothing beyond 1e-35 absolute;
       3. +Inf / -Inf / NaN in A: the SAME output rows are non-finite in both forms (an infinite term splits into (Inf, NaN, NaN): the row is
          NaN where the fp32 kernel has +-Inf or NaN — non-finite either way), all other rows are bit-identical to the run without them;
       4. the largest magnitudes of the domain, |x| = 3.3895e38 (the largest bf16; above it the first term would round to infinity):
@@ -133,7 +133,9 @@ def test_split_gemm_worst_cases():
     from lcrnet_amd import functional as F
     w = torch.randn(N, K, device=dev, generator=g) * 1e-40
     t = F.unsplit_bf16x3(F.split_bf16x3(w))
-    assert torch.equal((t[0] + t[1]) + t[2], w)                       # exact also below the normal range
+    # below the normal range the terms are NOT exact: the conversions flush subnormal results (h1 of a subnormal x may come out 0 or
+    # truncated) — the reconstruction error stays below the smallest normal number per element, i.e. it vanishes in any product
+    assert ((t[0] + t[1]) + t[2] - w).abs().max().item() < 1.2e-38
     bn = torch.randn(N, K, device=dev, generator=g)
     z0, z1 = _both(tiny, bn)
     assert z0.abs().max().item() < 1e-35 and z1.abs().max().item() < 1e-35

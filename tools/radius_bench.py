@@ -90,11 +90,6 @@ def main():
                 print("check %-24s rows equal: %s (%d of %d rows differ)" % (tag, same, nbad, want.shape[0]))
                 bad += nbad
         print("CHECK", "OK" if bad == 0 else "FAILED (%d rows)" % bad)
-        import ctypes
-        from lcrnet_amd import _lib
-        st = (ctypes.c_ulonglong * 8)()
-        if hasattr(_lib.lib(), "lcr_radius_lpq_stats") and _lib.lib().lcr_radius_lpq_stats(st, 1) == 0:
-            print("lpq stats: tiles %d passes %d staged candidates %d queries %d fallback queries %d" % tuple(st[:5]))
     if os.environ.get("LCR_RB_NO_CELL_ORDER"):
         return
     # the same searches with the QUERIES permuted into their own grid's cell order (spatially coherent wavefronts)
