@@ -623,7 +623,7 @@ def main():
                                              "ms_per_step": round(rs_launch * 1e3, 4),
                                              "ms_per_step_event_bracketed": round(t_rs / max(len(rsq), 1) * 1e3, 4)},
                              "north_star_target_frac": 0.6,
-                             # the search is bound by instruction issue, not by HBM: VALU wavefront-instructions per query
+                             # the search is bound by instruction issue, not by HBM (LABNOTES.md §4.4): VALU wavefront-instructions per query
                              # (rocprofv3 --pmc, profiles/) at 4 cycles each on a SIMD
                              "instruction_floor": {"valu_cycles_per_query_per_cu": RS_VALU_PER_QUERY, "queries_per_step": int(n_queries),
                                                    "ms_per_step": round(n_queries * RS_VALU_PER_QUERY / 256 / 2.4e9 * 1e3, 4),

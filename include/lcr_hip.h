@@ -221,6 +221,14 @@ int lcr_kpconv_aggregate(const float* s_feats, const uint8_t* s_pos, const float
                          const void* idx, int idx_is_64, int64_t M, int64_t Ns, int H, int C,
                          const float* kernel_points_host, float sigma, float* A, float* nn,
                          const int32_t* order /* optional i32[M]: processing order, e.g. lcr_support_grid_order */, void* stream);
+/* Same with flags.  LCR_KP_VALID_FIRST: the caller guarantees that every row of idx holds its valid entries first and the padding (any value
+ * outside [0, Ns)) behind them — what a radius search emits (radius_neighbors_cpu.cpp:70-88 pads behind the sorted hits); the kernel then
+ * stops reading a row at the first 64-column chunk that contains padding.  Results are identical for such rows. */
+#define LCR_KP_VALID_FIRST 1
+int lcr_kpconv_aggregate_ex(const float* s_feats, const uint8_t* s_pos, const float* q_pts, const float* s_pts,
+                            const void* idx, int idx_is_64, int64_t M, int64_t Ns, int H, int C,
+                            const float* kernel_points_host, float sigma, float* A, float* nn,
+                            const int32_t* order, int flags, void* stream);
 /* Whole KPConv (kpconv.py:79-122) for C_in = C_out = 32 — the two widest query sets of the encoder — in one launch: the
  * aggregate above lives only as 16-query tiles in LDS and is contracted there with W [15*32, 32] (split-K over the wavefronts,
  * weights in registers); out[M,32] = contraction / neighbour count + bias, plus the GroupNorm sums of `out` ADDED to
@@ -284,6 +292,8 @@ typedef struct LcrEncoderW {
   const float *c1_gn_w, *c1_gn_b;
   LcrBlockW blocks[LCR_ENC_BLOCKS];   /* encoder1_2, 2_1, 2_2, 2_3, 3_1, 3_2, 3_3, 4_1, 4_2, 4_3 */
 } LcrEncoderW;
+/* neighbors / subsampling: rows as a radius search emits them — valid entries first, padding (= number of support rows) behind them
+ * (LCR_KP_VALID_FIRST of lcr_kpconv_aggregate_ex; environment LCR_KP_VALID_FIRST=0 lifts the requirement). */
 int lcr_encoder_ws_bytes(const LcrEncoderW* W, const int64_t* n_host, int S, size_t* bytes);
 int lcr_encoder_forward(const LcrEncoderW* W, const float* feats0, const float* const* points, const int32_t* const* neighbors,
                         const int32_t* const* subsampling, const int32_t* const* order, const int64_t* const* seg_len, int S,

@@ -65,7 +65,7 @@ class KPEncoder(nn.Module):
         order = data_dict.get("order")
         # One native call (csrc/encoder.hip): the same launches in the same order issued by C++ — bit-identical outputs
         # (tests/test_encoder_gpu.py), ~30 % less host time per pass and no interpreter lock held while the pass is issued.  In the
-        # descriptor pipeline both drivers measure the same rate today (2 413 vs 2 421 scans/s; round 1's 10 % deficit
+        # descriptor pipeline both drivers measure the same rate today (2 413 vs 2 421 scans/s, LABNOTES.md §4.2; round 1's 10 % deficit
         # went away with the launch-turn gate and the prioritised pre-processing stream), so the native one is the default.
         if self.native and native_encoder.eligible(feats, data_dict):
             return native_encoder.forward(self, feats, data_dict)

@@ -101,13 +101,16 @@ static int residual_block(const LcrBlockW& b, const float* s_feats, const StageI
   float* kpo = ws.take<float>(static_cast<size_t>(M) * mid);
   double* stc = sp.take();
   if (!A || !nn || !kpo || !stc) return LCR_ESPACE;
-  static const bool fused32 = getenv("LCR_KPCONV_FUSED") != nullptr;       // opt-in, like KPConv.forward_raw
+  // the lists of a data dictionary come from radius searches (the reference's radius_neighbors and ours alike): valid entries first, padding
+  // (= Ns) behind them — the aggregation may stop at the first chunk with a hole (LCR_KP_VALID_FIRST=0: scan every chunk)
+  static const int vf_flag = (getenv("LCR_KP_VALID_FIRST") && atoi(getenv("LCR_KP_VALID_FIRST")) == 0) ? 0 : LCR_KP_VALID_FIRST;
+  static const bool fused32 = getenv("LCR_KPCONV_FUSED") != nullptr;       // opt-in, like KPConv.forward_raw (LABNOTES.md §4.2)
   if (fused32 && mid == 32 && sp.S <= 64) {
     if ((rc = TURN(lcr_kpconv_fused(x, pos, q.pts, sup.pts, idx, 0, M, Ns, H, mid, b.kernel_points_host, b.sigma, b.kp_w, b.kp_b, kpo, q.seg, sp.S, g,
                                     stc, q.order, s))))
       return rc;
   } else {
-    if ((rc = TURN(lcr_kpconv_aggregate(x, pos, q.pts, sup.pts, idx, 0, M, Ns, H, mid, b.kernel_points_host, b.sigma, A, nn, q.order, s)))) return rc;
+    if ((rc = TURN(lcr_kpconv_aggregate_ex(x, pos, q.pts, sup.pts, idx, 0, M, Ns, H, mid, b.kernel_points_host, b.sigma, A, nn, q.order, vf_flag, s)))) return rc;
     // weights pre-transposed by the caller ([mid, 15 mid]): both operands k-contiguous -> the K-deep GEMM form
     if (b.kp_wt_split && mid >= 64) {      // N = 32 contractions stream A at the HBM rate on the fp32 form already
       if ((rc = TURN(lcr_gemm_f32_bsplit(A, b.kp_wt_split, kpo, M, mid, 15 * mid, b.kp_b, nn, q.seg, sp.S, g, stc, s)))) return rc;

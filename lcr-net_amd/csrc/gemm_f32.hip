@@ -929,7 +929,7 @@ __global__ __launch_bounds__(256) void k_split_bf16x3_tiles(const float* __restr
 // 64 x 64 tile, 2 x 2 wavefronts of 32 x 32 (the stage-3/4 contractions are 200-600 such tiles on 256 CUs).  Both operands' planes in LDS,
 // DOUBLE-buffered: the split + plane writes of tile t+1 run under the MFMAs of tile t and a K-step has ONE barrier; tiles t+1 and t+2 in flight /
 // parked in two register stages; every load instruction fetches full 128-B lines (A: 8 lanes per row; B: the pre-tiled planes, verbatim).
-// What was measured on the way (tools/gemm_split_bench.py), each against the fp32 K-deep kernel over the 13 bench shapes:
+// What was measured on the way (tools/gemm_split_bench.py, LABNOTES.md §4.4), each against the fp32 K-deep kernel over the 13 bench shapes:
 // single-buffered LDS with two barriers per step 1.00x; larger tiles (128 x 64, 128 x 128 on 4 wavefronts; 128 x 64 on 8) lose on the encoder's
 // shapes (too few tiles) and win on 8192 x 1024 x 1024 (1.45x); A straight from global memory into fragment registers 0.92x; four register
 // stages: no change; 80-byte padded LDS rows: a third of the LDS cycles were bank conflicts of the 16-B WRITES (SQ_LDS_BANK_CONFLICT) — the XOR

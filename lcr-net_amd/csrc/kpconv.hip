@@ -11,7 +11,7 @@
 //   3. writes the (15*C) row that lcr_gemm_f32 contracts with the (15*C, Cout) weights (:108-110) and the neighbour
 //      count used by its epilogue (:113-116: neighbours whose feature row sums to > 0).
 // Only the (M, 15*C) aggregate goes through HBM/Infinity-Cache between the two halves.  Earlier variants (VALU accumulation with
-// the influences parked in LDS; MFMA with scalar 4-B gathers) are described with their measurements in DESIGN.md §4.1.
+// the influences parked in LDS; MFMA with scalar 4-B gathers) are described with their measurements in LABNOTES.md §4.1.
 // encoder1_1 (C_in = 1, backbone4.py:15) is fully fused in k_kpconv_cin1.
 #include <algorithm>
 #include <cstdlib>
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate_vec(const fl
                                                                         const float* __restrict__ q_pts, const float* __restrict__ s_pts,
                                                                         const IdxT* __restrict__ idx, int64_t M, int64_t Ns, int H, KPoints kp,
                                                                         float sigma, float* __restrict__ A, float* __restrict__ nn,
-                                                                        const int32_t* __restrict__ order) {
+                                                                        const int32_t* __restrict__ order, int valid_first) {
   constexpr int V = C >= 64 ? 4 : 2;
   constexpr int NL = C / (16 * V);           // vector loads per lane per 4-neighbour step
   constexpr int D = NL == 1 ? 4 : 2;         // steps in flight (register ring)
@@ -111,6 +111,9 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate_vec(const fl
       }
       n += __popcll(mk);
       cnt += __popcll(wave_ballot(positive));      // scalar popcount of a lane mask instead of a six-step cross-lane sum
+      // rows of a radius search are "valid first, padding last": a chunk with a hole is the row's last one — H = 65 ... 80 rows
+      // (stages 1-3) whose ball holds <= 64 supports skip their second, all-padding chunk (LCR_KP_VALID_FIRST; wave-uniform)
+      if (valid_first && mk != ~0ull) break;
     }
     // The list is padded with far-away neighbours (relative position 1e6: linear influence exactly 0 for every kernel point; feature
     // row 0, multiplied by that 0): the steps then need neither an index clamp nor an in-range mask — 6 of ~19 VALU instructions per
@@ -654,12 +657,13 @@ static int g_agg_force_off64 = 0;          // tests: run the 64-bit-offset form 
 
 template <typename IdxT>
 static int launch_aggregate(const float* s_feats, const uint8_t* s_pos, const float* q_pts, const float* s_pts, const IdxT* idx, int64_t M,
-                            int64_t Ns, int H, int C, const KPoints& kp, float sigma, float* A, float* nn, const int32_t* order, hipStream_t st) {
+                            int64_t Ns, int H, int C, const KPoints& kp, float sigma, float* A, float* nn, const int32_t* order, int vf,
+                            hipStream_t st) {
   dim3 grid(grid_for_xcd(M, KP_WAVES)), block(KP_WAVES * 64);
   const bool off32 = Ns * C < (int64_t(1) << 30) && !g_agg_force_off64;          // feature rows addressable with 32-bit byte offsets
 #define LCR_AGG(CC)                                                                                                                          \
-  if (off32) LCR_LAUNCH_TIMED((k_kpconv_aggregate_vec<IdxT, CC, true>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order); \
-  else LCR_LAUNCH_TIMED((k_kpconv_aggregate_vec<IdxT, CC, false>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order);      \
+  if (off32) LCR_LAUNCH_TIMED((k_kpconv_aggregate_vec<IdxT, CC, true>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order, vf); \
+  else LCR_LAUNCH_TIMED((k_kpconv_aggregate_vec<IdxT, CC, false>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order, vf);      \
   break
   switch (C) {
     case 32: LCR_AGG(32);
@@ -681,6 +685,12 @@ extern "C" void lcr_kpconv_debug_off64(int on) { g_agg_force_off64 = on; }
 extern "C" int lcr_kpconv_aggregate(const float* s_feats, const uint8_t* s_pos, const float* q_pts, const float* s_pts, const void* idx,
                                     int idx_is_64, int64_t M, int64_t Ns, int H, int C, const float* kernel_points_host, float sigma,
                                     float* A, float* nn, const int32_t* order, void* stream) {
+  return lcr_kpconv_aggregate_ex(s_feats, s_pos, q_pts, s_pts, idx, idx_is_64, M, Ns, H, C, kernel_points_host, sigma, A, nn, order, 0, stream);
+}
+
+extern "C" int lcr_kpconv_aggregate_ex(const float* s_feats, const uint8_t* s_pos, const float* q_pts, const float* s_pts, const void* idx,
+                                       int idx_is_64, int64_t M, int64_t Ns, int H, int C, const float* kernel_points_host, float sigma,
+                                       float* A, float* nn, const int32_t* order, int flags, void* stream) {
   if (!s_feats || !s_pos || !q_pts || !s_pts || !idx || !kernel_points_host || !A || !nn || M < 0 || Ns < 0 || H < 1 || H > KP_HMAX ||
       !(sigma > 0.f)) {
     set_error("lcr_kpconv_aggregate: bad argument (H must be in [1,%d])", KP_HMAX);
@@ -690,8 +700,9 @@ extern "C" int lcr_kpconv_aggregate(const float* s_feats, const uint8_t* s_pos, 
   const KPoints kp = load_kp(kernel_points_host);
   hipStream_t st = static_cast<hipStream_t>(stream);
   KernelTimerScope timed(KT_AGGREGATE, st, M, Ns, H, C, idx_is_64 ? 8 : 4);
-  return idx_is_64 ? launch_aggregate(s_feats, s_pos, q_pts, s_pts, static_cast<const int64_t*>(idx), M, Ns, H, C, kp, sigma, A, nn, order, st)
-                   : launch_aggregate(s_feats, s_pos, q_pts, s_pts, static_cast<const int32_t*>(idx), M, Ns, H, C, kp, sigma, A, nn, order, st);
+  const int vf = (flags & LCR_KP_VALID_FIRST) ? 1 : 0;
+  return idx_is_64 ? launch_aggregate(s_feats, s_pos, q_pts, s_pts, static_cast<const int64_t*>(idx), M, Ns, H, C, kp, sigma, A, nn, order, vf, st)
+                   : launch_aggregate(s_feats, s_pos, q_pts, s_pts, static_cast<const int32_t*>(idx), M, Ns, H, C, kp, sigma, A, nn, order, vf, st);
 }
 
 extern "C" int lcr_kpconv_fused(const float* s_feats, const uint8_t* s_pos, const float* q_pts, const float* s_pts, const void* idx,

@@ -14,7 +14,7 @@
 // index).  Rows whose in-radius count exceeds the LDS capacity fall back to a storage-free rank by re-enumeration (exact,
 // slow, rare).  Nominally HBM-bound by its output rows (limit * 4 or 8 bytes per query); measured, it is bound by instruction
 // issue on three units at once — per query ≈350 VALU, ≈180 SALU and ≈25 LDS wavefront instructions, the LDS unit being shared
-// by the four SIMDs of a CU (DESIGN.md §4.1 has the ablation numbers).
+// by the four SIMDs of a CU (LABNOTES.md §4.1 has the ablation numbers).
 #include <cstdlib>
 
 #include "common.h"

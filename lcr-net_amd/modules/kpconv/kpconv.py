@@ -13,7 +13,7 @@ from ...weights import base_kernel_points
 
 
 # Opt-in: the one-launch KPConv for C = 32 (lcr_kpconv_fused).  It removes the (M, 480) intermediate from memory, and measured
-# 1.75-2.1x SLOWER than aggregate + GEMM on MI355X (324 vs 185 us, 190 vs 88 us: DESIGN.md §4.2) — the gather needs the occupancy
+# 1.75-2.1x SLOWER than aggregate + GEMM on MI355X (324 vs 185 us, 190 vs 88 us: LABNOTES.md §4.2) — the gather needs the occupancy
 # that the tile in LDS and the weights in registers take away.
 _FUSED = bool(os.environ.get("LCR_KPCONV_FUSED"))
 

@@ -5,7 +5,7 @@
   whole wavefront, candidate broadcast from scalar registers) all test the UNION of their neighbourhoods' cells, un-culled per query.
 
 For a stage-0 cloud it prints the mean candidates per query of the first form and the mean union size per tile of the second, and what both
-cost in wavefront instructions per query with the per-step counts of DESIGN.md §4.4.  No GPU involved: this sizes the experiment before it is built."""
+cost in wavefront instructions per query with the per-step counts of LABNOTES.md §4.4.  No GPU involved: this sizes the experiment before it is built."""
 import os
 import sys
 

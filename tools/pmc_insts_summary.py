@@ -7,7 +7,7 @@
 Counters are wavefront instructions summed over the chip.  Encoder kernels are divided by PASSES, pre-processing kernels (run once per
 distinct batch before the passes) by BATCHES: both columns are "per 8-scan step".  `valu issue us` = VALU instructions x 4 cycles (a
 64-lane instruction on a 16-lane SIMD) / (1024 SIMDs x 2.4 GHz): the time the chip's VALU issue ports would need for this kernel alone if
-they never idled — the quantity the step is short of."""
+they never idled — the quantity the step is short of (LABNOTES.md §4.4)."""
 import collections
 import csv
 import sys
