@@ -281,44 +281,57 @@ class LCRNet(nn.Module):
         K = self.num_points_in_patch
         dev = pts_f.device
         n_all = pts_f.shape[0]
-        parts = []
+        import numpy as np
+        parts, stacks = [], []
         for g0 in range(0, 2 * P, 64):                                  # one launch sequence per 64 clouds of the stack
             g1 = min(2 * P, g0 + 64)
             _, nm, knn, km = F.point_to_node_partition_stack(pts_f, off_f[g0:g1 + 1], vd["points_c"], off_m[g0:g1 + 1], K)
+            stacks.append((nm, knn, km))
             for c in range(g0, g1):
                 lo, hi = off_m[c] - off_m[g0], off_m[c + 1] - off_m[g0]
                 parts.append((nm[lo:hi], knn[lo:hi], km[lo:hi]))
+        nm_all, knn_all, km_all = (stacks[0] if len(stacks) == 1 else tuple(torch.cat([st[i] for st in stacks]) for i in range(3)))
         m = [off_m[c + 1] - off_m[c] for c in range(2 * P)]
         Mx, Nx = max(m[0::2]), max(m[1::2])
         fc = vd["feats_c"]
-        fp = torch.zeros((P, Mx, fc.shape[1]), dtype=fc.dtype, device=dev)
-        fa = torch.zeros((P, Nx, fc.shape[1]), dtype=fc.dtype, device=dev)
-        rm = torch.zeros((P, Mx), dtype=torch.bool, device=dev)
-        cm = torch.zeros((P, Nx), dtype=torch.bool, device=dev)
-        for p in range(P):
-            fp[p, :m[2 * p]] = fc[off_m[2 * p]:off_m[2 * p + 1]]
-            fa[p, :m[2 * p + 1]] = fc[off_m[2 * p + 1]:off_m[2 * p + 2]]
-            rm[p, :m[2 * p]] = parts[2 * p][0]
-            cm[p, :m[2 * p + 1]] = parts[2 * p + 1][0]
+        # ---- the padded (P, Mx | Nx) node batches and everything per node row, for ALL pairs at once: the row maps are built on the host
+        # (plain index arithmetic on the offset lists) and uploaded in ONE copy; a per-pair / per-side loop of torch ops was ~120 launches
+        # of 5-10 us per 8-pair call (profiles/r05_pair_model_kernel_summary.md)
+        cloud = np.repeat(np.arange(2 * P), m)                                        # cloud of every stacked node row
+        local = np.arange(off_m[-1] - off_m[0]) - np.asarray(off_m[:-1])[cloud] + off_m[0]
+        side = cloud & 1
+        dst = (cloud >> 1) * np.where(side == 0, Mx, Nx) + local                      # row in the flattened (P * Mx) / (P * Nx) batch
+        n_f = np.asarray(off_f[1:]) - np.asarray(off_f[:-1])
+        host = np.stack([dst, np.asarray(off_f[:-1])[cloud], n_f[cloud], side]).astype(np.int64)
+        tab = torch.from_numpy(host).to(dev, non_blocking=True)
+        rows_pos = torch.from_numpy(np.nonzero(side == 0)[0]).to(dev, non_blocking=True)
+        rows_anc = torch.from_numpy(np.nonzero(side == 1)[0]).to(dev, non_blocking=True)
+        fp = torch.zeros((P * Mx, fc.shape[1]), dtype=fc.dtype, device=dev)
+        fa = torch.zeros((P * Nx, fc.shape[1]), dtype=fc.dtype, device=dev)
+        rm = torch.zeros((P * Mx,), dtype=torch.bool, device=dev)
+        cm = torch.zeros((P * Nx,), dtype=torch.bool, device=dev)
+        dpos, danc = tab[0][rows_pos], tab[0][rows_anc]
+        fp[dpos] = fc[rows_pos]
+        fa[danc] = fc[rows_anc]
+        rm[dpos] = nm_all[rows_pos]
+        cm[danc] = nm_all[rows_anc]
+        fp, fa, rm, cm = fp.view(P, Mx, -1), fa.view(P, Nx, -1), rm.view(P, Mx), cm.view(P, Nx)
         ns = F.log_optimal_transport(F.bmm_nt(fp, fa), rm, cm, self.node_optimal_transport.alpha,
                                      scale=1.0 / fc.shape[1] ** 0.5, iters=self.node_optimal_transport.num_iterations)
         nbij, nscore = F.top1_matching(ns)                              # rows (pair, i, j), pair-major; padding never beats a dustbin
-        per_pair = torch.bincount(nbij[:, 0].long(), minlength=P).tolist()          # host sync: node correspondences per pair
+        nb = nbij.long()
+        per_pair = torch.bincount(nb[:, 0], minlength=P).tolist()                   # host sync: node correspondences per pair
         q_off = [0]
         for x in per_pair:
             q_off.append(q_off[-1] + x)
-        pk_g, ak_g, pkm, akm, node_idx = [], [], [], [], []
-        for p in range(P):
-            rows = nbij[q_off[p]:q_off[p + 1]]
-            pi, ai = rows[:, 1].long(), rows[:, 2].long()
-            node_idx.append((pi, ai))
-            for side, idx, out_g, out_m in ((2 * p, pi, pk_g, pkm), (2 * p + 1, ai, ak_g, akm)):
-                knn = parts[side][1][idx]                                # (Q, K) point indices inside the cloud, pad = its point count
-                n_f = off_f[side + 1] - off_f[side]
-                out_g.append(torch.where(knn == n_f, torch.full_like(knn, n_all), knn + off_f[side]))   # -> rows of the whole stack
-                out_m.append(parts[side][2][idx])
-        pk_g, ak_g = torch.cat(pk_g).contiguous(), torch.cat(ak_g).contiguous()
-        pkm, akm = torch.cat(pkm).contiguous(), torch.cat(akm).contiguous()
+        # patch point indices of the matched nodes as rows of the WHOLE stack (pad = n_all), every pair and side in one pass
+        knn_g = torch.where(knn_all == tab[2][:, None], torch.full_like(knn_all, n_all), knn_all + tab[1][:, None])
+        off_even = torch.tensor([off_m[2 * p] - off_m[0] for p in range(P)], dtype=torch.int64).to(dev, non_blocking=True)
+        off_odd = torch.tensor([off_m[2 * p + 1] - off_m[0] for p in range(P)], dtype=torch.int64).to(dev, non_blocking=True)
+        gi, gj = nb[:, 1] + off_even[nb[:, 0]], nb[:, 2] + off_odd[nb[:, 0]]
+        pk_g, ak_g, pkm, akm = knn_g[gi], knn_g[gj], km_all[gi], km_all[gj]
+        node_idx = [(nb[q_off[p]:q_off[p + 1], 1], nb[q_off[p]:q_off[p + 1], 2]) for p in range(P)]
+        pk_g, ak_g, pkm, akm = pk_g.contiguous(), ak_g.contiguous(), pkm.contiguous(), akm.contiguous()
         pkp, akp = F.gather_rows(pts_f, pk_g), F.gather_rows(pts_f, ak_g)
         pkf, akf = F.gather_rows(feats_f, pk_g), F.gather_rows(feats_f, ak_g)
         ms = F.log_optimal_transport(F.bmm_nt(pkf, akf), pkm, akm, self.optimal_transport.alpha,
