@@ -1037,14 +1037,15 @@ __global__ __launch_bounds__(256) void k_top1_stats(const float* __restrict__ lo
   }
 }
 
-// count / emit the (i, j) pairs of every row in row-major order: (rowarg hit) OR (column hits with colarg == i), i < M, j < N,
+// count / emit the (i, j) pairs of every row in row-major order: (rowarg hit) OR — AND with `mutual` — (column hits with colarg == i), i < M, j < N,
 // optionally gated by validity masks.  PHASE 0 = count per (b, i); PHASE 1 = write at the scanned offsets.
 template <int PHASE>
 __global__ __launch_bounds__(256) void k_top1_emit(const float* __restrict__ logS, int64_t B, int M, int N, const int32_t* __restrict__ rowarg,
                                                    const uint8_t* __restrict__ rowbeat, const int32_t* __restrict__ colarg,
                                                    const uint8_t* __restrict__ colbeat, const uint8_t* __restrict__ row_mask,
                                                    const uint8_t* __restrict__ col_mask, int32_t* __restrict__ counts,
-                                                   const int32_t* __restrict__ offsets, int32_t* __restrict__ out_bij, float* __restrict__ out_score) {
+                                                   const int32_t* __restrict__ offsets, int32_t* __restrict__ out_bij, float* __restrict__ out_score,
+                                                   int mutual) {
   const int M1 = M + 1, N1 = N + 1;
   const int64_t rows = B * M;
   for (int64_t t = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; t < rows; t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
@@ -1058,7 +1059,8 @@ __global__ __launch_bounds__(256) void k_top1_emit(const float* __restrict__ log
       const int64_t o = PHASE ? offsets[t] : 0;
       for (int j = 0; j < N; ++j) {
         if (col_mask && !col_mask[b * N + j]) continue;
-        const bool hit = (rb && ra == j) || (colbeat[b * N1 + j] && colarg[b * N1 + j] == i);
+        const bool from_row = rb && ra == j, from_col = colbeat[b * N1 + j] && colarg[b * N1 + j] == i;
+        const bool hit = mutual ? (from_row && from_col) : (from_row || from_col);      // local_global_registration.py:84-87
         if (hit) {
           if (PHASE) {
             out_bij[3 * (o + c) + 0] = static_cast<int32_t>(b);
@@ -1687,6 +1689,13 @@ extern "C" int lcr_top1_matching_ws_bytes(int64_t B, int M, int N, size_t* bytes
 // then call again with buffers of `total` entries.  (b,i,j) triplets in row-major order; scores in the exp domain.
 extern "C" int lcr_top1_matching(const float* logS, int64_t B, int M, int N, const uint8_t* row_mask, const uint8_t* col_mask, int64_t* total,
                                  int32_t* out_bij, float* out_score, void* ws, size_t ws_bytes, void* stream) {
+  return lcr_top1_matching_ex(logS, B, M, N, row_mask, col_mask, 0, total, out_bij, out_score, ws, ws_bytes, stream);
+}
+
+// mutual != 0: a pair is kept only if it is BOTH its row's and its column's dustbin-beating maximum (LocalGlobalRegistration(mutual=True),
+// local_global_registration.py:84-85); 0: either (the shipped configuration)
+extern "C" int lcr_top1_matching_ex(const float* logS, int64_t B, int M, int N, const uint8_t* row_mask, const uint8_t* col_mask, int mutual,
+                                    int64_t* total, int32_t* out_bij, float* out_score, void* ws, size_t ws_bytes, void* stream) {
   if (!logS || !ws || B < 1 || M < 1 || N < 1 || (!out_bij && !total)) return LCR_EARG;
   size_t need = 0;
   lcr_top1_matching_ws_bytes(B, M, N, &need);
@@ -1704,13 +1713,13 @@ extern "C" int lcr_top1_matching(const float* logS, int64_t B, int M, int N, con
     const int slices = B >= 64 ? 1 : std::max(1, std::min(32, (M + 1 + 15) / 16));
     hipLaunchKernelGGL(k_top1_stats, dim3(static_cast<int>(B), slices), dim3(256), 0, st, logS, M, N, rowarg, rowbeat, colarg, colbeat);
     hipLaunchKernelGGL((k_top1_emit<0>), dim3(blocks_for(B * M)), dim3(256), 0, st, logS, B, M, N, rowarg, rowbeat, colarg, colbeat, row_mask, col_mask,
-                       counts, offsets, out_bij, out_score);
+                       counts, offsets, out_bij, out_score, mutual);
     hipMemsetAsync(counts + B * M, 0, sizeof(int32_t), st);
     int rc = exclusive_scan_i32(counts, offsets, B * M + 1, total, sws, st);
     if (rc) return rc;
   } else {
     hipLaunchKernelGGL((k_top1_emit<1>), dim3(blocks_for(B * M)), dim3(256), 0, st, logS, B, M, N, rowarg, rowbeat, colarg, colbeat, row_mask, col_mask,
-                       counts, offsets, out_bij, out_score);
+                       counts, offsets, out_bij, out_score, mutual);
   }
   return check_launch("lcr_top1_matching");
 }

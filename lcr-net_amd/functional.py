@@ -569,8 +569,9 @@ def log_optimal_transport(raw_scores, row_masks, col_masks, alpha, scale=1.0, it
     return S
 
 
-def top1_matching(log_scores, row_masks=None, col_masks=None):
+def top1_matching(log_scores, row_masks=None, col_masks=None, mutual=False):
     """(bij int32 [C,3], scores f32 [C], per-row offsets are internal) — dustbin top-1 matching, row-major order.
+    mutual: keep a pair only if it is the maximum of its row AND of its column (local_global_registration.py:84-85) instead of either.
     One host sync for the (data-dependent) number of correspondences."""
     B, M1, N1 = log_scores.shape
     M, N, dev = M1 - 1, N1 - 1, log_scores.device
@@ -580,14 +581,14 @@ def top1_matching(log_scores, row_masks=None, col_masks=None):
     rm = row_masks.to(torch.uint8).contiguous() if row_masks is not None else None
     cm = col_masks.to(torch.uint8).contiguous() if col_masks is not None else None
     total = torch.zeros(1, dtype=torch.int64, device=dev)
-    args = (_lib.ptr(log_scores.contiguous()), B, M, N, _lib.ptr(rm), _lib.ptr(cm))
-    _lib.check(_L().lcr_top1_matching(*args, _lib.ptr(total), None, None, _lib.ptr(ws), ws.numel(), _sp(log_scores)), "lcr_top1_matching")
+    args = (_lib.ptr(log_scores.contiguous()), B, M, N, _lib.ptr(rm), _lib.ptr(cm), int(bool(mutual)))
+    _lib.check(_L().lcr_top1_matching_ex(*args, _lib.ptr(total), None, None, _lib.ptr(ws), ws.numel(), _sp(log_scores)), "lcr_top1_matching")
     n = int(total.item())
     check_transport_status()
     bij = torch.empty((max(n, 1), 3), dtype=torch.int32, device=dev)
     sc = torch.empty((max(n, 1),), dtype=torch.float32, device=dev)
     if n:
-        _lib.check(_L().lcr_top1_matching(*args, _lib.ptr(total), _lib.ptr(bij), _lib.ptr(sc), _lib.ptr(ws), ws.numel(), _sp(log_scores)),
+        _lib.check(_L().lcr_top1_matching_ex(*args, _lib.ptr(total), _lib.ptr(bij), _lib.ptr(sc), _lib.ptr(ws), ws.numel(), _sp(log_scores)),
                    "lcr_top1_matching")
     return bij[:n], sc[:n]
 

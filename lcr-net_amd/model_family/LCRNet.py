@@ -127,6 +127,10 @@ class LCRNet(nn.Module):
         self.acceptance_radius = fm.get("acceptance_radius", 0.45)
         self.correspondence_threshold = fm.get("correspondence_threshold", 3)
         self.num_refinement_steps = fm.get("num_refinement_steps", 5)
+        self.mutual = bool(fm.get("mutual", False))                  # LocalGlobalRegistration(mutual=...), local_global_registration.py:84-87
+        if fm.get("topk", 1) != 1 or not fm.get("use_dustbin", True) or fm.get("correspondence_limit") is not None:
+            raise NotImplementedError("fine_matching: only topk=1, use_dustbin=True, correspondence_limit=None (the reference's shipped "
+                                      "config_model.py) are built; mutual may be either")
         self.proj_node_overlap_score = nn.Linear(g["output_dim"] * 2, 1)
         self.transformer = ThDRoFormer(g["input_dim"], g["output_dim"], g["hidden_dim"], g["num_heads"], g["num_layers"], g["k"])
         self.kpdecoder = KPDecoder(b["init_dim"], b["group_norm"])
@@ -135,7 +139,7 @@ class LCRNet(nn.Module):
         if self.global_head:
             self.netvlad = NetVLADLoupe2(feature_size=1024, cluster_size=64, output_dim=256, gating=True, add_norm=True, is_training=False)
 
-    # ---- LocalGlobalRegistration (geotransformer/local_global_registration.py:134-246; k=1, mutual=False, dustbin) --------
+    # ---- LocalGlobalRegistration (geotransformer/local_global_registration.py:134-246; k=1, dustbin; mutual from the config) --------
     def _local_global_registration_group(self, ref_knn_points, src_knn_points, ref_masks, src_masks, log_scores, patch_off):
         """The registration tail of S pairs at once.  Patch correspondences of all pairs are stacked (pair s owns patches
         [patch_off[s], patch_off[s+1])): ONE dustbin top-1 matching over all patches, the matched points gathered once, and the
@@ -144,7 +148,7 @@ class LCRNet(nn.Module):
         One host read-back of the per-pair correspondence counts (output shapes) on top of top-1 matching's own."""
         Pn, K = ref_masks.shape
         S = len(patch_off) - 1
-        bij, sc = F.top1_matching(log_scores, ref_masks, src_masks)
+        bij, sc = F.top1_matching(log_scores, ref_masks, src_masks, mutual=self.mutual)
         if bij.shape[0] == 0:
             raise RuntimeError("no dense correspondences (the reference fails here as well)")
         b, i, j = bij[:, 0].long(), bij[:, 1].long(), bij[:, 2].long()

@@ -376,8 +376,8 @@ def _apply(T, p):
     return p @ T[..., :3, :3].transpose(-1, -2) + T[..., None, :3, 3]
 
 
-def local_global_registration(ref_knn_pts, src_knn_pts, ref_masks, src_masks, log_scores, acceptance_radius=0.45, threshold=3, steps=5):
-    """geotransformer/local_global_registration.py:204-246 with k=1, mutual=False, use_dustbin=True, no correspondence limit."""
+def local_global_registration(ref_knn_pts, src_knn_pts, ref_masks, src_masks, log_scores, acceptance_radius=0.45, threshold=3, steps=5, mutual=False):
+    """geotransformer/local_global_registration.py:204-246 with k=1, use_dustbin=True, no correspondence limit; mutual as given (:84-87)."""
     S = torch.exp(log_scores)
     B, M1, N1 = S.shape
     bi = torch.arange(B)
@@ -389,7 +389,7 @@ def local_global_registration(ref_knn_pts, src_knn_pts, ref_masks, src_masks, lo
     sv, si = S.max(1)
     stop[bi[:, None], si, torch.arange(N1)[None]] = sv
     src_c = stop > S[:, -1, :][:, None, :]
-    corr = (ref_c | src_c)[:, :-1, :-1] & (ref_masks[:, :, None] & src_masks[:, None, :])
+    corr = ((ref_c & src_c) if mutual else (ref_c | src_c))[:, :-1, :-1] & (ref_masks[:, :, None] & src_masks[:, None, :])
     S = S[:, :-1, :-1] * corr.float()
     b, i, j = corr.nonzero(as_tuple=True)
     rp, sp, sc = ref_knn_pts[b, i], src_knn_pts[b, j], S[b, i, j]

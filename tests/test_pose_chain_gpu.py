@@ -242,3 +242,30 @@ def test_patch_transport_on_reference_scores(gold):
             assert e_ref < TOL, k
             worst = max(worst, e_ref)
     print("patch transport: worst difference to the reference on the problems it resolves itself: %.2e" % worst)
+
+
+def test_mutual_matching_branch_vs_reference_module(model):
+    """`fine_matching.mutual = True` (local_global_registration.py:84-87: a pair must be the dustbin-beating maximum of its row AND of its
+    column) — the value of the switch the shipped config does not use, built in round 5 (lcr_top1_matching_ex): correspondences exact,
+    scores 1e-6, refined transform 1e-4 against the imported reference module on the well-conditioned synthetic case; and the default
+    (either side) still equals the reference's."""
+    from make_golden_pose_chain import synthetic_lgr_case
+    from lcrnet_amd import functional as F
+    g = np.load(os.path.join(GOLDEN, "mutual_golden.npz"))
+    ref, src, rm, sm, logs, T_true = synthetic_lgr_case()
+    assert len(g["mutual_corr_bij"]) < len(g["either_corr_bij"])                      # the switch does something on this input
+    was = model.mutual
+    try:
+        for mutual, tag in ((True, "mutual_"), (False, "either_")):
+            model.mutual = mutual
+            with torch.no_grad():
+                rp, sp, sc, T = model._local_global_registration(cu(ref), cu(src), cu(rm), cu(sm), cu(logs))
+                bij, _ = F.top1_matching(cu(logs), cu(rm), cu(sm), mutual=mutual)
+            assert np.array_equal(bij.cpu().numpy().astype(np.int32), g[tag + "corr_bij"])
+            assert np.array_equal(rp.cpu().numpy(), g[tag + "ref_corr_points"]) and np.array_equal(sp.cpu().numpy(), g[tag + "src_corr_points"])
+            assert np.abs(sc.cpu().numpy() - g[tag + "corr_scores"]).max() < 1e-6
+            e_T = np.abs(T.cpu().numpy() - g[tag + "transform"]).max()
+            print("mutual=%s: %d correspondences, T within %.2e of the reference module's" % (mutual, len(sc), e_T))
+            assert e_T < TOL
+    finally:
+        model.mutual = was
