@@ -331,6 +331,12 @@ int lcr_attention_f32(const float* q, const float* k, const float* v, int64_t Nq
  * MultiHeadAttention for P registration pairs per call (reference loop: model_family/LCRNet.py:274-321, one pair per forward). */
 int lcr_attention_seg_f32(const float* q, const float* k, const float* v, const int64_t* q_len_host, const int64_t* k_len_host, int P,
                           int heads, int head_dim, float* out, void* stream);
+/* Top-k sparsified attention — dynamic_attention with k != None (rpetransformer.py:19-39; cfg.GAT.k, None in the shipped configuration):
+ * per query and head the kk_host[p] largest scores of problem p are soft-maxed, all others contribute nothing (kk = int(n_queries * k) is
+ * the caller's arithmetic; ties at the threshold are taken in index order — torch.topk leaves that order unspecified).  Keys per problem
+ * <= 4096. */
+int lcr_attention_topk_f32(const float* q, const float* k, const float* v, const int64_t* q_len_host, const int64_t* k_len_host,
+                           const int* kk_host, int P, int heads, int head_dim, float* out, void* stream);
 /* y = LayerNorm(a + b) (b may be NULL), rows of D <= 1024 features. */
 int lcr_add_layernorm(const float* a, const float* b, const float* gamma, const float* beta, int64_t N, int D, float eps,
                       float* y, void* stream);

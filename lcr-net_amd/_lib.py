@@ -60,6 +60,7 @@ _SIGS = {
     "lcr_rotary_embed": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),
     "lcr_attention_f32": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp]),
     "lcr_attention_seg_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
+    "lcr_attention_topk_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "lcr_add_layernorm": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_float, c_vp, c_vp]),
     "lcr_relu_inplace": (c_int, [c_vp, c_i64, c_vp]),
     "lcr_retrieval_ws_bytes": (c_int, [c_i64, c_i64, c_size_p]),

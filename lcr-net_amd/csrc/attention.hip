@@ -241,6 +241,153 @@ __global__ __launch_bounds__(64 * AT_SPLIT) void k_attention_seg(const float* __
                  static_cast<int64_t>(static_cast<int>(blockIdx.x) - seg.tile_off[p]) * 32, blockIdx.y, s_q, s_k[wsp], s_v[wsp], &s_mg);
 }
 
+// ---- top-k sparsified attention: dynamic_attention with k != None (rpetransformer.py:19-39) --------------------------------------
+// The shipped configuration has cfg.GAT.k = None (full softmax, the fused kernel above); with a fraction per self layer the reference keeps,
+// per query and head, the kk = int(n_queries * k) largest scores, soft-maxes THOSE and zeroes the rest.  Built for completeness, not for
+// speed (one wavefront per (query, head); scores of the row parked in LDS, the kk-th largest found by a 4-pass radix select on the
+// order-preserving bits, ties at the threshold taken in index order — torch.topk leaves that order unspecified).
+constexpr int ATK_MAXK = 4096;        // keys per problem (16 KB of LDS per wavefront)
+struct AttnTopkSeg {
+  int P;
+  int q_off[AT_MAX_P + 1], k_off[AT_MAX_P + 1], kk[AT_MAX_P];
+};
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+  return v;
+}
+__global__ __launch_bounds__(256) void k_attention_topk(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                        AttnTopkSeg seg, int heads, float scale, float* __restrict__ out) {
+  __shared__ float s_sc[4][ATK_MAXK];
+  __shared__ int s_hist[4][256];
+  __shared__ float s_o[4][AT_D];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t qi = static_cast<int64_t>(blockIdx.x) * 4 + w;
+  if (qi >= seg.q_off[seg.P]) return;                           // whole wavefront (no block-wide barriers below)
+  int p = 0;
+  while (p + 1 < seg.P && qi >= seg.q_off[p + 1]) ++p;
+  const int head = blockIdx.y, ld = heads * AT_D;
+  const int64_t ko = seg.k_off[p];
+  const int m = seg.k_off[p + 1] - seg.k_off[p], kk = min(seg.kk[p], m);
+  float* sc = s_sc[w];
+  int* hist = s_hist[w];
+  float* op = out + qi * ld + head * AT_D;
+  if (kk <= 0) {                                                // topk(0): nothing kept, the output row is zero
+    if (lane < AT_D) op[lane] = 0.f;
+    return;
+  }
+  float qv[AT_D];
+  {
+    const float4* qp = reinterpret_cast<const float4*>(q + qi * ld + head * AT_D);
+#pragma unroll
+    for (int c = 0; c < AT_D / 4; ++c) {
+      const float4 t = qp[c];
+      qv[4 * c] = t.x, qv[4 * c + 1] = t.y, qv[4 * c + 2] = t.z, qv[4 * c + 3] = t.w;
+    }
+  }
+  float mx = -INFINITY;
+  for (int j = lane; j < m; j += 64) {
+    const float4* kp = reinterpret_cast<const float4*>(k + (ko + j) * ld + head * AT_D);
+    float sdot = 0.f;
+#pragma unroll
+    for (int c = 0; c < AT_D / 4; ++c) {
+      const float4 t = kp[c];
+      sdot = fmaf(qv[4 * c], t.x, sdot);
+      sdot = fmaf(qv[4 * c + 1], t.y, sdot);
+      sdot = fmaf(qv[4 * c + 2], t.z, sdot);
+      sdot = fmaf(qv[4 * c + 3], t.w, sdot);
+    }
+    sdot *= scale;
+    sc[j] = sdot;
+    mx = fmaxf(mx, sdot);
+  }
+  mx = wave_max_f(mx);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // kk-th largest score: radix select over the order-preserving 32-bit keys, most significant byte first
+  uint32_t prefix = 0u, mask = 0u;
+  int remaining = kk;                                           // how many of the keys matching `prefix` are still to be taken from the top
+  if (kk < m) {
+    for (int pass = 3; pass >= 0; --pass) {
+      const int sh = 8 * pass;
+      for (int i = lane; i < 256; i += 64) hist[i] = 0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int j = lane; j < m; j += 64) {
+        const uint32_t u = f2ord(sc[j]);
+        if ((u & mask) == prefix) atomicAdd(&hist[(u >> sh) & 255u], 1);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // lane L owns bins 255-4L .. 252-4L (descending), so an inclusive scan over the lanes counts the keys in HIGHER bins
+      const int d0 = 255 - 4 * lane;
+      const int c0 = hist[d0], c1 = hist[d0 - 1], c2 = hist[d0 - 2], c3 = hist[d0 - 3];
+      const int tot = c0 + c1 + c2 + c3;
+      const int incl = wave_incl_scan(tot), excl = incl - tot;
+      const bool mine = excl < remaining && remaining <= incl;  // exactly one lane
+      int bsel = 0, above = 0;
+      if (mine) {
+        int acc = excl;
+        if (remaining <= acc + c0) bsel = d0, above = acc;
+        else if (remaining <= acc + c0 + c1) bsel = d0 - 1, above = acc + c0;
+        else if (remaining <= acc + c0 + c1 + c2) bsel = d0 - 2, above = acc + c0 + c1;
+        else bsel = d0 - 3, above = acc + c0 + c1 + c2;
+      }
+      const int src = __builtin_ctzll(wave_ballot(mine));
+      bsel = rdlane(bsel, src);
+      above = rdlane(above, src);
+      prefix |= static_cast<uint32_t>(bsel) << sh;
+      mask |= 0xffu << sh;
+      remaining -= above;
+    }
+  }
+  // soft-max over the kept scores (their largest is the row's largest) and the weighted sum of their value rows
+  float acc[AT_D];
+#pragma unroll
+  for (int d = 0; d < AT_D; ++d) acc[d] = 0.f;
+  float sum = 0.f;
+  int eq_taken = 0;
+  for (int j0 = 0; j0 < m; j0 += 64) {
+    const int j = j0 + lane;
+    const bool live = j < m;
+    const float sj = live ? sc[j] : 0.f;
+    const uint32_t u = f2ord(sj);
+    bool sel = live;
+    if (kk < m) {
+      const bool eq = live && u == prefix;
+      const uint64_t be = wave_ballot(eq);
+      sel = live && (u > prefix || (eq && eq_taken + mbcnt_lt(be) < remaining));
+      eq_taken += __popcll(be);
+    }
+    if (sel) {
+      const float pj = expf(sj - mx);
+      sum += pj;
+      const float4* vp = reinterpret_cast<const float4*>(v + (ko + j) * ld + head * AT_D);
+#pragma unroll
+      for (int c = 0; c < AT_D / 4; ++c) {
+        const float4 t = vp[c];
+        acc[4 * c] = fmaf(pj, t.x, acc[4 * c]);
+        acc[4 * c + 1] = fmaf(pj, t.y, acc[4 * c + 1]);
+        acc[4 * c + 2] = fmaf(pj, t.z, acc[4 * c + 2]);
+        acc[4 * c + 3] = fmaf(pj, t.w, acc[4 * c + 3]);
+      }
+    }
+  }
+  sum = wave_sum(sum);
+#pragma unroll
+  for (int d = 0; d < AT_D; ++d) {
+    const float t = wave_sum(acc[d]);
+    if (lane == 0) s_o[w][d] = t / sum;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (lane < AT_D) op[lane] = s_o[w][lane];
+}
+
 // y = LayerNorm(a + b) * gamma + beta, rows of D (<= 1024) features; one wavefront per row
 __global__ __launch_bounds__(256) void k_add_layernorm(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int64_t N, int D, float eps, float* __restrict__ y) {
@@ -339,6 +486,41 @@ extern "C" int lcr_attention_seg_f32(const float* q, const float* k, const float
   KernelTimerScope timed(KT_ATTENTION, static_cast<hipStream_t>(stream), qk, P, heads, head_dim);
   hipLaunchKernelGGL(k_attention_seg, dim3(static_cast<int>(to), heads), dim3(64 * AT_SPLIT), 0, static_cast<hipStream_t>(stream), q, k, v, seg, heads, scale, out);
   return check_launch("lcr_attention_seg_f32");
+}
+
+// top-k sparsified attention (rpetransformer.py:19-39 with k != None): problem p keeps, per query and head, its kk_host[p] largest scores
+extern "C" int lcr_attention_topk_f32(const float* q, const float* k, const float* v, const int64_t* q_len_host, const int64_t* k_len_host,
+                                      const int* kk_host, int P, int heads, int head_dim, float* out, void* stream) {
+  if (!q || !k || !v || !out || !q_len_host || !k_len_host || !kk_host || P < 1 || P > AT_MAX_P || heads < 1 || head_dim != AT_D) {
+    set_error("lcr_attention_topk_f32: bad argument (head_dim must be %d, 1 <= P <= %d)", AT_D, AT_MAX_P);
+    return LCR_EARG;
+  }
+  AttnTopkSeg seg;
+  seg.P = P;
+  int64_t qo = 0, ko = 0;
+  for (int p = 0; p < P; ++p) {
+    if (q_len_host[p] < 0 || k_len_host[p] < 1 || k_len_host[p] > ATK_MAXK || kk_host[p] < 0) {
+      set_error("lcr_attention_topk_f32: problem %d has %lld queries / %lld keys (1 <= keys <= %d), k = %d", p, static_cast<long long>(q_len_host[p]),
+                static_cast<long long>(k_len_host[p]), ATK_MAXK, kk_host[p]);
+      return LCR_EARG;
+    }
+    seg.q_off[p] = static_cast<int>(qo);
+    seg.k_off[p] = static_cast<int>(ko);
+    seg.kk[p] = kk_host[p];
+    qo += q_len_host[p];
+    ko += k_len_host[p];
+    if (qo > 2147483647 || ko > 2147483647) {
+      set_error("lcr_attention_topk_f32: more than 2^31-1 stacked rows");
+      return LCR_EARG;
+    }
+  }
+  seg.q_off[P] = static_cast<int>(qo);
+  seg.k_off[P] = static_cast<int>(ko);
+  if (qo == 0) return LCR_OK;
+  const float scale = 1.f / sqrtf(static_cast<float>(head_dim));
+  hipLaunchKernelGGL(k_attention_topk, dim3(static_cast<int>((qo + 3) / 4), heads), dim3(256), 0, static_cast<hipStream_t>(stream), q, k, v, seg, heads,
+                     scale, out);
+  return check_launch("lcr_attention_topk_f32");
 }
 
 extern "C" int lcr_add_layernorm(const float* a, const float* b, const float* gamma, const float* beta, int64_t N, int D, float eps, float* y,

@@ -428,6 +428,21 @@ def attention(q, k, v, heads, q_lens=None, k_lens=None):
     return out
 
 
+def attention_topk(q, k, v, heads, q_lens, k_lens, kks):
+    """dynamic_attention with k != None (rpetransformer.py:19-39): per problem p (rows stacked like `attention`), query and head, only the
+    kks[p] largest scores are soft-maxed.  kks[p] = int(n_queries_p * fraction) is computed by the caller as the reference does."""
+    assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
+    P = len(q_lens)
+    assert len(k_lens) == P and len(kks) == P and sum(q_lens) == q.shape[0] and sum(k_lens) == k.shape[0]
+    out = torch.empty_like(q)
+    ql, kl = (ctypes.c_int64 * P)(*[int(x) for x in q_lens]), (ctypes.c_int64 * P)(*[int(x) for x in k_lens])
+    kk = (ctypes.c_int * P)(*[int(x) for x in kks])
+    _lib.check(_lib.lib().lcr_attention_topk_f32(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), ctypes.cast(ql, ctypes.c_void_p), ctypes.cast(kl, ctypes.c_void_p),
+                                                 ctypes.cast(kk, ctypes.c_void_p), P, heads, q.shape[1] // heads, _lib.ptr(out), _lib.stream_ptr(q.device)),
+               "lcr_attention_topk_f32")
+    return out
+
+
 def add_layernorm(a, b, gamma, beta, eps=1e-5):
     y = torch.empty_like(a)
     _lib.check(_lib.lib().lcr_add_layernorm(_lib.ptr(a), _lib.ptr(b), _lib.ptr(gamma), _lib.ptr(beta), a.shape[0], a.shape[1], float(eps),

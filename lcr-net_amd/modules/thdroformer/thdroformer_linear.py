@@ -32,13 +32,17 @@ class _MultiHeadAttention(nn.Module):
         self.proj_k = nn.Linear(d_model, d_model)
         self.proj_v = nn.Linear(d_model, d_model)
 
-    def forward(self, input_q, input_k, input_v, theta_q=None, q_lens=None, k_lens=None):
+    def forward(self, input_q, input_k, input_v, theta_q=None, q_lens=None, k_lens=None, topk_frac=None):
         q = F.linear(input_q, self.proj_q.weight, self.proj_q.bias)
         k = F.linear(input_k, self.proj_k.weight, self.proj_k.bias)
         v = F.linear(input_v, self.proj_v.weight, self.proj_v.bias)
         if theta_q is not None:                                   # self layers: the SAME theta rotates q and k
             F.rotary_embed_(q, theta_q, self.num_heads)
             F.rotary_embed_(k, theta_q, self.num_heads)
+        if topk_frac is not None:                                 # dynamic_attention(q, k, v, self.k[layer]): k = int(n * k), n = the cloud's queries
+            ql = list(q_lens) if q_lens is not None else [q.shape[0]]
+            kl = list(k_lens) if k_lens is not None else [k.shape[0]]
+            return F.attention_topk(q, k, v, self.num_heads, ql, kl, [int(n * topk_frac) for n in ql])
         return F.attention(q, k, v, self.num_heads, q_lens, k_lens)
 
 
@@ -49,8 +53,8 @@ class _AttentionLayer(nn.Module):
         self.linear = nn.Linear(d_model, d_model)
         self.norm = nn.LayerNorm(d_model)
 
-    def forward(self, x, memory, theta=None, x_lens=None, m_lens=None):
-        h = self.attention(x, memory, memory, theta, x_lens, m_lens)
+    def forward(self, x, memory, theta=None, x_lens=None, m_lens=None, topk_frac=None):
+        h = self.attention(x, memory, memory, theta, x_lens, m_lens, topk_frac)
         h = F.linear(h, self.linear.weight, self.linear.bias)
         return F.add_layernorm(h, x, self.norm.weight, self.norm.bias, self.norm.eps)
 
@@ -74,14 +78,17 @@ class _TransformerLayer(nn.Module):
         self.attention = _AttentionLayer(d_model, num_heads)
         self.output = _AttentionOutput(d_model)
 
-    def forward(self, x, memory, theta=None, x_lens=None, m_lens=None):
-        return self.output(self.attention(x, memory, theta, x_lens, m_lens))
+    def forward(self, x, memory, theta=None, x_lens=None, m_lens=None, topk_frac=None):
+        return self.output(self.attention(x, memory, theta, x_lens, m_lens, topk_frac))
 
 
 class RPEConditionalTransformer(nn.Module):
-    def __init__(self, blocks, d_model, num_heads, parallel=False):
+    def __init__(self, blocks, d_model, num_heads, parallel=False, k=None):
         super().__init__()
         self.blocks, self.parallel = list(blocks), parallel
+        self.k = None if k is None else [float(x) for x in k]      # top-k fraction per SELF layer (rpetransformer.py:101-102: self.k[layer])
+        if self.k is not None and len(self.k) < sum(b == "self" for b in self.blocks):
+            raise ValueError("k needs one fraction per self layer")
         self.layers = nn.ModuleList([_TransformerLayer(d_model, num_heads) for _ in self.blocks])
 
     def forward(self, feats0, feats1, theta0, theta1, lens0=None, lens1=None):
@@ -92,10 +99,12 @@ class RPEConditionalTransformer(nn.Module):
         # at half the launches (these kernels sit on their launch floors: 11 fewer per self layer)
         theta_cat = torch.cat([theta0, theta1])
         lens_cat = (list(lens0) + list(lens1)) if lens0 is not None else [n0, feats1.shape[0]]
+        self_idx = 0
         for i, block in enumerate(self.blocks):
             if block == "self":
                 x = torch.cat([feats0, feats1])
-                x = self.layers[i](x, x, theta_cat, lens_cat, lens_cat)
+                x = self.layers[i](x, x, theta_cat, lens_cat, lens_cat, None if self.k is None else self.k[self_idx])
+                self_idx += 1
                 feats0, feats1 = x[:n0], x[n0:]
             elif self.parallel:
                 feats0, feats1 = self.layers[i](feats0, feats1, None, lens0, lens1), self.layers[i](feats1, feats0, None, lens1, lens0)
@@ -108,10 +117,10 @@ class RPEConditionalTransformer(nn.Module):
 class ThDRoFormer(nn.Module):
     def __init__(self, input_dim, output_dim, hidden_dim, num_heads, num_layers, k=None, dropout=None, activation_fn="ReLU", reduction_a="max"):
         super().__init__()
-        assert k is None and dropout is None and activation_fn == "ReLU", "reference configuration: full softmax, no dropout, ReLU"
+        assert dropout is None and activation_fn == "ReLU", "reference configuration: no dropout, ReLU"
         self.embedding = LinearLearnablePosEmbedding(hidden_dim, reduction_a=reduction_a)
         self.in_proj = nn.Linear(input_dim, hidden_dim)
-        self.transformer = RPEConditionalTransformer(["self", "cross"] * num_layers, hidden_dim, num_heads)
+        self.transformer = RPEConditionalTransformer(["self", "cross"] * num_layers, hidden_dim, num_heads, k=k)
         self.out_proj = nn.Linear(hidden_dim, output_dim)
 
     def forward(self, ref_points, src_points, ref_feats, src_feats, ref_lens=None, src_lens=None, return_pos_emb=False):

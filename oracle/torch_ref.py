@@ -153,15 +153,33 @@ def _heads(x, h):
     return x.reshape(x.shape[0], h, -1).permute(1, 0, 2)       # (N, h*c) -> (h, N, c)
 
 
-def attention_layer(sd, pfx, x, mem, heads, theta_x=None):
-    """Self (rotary, rpetransformer.py:57-170) when theta_x is given, else vanilla cross (vanilla_transformer.py:30-144)."""
+def topk_attention(q, k, v, kk):
+    """dynamic_attention with k != None (rpetransformer.py:19-39) on (H,N,D) / (H,M,D) heads: the kk largest scores of every row are
+    soft-maxed, everything else is zero.  Ties at the threshold: lowest key index first (torch.topk leaves it unspecified)."""
+    sc = torch.einsum("hnd,hmd->hnm", q, k) / math.sqrt(q.shape[-1])
+    if kk <= 0:
+        return torch.zeros_like(q)
+    if kk >= sc.shape[-1]:
+        return torch.einsum("hnm,hmd->hnd", torch.softmax(sc, dim=-1), v)
+    order = torch.sort(sc, dim=-1, descending=True, stable=True).indices[..., :kk]       # stable: equal scores keep index order
+    vals = torch.gather(sc, -1, order)
+    prob = torch.zeros_like(sc).scatter_(-1, order, torch.softmax(vals, dim=-1))
+    return torch.einsum("hnm,hmd->hnd", prob, v)
+
+
+def attention_layer(sd, pfx, x, mem, heads, theta_x=None, topk_frac=None):
+    """Self (rotary, rpetransformer.py:57-170) when theta_x is given, else vanilla cross (vanilla_transformer.py:30-144).
+    topk_frac: the self layer's fraction of cfg.GAT.k (kk = int(n_queries * fraction), rpetransformer.py:27)."""
     a = pfx + "attention.attention."
     q, k, v = _heads(_lin(sd, a + "proj_q.", x), heads), _heads(_lin(sd, a + "proj_k.", mem), heads), _heads(_lin(sd, a + "proj_v.", mem), heads)
     if theta_x is not None:
         th = _heads(theta_x, heads)
         q, k = rotary(q, th), rotary(k, th)
-    s = torch.softmax(torch.einsum("hnd,hmd->hnm", q, k) / math.sqrt(q.shape[-1]), dim=-1)
-    hdn = torch.einsum("hnm,hmd->hnd", s, v).permute(1, 0, 2).reshape(x.shape[0], -1)
+    if topk_frac is not None:
+        hdn = topk_attention(q, k, v, int(x.shape[0] * topk_frac)).permute(1, 0, 2).reshape(x.shape[0], -1)
+    else:
+        s = torch.softmax(torch.einsum("hnd,hmd->hnm", q, k) / math.sqrt(q.shape[-1]), dim=-1)
+        hdn = torch.einsum("hnm,hmd->hnd", s, v).permute(1, 0, 2).reshape(x.shape[0], -1)
     hdn = _lin(sd, pfx + "attention.linear.", hdn)
     y = _ln(sd, pfx + "attention.norm.", hdn + x)
     o = pfx + "output."
@@ -169,7 +187,7 @@ def attention_layer(sd, pfx, x, mem, heads, theta_x=None):
     return _ln(sd, o + "norm.", y + z)
 
 
-def thd_roformer(sd, ref_pts, src_pts, ref_feats, src_feats, pfx="transformer.", heads=4, num_layers=4):
+def thd_roformer(sd, ref_pts, src_pts, ref_feats, src_feats, pfx="transformer.", heads=4, num_layers=4, k=None):
     """thdroformer_linear.py:50-97 + RPEConditionalTransformer.forward rpetransformer.py:198-220 (sequential cross)."""
     emb = lambda p: _lin(sd, pfx + "embedding.encoder2.", _lin(sd, pfx + "embedding.encoder.", p))
     e0, e1 = emb(ref_pts), emb(src_pts)
@@ -177,8 +195,9 @@ def thd_roformer(sd, ref_pts, src_pts, ref_feats, src_feats, pfx="transformer.",
     for i in range(2 * num_layers):
         L = f"{pfx}transformer.layers.{i}."
         if i % 2 == 0:
-            f0 = attention_layer(sd, L, f0, f0, heads, e0)
-            f1 = attention_layer(sd, L, f1, f1, heads, e1)
+            fr = None if k is None else k[i // 2]
+            f0 = attention_layer(sd, L, f0, f0, heads, e0, fr)
+            f1 = attention_layer(sd, L, f1, f1, heads, e1, fr)
         else:
             f0 = attention_layer(sd, L, f0, f1, heads)
             f1 = attention_layer(sd, L, f1, f0, heads)      # attends to the UPDATED f0 (parallel=False)
