@@ -545,8 +545,10 @@ class PairPipeline:
     model, `workers` pairs in flight: one host thread + one HIP stream per worker, results handed back in input order.
 
     One pair is ~1000 short, dependent launches and four host round trips (NMS sizes, match counts, ...), i.e. bound by the host
-    and by launch latency, not by the GPU; a second pair in flight fills the gaps (80 -> 100-120 pairs/s on the demo pair).  More than
-    two workers lose to interpreter-lock contention (59 pairs/s with three)."""
+    and by launch latency, not by the GPU; a second pair in flight fills the gaps (80 -> 100-120 pairs/s on the demo pair).  At ONE pair
+    per call more than two workers lose to interpreter-lock contention (59 pairs/s with three, round 2); with pairs batched per call
+    (pairs_per_call >= 8: most of a call is native launch sequences that release the lock) a third worker fills the latency-bound tail:
+    584 / 628 / 629 pairs/s with 2 / 3 / 4 workers at 16 pairs per call (round 5)."""
 
     def __init__(self, model, voxel_size=0.3, radius=1.275, num_stages=4, neighbor_limits=(74, 68, 70, 67), workers=2, pairs_per_call=1):
         """pairs_per_call > 1: consecutive pairs are stacked and go through `LCRNet.forward_pairs` together (one collate, one encoder /
