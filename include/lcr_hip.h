@@ -410,6 +410,12 @@ int lcr_top1_matching(const float* logS, int64_t B, int M, int N, const uint8_t*
  * its row's and its column's maximum (each beating its dustbin); 0 = either, the shipped configuration. */
 int lcr_top1_matching_ex(const float* logS, int64_t B, int M, int N, const uint8_t* row_mask, const uint8_t* col_mask, int mutual,
                          int64_t* total, int32_t* out_bij, float* out_score, void* ws, size_t ws_bytes, void* stream);
+/* Dustbin top-K matching for K >= 1 (LocalGlobalRegistration(k=K), local_global_registration.py:56-82; K = 1 in the shipped configuration):
+ * (i, j) is kept from the row side if P[i][j] is among the K largest of row i — dustbin column included, equal values in index order — and
+ * beats the row's dustbin; from the column side likewise; `mutual` as above.  Two-phase and row-major like lcr_top1_matching. */
+int lcr_topk_matching_ws_bytes(int64_t B, int M, int N, size_t* bytes);
+int lcr_topk_matching(const float* logS, int64_t B, int M, int N, const uint8_t* row_mask, const uint8_t* col_mask, int K, int mutual,
+                      int64_t* total, int32_t* out_bij, float* out_score, void* ws, size_t ws_bytes, void* stream);
 /* out[n] = [ x[idx[n,0]] (zeros for the shadow index), skip[n] ]  (nearest_upsample + cat, backbone4.py:355-367) */
 int lcr_upsample_concat(const float* x, int64_t Nx, int C1, const void* idx, int idx_is_64, int H, const float* skip, int C2,
                         int64_t N, float* out, void* stream);

@@ -84,6 +84,8 @@ _SIGS = {
     "lcr_top1_matching_ws_bytes": (c_int, [c_i64, c_int, c_int, c_size_p]),
     "lcr_top1_matching": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "lcr_top1_matching_ex": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "lcr_topk_matching_ws_bytes": (c_int, [c_i64, c_int, c_int, c_size_p]),
+    "lcr_topk_matching": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "lcr_upsample_concat": (c_int, [c_vp, c_i64, c_int, c_vp, c_int, c_int, c_vp, c_int, c_i64, c_vp, c_vp]),
     "lcr_gather_rows": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_vp]),
     "lcr_procrustes_batched": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_float, c_vp, c_vp]),

@@ -1076,6 +1076,117 @@ __global__ __launch_bounds__(256) void k_top1_emit(const float* __restrict__ log
   }
 }
 
+// ---- dustbin top-K matching, K > 1 (LocalGlobalRegistration(k=K), local_global_registration.py:56-82; the shipped configuration has K = 1) ----
+// A pair (i, j) is kept from the row side if P[i][j] is among the K largest of row i (over the N + 1 columns, dustbin included) and beats the
+// row's dustbin P[i][N]; from the column side likewise.  "Among the K largest" in the order (value descending, index ascending) — torch.topk
+// leaves the order of equal values open — so the row keeps the K-th element (value, index) and membership is one comparison.
+__global__ __launch_bounds__(256) void k_topk_stats(const float* __restrict__ logS, int M, int N, int K, float* __restrict__ rowv, int32_t* __restrict__ rowj,
+                                                    float* __restrict__ colv, int32_t* __restrict__ coli) {
+  const int b = blockIdx.x, slice = blockIdx.y, nslices = gridDim.y;
+  const int M1 = M + 1, N1 = N + 1;
+  const float* s = logS + static_cast<int64_t>(b) * M1 * N1;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int i = slice * 4 + w; i < M1; i += 4 * nslices) {
+    float pv = INFINITY;                                     // the previous pick: everything is "after" (+inf, -1)
+    int pj = -1;
+    bool exhausted = false;
+    for (int t = 0; t < K; ++t) {
+      float best = -INFINITY;
+      int bj = 0x7fffffff;
+      for (int j = lane; j < N1; j += 64) {
+        const float p = expf(s[i * N1 + j]);
+        const bool after = p < pv || (p == pv && j > pj);
+        if (after && (p > best || (p == best && j < bj))) {
+          best = p;
+          bj = j;
+        }
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        const float ob = __shfl_xor(best, d);
+        const int oj = __shfl_xor(bj, d);
+        if (ob > best || (ob == best && oj < bj)) {
+          best = ob;
+          bj = oj;
+        }
+      }
+      if (bj == 0x7fffffff) {                                // fewer than K entries: the whole row is in the set
+        exhausted = true;
+        break;
+      }
+      pv = best;
+      pj = bj;
+    }
+    if (lane == 0) {
+      rowv[static_cast<int64_t>(b) * M1 + i] = exhausted ? -INFINITY : pv;
+      rowj[static_cast<int64_t>(b) * M1 + i] = exhausted ? 0x7fffffff : pj;
+    }
+  }
+  for (int j = slice * 256 + threadIdx.x; j < N1; j += 256 * nslices) {
+    float pv = INFINITY;
+    int pi = -1;
+    bool exhausted = false;
+    for (int t = 0; t < K; ++t) {
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+      for (int i = 0; i < M1; ++i) {
+        const float p = expf(s[i * N1 + j]);
+        const bool after = p < pv || (p == pv && i > pi);
+        if (after && (p > best || (p == best && i < bi))) {
+          best = p;
+          bi = i;
+        }
+      }
+      if (bi == 0x7fffffff) {
+        exhausted = true;
+        break;
+      }
+      pv = best;
+      pi = bi;
+    }
+    colv[static_cast<int64_t>(b) * N1 + j] = exhausted ? -INFINITY : pv;
+    coli[static_cast<int64_t>(b) * N1 + j] = exhausted ? 0x7fffffff : pi;
+  }
+}
+
+template <int PHASE>
+__global__ __launch_bounds__(256) void k_topk_emit(const float* __restrict__ logS, int64_t B, int M, int N, const float* __restrict__ rowv,
+                                                   const int32_t* __restrict__ rowj, const float* __restrict__ colv, const int32_t* __restrict__ coli,
+                                                   const uint8_t* __restrict__ row_mask, const uint8_t* __restrict__ col_mask, int32_t* __restrict__ counts,
+                                                   const int32_t* __restrict__ offsets, int32_t* __restrict__ out_bij, float* __restrict__ out_score,
+                                                   int mutual) {
+  const int M1 = M + 1, N1 = N + 1;
+  const int64_t rows = B * M;
+  for (int64_t t = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; t < rows; t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t b = t / M;
+    const int i = static_cast<int>(t - b * M);
+    int c = 0;
+    if (!row_mask || row_mask[b * M + i]) {
+      const float* srow = logS + (b * M1 + i) * N1;
+      const float rv = rowv[b * M1 + i], rdust = expf(srow[N]);
+      const int rj = rowj[b * M1 + i];
+      const int64_t o = PHASE ? offsets[t] : 0;
+      for (int j = 0; j < N; ++j) {
+        if (col_mask && !col_mask[b * N + j]) continue;
+        const float p = expf(srow[j]);
+        const float cv = colv[b * N1 + j];
+        const bool from_row = (p > rv || (p == rv && j <= rj)) && p > rdust;
+        const bool from_col = (p > cv || (p == cv && i <= coli[b * N1 + j])) && p > expf(logS[(b * M1 + M) * N1 + j]);
+        if (mutual ? (from_row && from_col) : (from_row || from_col)) {
+          if (PHASE) {
+            out_bij[3 * (o + c) + 0] = static_cast<int32_t>(b);
+            out_bij[3 * (o + c) + 1] = i;
+            out_bij[3 * (o + c) + 2] = j;
+            out_score[o + c] = p;
+          }
+          ++c;
+        }
+      }
+    }
+    if (!PHASE) counts[t] = c;
+  }
+}
+
 // ---- decoder: out[n] = [ x[idx[n][0]] (zeros for the shadow index) , skip[n] ] -------------------------------------------------
 template <typename IdxT>
 __global__ __launch_bounds__(256) void k_upsample_concat(const float* __restrict__ x, int64_t Nx, int C1, const IdxT* __restrict__ idx, int H,
@@ -1722,6 +1833,51 @@ extern "C" int lcr_top1_matching_ex(const float* logS, int64_t B, int M, int N, 
                        counts, offsets, out_bij, out_score, mutual);
   }
   return check_launch("lcr_top1_matching");
+}
+
+extern "C" int lcr_topk_matching_ws_bytes(int64_t B, int M, int N, size_t* bytes) {
+  if (!bytes || B < 1 || M < 1 || N < 1) return LCR_EARG;
+  Carver c(nullptr, ~size_t(0));
+  c.take<float>(B * (M + 1));
+  c.take<int32_t>(B * (M + 1));
+  c.take<float>(B * (N + 1));
+  c.take<int32_t>(B * (N + 1));
+  c.take<int32_t>(B * M + 1);
+  c.take<int32_t>(B * M + 1);
+  c.take<char>(scan_ws_bytes(B * M + 1));
+  *bytes = c.off;
+  return LCR_OK;
+}
+
+// dustbin top-K matching (K >= 1), two-phase like lcr_top1_matching; for K = 1 the rows equal lcr_top1_matching_ex's
+extern "C" int lcr_topk_matching(const float* logS, int64_t B, int M, int N, const uint8_t* row_mask, const uint8_t* col_mask, int K, int mutual,
+                                 int64_t* total, int32_t* out_bij, float* out_score, void* ws, size_t ws_bytes, void* stream) {
+  if (!logS || !ws || B < 1 || M < 1 || N < 1 || K < 1 || (!out_bij && !total)) return LCR_EARG;
+  size_t need = 0;
+  lcr_topk_matching_ws_bytes(B, M, N, &need);
+  if (need > ws_bytes) return LCR_ESPACE;
+  Carver c(ws, ws_bytes);
+  float* rowv = c.take<float>(B * (M + 1));
+  int32_t* rowj = c.take<int32_t>(B * (M + 1));
+  float* colv = c.take<float>(B * (N + 1));
+  int32_t* coli = c.take<int32_t>(B * (N + 1));
+  int32_t* counts = c.take<int32_t>(B * M + 1);
+  int32_t* offsets = c.take<int32_t>(B * M + 1);
+  void* sws = c.take<char>(scan_ws_bytes(B * M + 1));
+  hipStream_t st = ST(stream);
+  if (!out_bij) {
+    const int slices = B >= 64 ? 1 : std::max(1, std::min(32, (M + 1 + 15) / 16));
+    hipLaunchKernelGGL(k_topk_stats, dim3(static_cast<int>(B), slices), dim3(256), 0, st, logS, M, N, K, rowv, rowj, colv, coli);
+    hipLaunchKernelGGL((k_topk_emit<0>), dim3(blocks_for(B * M)), dim3(256), 0, st, logS, B, M, N, rowv, rowj, colv, coli, row_mask, col_mask, counts,
+                       offsets, out_bij, out_score, mutual);
+    hipMemsetAsync(counts + B * M, 0, sizeof(int32_t), st);
+    int rc = exclusive_scan_i32(counts, offsets, B * M + 1, total, sws, st);
+    if (rc) return rc;
+  } else {
+    hipLaunchKernelGGL((k_topk_emit<1>), dim3(blocks_for(B * M)), dim3(256), 0, st, logS, B, M, N, rowv, rowj, colv, coli, row_mask, col_mask, counts,
+                       offsets, out_bij, out_score, mutual);
+  }
+  return check_launch("lcr_topk_matching");
 }
 
 extern "C" int lcr_upsample_concat(const float* x, int64_t Nx, int C1, const void* idx, int idx_is_64, int H, const float* skip, int C2, int64_t N,

@@ -584,27 +584,33 @@ def log_optimal_transport(raw_scores, row_masks, col_masks, alpha, scale=1.0, it
     return S
 
 
-def top1_matching(log_scores, row_masks=None, col_masks=None, mutual=False):
-    """(bij int32 [C,3], scores f32 [C], per-row offsets are internal) — dustbin top-1 matching, row-major order.
-    mutual: keep a pair only if it is the maximum of its row AND of its column (local_global_registration.py:84-85) instead of either.
+def top1_matching(log_scores, row_masks=None, col_masks=None, mutual=False, topk=1):
+    """(bij int32 [C,3], scores f32 [C], per-row offsets are internal) — dustbin top-k matching (k = 1 in the shipped configuration),
+    row-major order.  mutual: keep a pair only if it is kept from its row AND from its column (local_global_registration.py:84-85)
+    instead of either.  topk > 1: the k largest of a row / column, dustbin included, each against the dustbin (:56-82; lcr_topk_matching).
     One host sync for the (data-dependent) number of correspondences."""
     B, M1, N1 = log_scores.shape
     M, N, dev = M1 - 1, N1 - 1, log_scores.device
+    topk = int(topk)
+    assert topk >= 1
     nbytes = ctypes.c_size_t(0)
-    _lib.check(_L().lcr_top1_matching_ws_bytes(B, M, N, ctypes.byref(nbytes)), "lcr_top1_matching_ws_bytes")
+    ws_fn = _L().lcr_top1_matching_ws_bytes if topk == 1 else _L().lcr_topk_matching_ws_bytes
+    _lib.check(ws_fn(B, M, N, ctypes.byref(nbytes)), "lcr_top1_matching_ws_bytes")
     ws = _lib.workspace(nbytes.value, dev)
     rm = row_masks.to(torch.uint8).contiguous() if row_masks is not None else None
     cm = col_masks.to(torch.uint8).contiguous() if col_masks is not None else None
     total = torch.zeros(1, dtype=torch.int64, device=dev)
-    args = (_lib.ptr(log_scores.contiguous()), B, M, N, _lib.ptr(rm), _lib.ptr(cm), int(bool(mutual)))
-    _lib.check(_L().lcr_top1_matching_ex(*args, _lib.ptr(total), None, None, _lib.ptr(ws), ws.numel(), _sp(log_scores)), "lcr_top1_matching")
+    if topk == 1:
+        fn, args = _L().lcr_top1_matching_ex, (_lib.ptr(log_scores.contiguous()), B, M, N, _lib.ptr(rm), _lib.ptr(cm), int(bool(mutual)))
+    else:
+        fn, args = _L().lcr_topk_matching, (_lib.ptr(log_scores.contiguous()), B, M, N, _lib.ptr(rm), _lib.ptr(cm), topk, int(bool(mutual)))
+    _lib.check(fn(*args, _lib.ptr(total), None, None, _lib.ptr(ws), ws.numel(), _sp(log_scores)), "lcr_top1_matching")
     n = int(total.item())
     check_transport_status()
     bij = torch.empty((max(n, 1), 3), dtype=torch.int32, device=dev)
     sc = torch.empty((max(n, 1),), dtype=torch.float32, device=dev)
     if n:
-        _lib.check(_L().lcr_top1_matching_ex(*args, _lib.ptr(total), _lib.ptr(bij), _lib.ptr(sc), _lib.ptr(ws), ws.numel(), _sp(log_scores)),
-                   "lcr_top1_matching")
+        _lib.check(fn(*args, _lib.ptr(total), _lib.ptr(bij), _lib.ptr(sc), _lib.ptr(ws), ws.numel(), _sp(log_scores)), "lcr_top1_matching")
     return bij[:n], sc[:n]
 
 

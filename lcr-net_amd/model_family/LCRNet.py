@@ -128,9 +128,10 @@ class LCRNet(nn.Module):
         self.correspondence_threshold = fm.get("correspondence_threshold", 3)
         self.num_refinement_steps = fm.get("num_refinement_steps", 5)
         self.mutual = bool(fm.get("mutual", False))                  # LocalGlobalRegistration(mutual=...), local_global_registration.py:84-87
-        if fm.get("topk", 1) != 1 or not fm.get("use_dustbin", True) or fm.get("correspondence_limit") is not None:
-            raise NotImplementedError("fine_matching: only topk=1, use_dustbin=True, correspondence_limit=None (the reference's shipped "
-                                      "config_model.py) are built; mutual may be either")
+        self.topk = int(fm.get("topk", 1))                           # LocalGlobalRegistration(k=...), :56-82
+        if self.topk < 1 or not fm.get("use_dustbin", True) or fm.get("correspondence_limit") is not None:
+            raise NotImplementedError("fine_matching: use_dustbin=True and correspondence_limit=None (the reference's shipped config_model.py) "
+                                      "are the only values built; mutual and topk may be anything")
         self.proj_node_overlap_score = nn.Linear(g["output_dim"] * 2, 1)
         self.transformer = ThDRoFormer(g["input_dim"], g["output_dim"], g["hidden_dim"], g["num_heads"], g["num_layers"], g["k"])
         self.kpdecoder = KPDecoder(b["init_dim"], b["group_norm"])
@@ -148,7 +149,7 @@ class LCRNet(nn.Module):
         One host read-back of the per-pair correspondence counts (output shapes) on top of top-1 matching's own."""
         Pn, K = ref_masks.shape
         S = len(patch_off) - 1
-        bij, sc = F.top1_matching(log_scores, ref_masks, src_masks, mutual=self.mutual)
+        bij, sc = F.top1_matching(log_scores, ref_masks, src_masks, mutual=self.mutual, topk=self.topk)
         if bij.shape[0] == 0:
             raise RuntimeError("no dense correspondences (the reference fails here as well)")
         b, i, j = bij[:, 0].long(), bij[:, 1].long(), bij[:, 2].long()

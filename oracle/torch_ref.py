@@ -395,18 +395,17 @@ def _apply(T, p):
     return p @ T[..., :3, :3].transpose(-1, -2) + T[..., None, :3, 3]
 
 
-def local_global_registration(ref_knn_pts, src_knn_pts, ref_masks, src_masks, log_scores, acceptance_radius=0.45, threshold=3, steps=5, mutual=False):
-    """geotransformer/local_global_registration.py:204-246 with k=1, use_dustbin=True, no correspondence limit; mutual as given (:84-87)."""
+def local_global_registration(ref_knn_pts, src_knn_pts, ref_masks, src_masks, log_scores, acceptance_radius=0.45, threshold=3, steps=5, mutual=False,
+                              topk=1):
+    """geotransformer/local_global_registration.py:204-246 with use_dustbin=True, no correspondence limit; mutual (:84-87) and k (:56-82) as
+    given.  Equal values are taken in index order (a stable descending sort; torch.topk leaves it open)."""
     S = torch.exp(log_scores)
     B, M1, N1 = S.shape
-    bi = torch.arange(B)
-    rtop = torch.zeros_like(S)
-    rv, ri = S.max(2)
-    rtop[bi[:, None], torch.arange(M1)[None], ri] = rv
+    ri = torch.sort(S, dim=2, descending=True, stable=True).indices[:, :, :topk]
+    rtop = torch.zeros_like(S).scatter_(2, ri, torch.gather(S, 2, ri))
     ref_c = rtop > S[:, :, -1][:, :, None]
-    stop = torch.zeros_like(S)
-    sv, si = S.max(1)
-    stop[bi[:, None], si, torch.arange(N1)[None]] = sv
+    si = torch.sort(S, dim=1, descending=True, stable=True).indices[:, :topk, :]
+    stop = torch.zeros_like(S).scatter_(1, si, torch.gather(S, 1, si))
     src_c = stop > S[:, -1, :][:, None, :]
     corr = ((ref_c & src_c) if mutual else (ref_c | src_c))[:, :-1, :-1] & (ref_masks[:, :, None] & src_masks[:, None, :])
     S = S[:, :-1, :-1] * corr.float()

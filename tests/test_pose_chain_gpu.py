@@ -245,8 +245,9 @@ def test_patch_transport_on_reference_scores(gold):
 
 
 def test_mutual_matching_branch_vs_reference_module(model):
-    """`fine_matching.mutual = True` (local_global_registration.py:84-87: a pair must be the dustbin-beating maximum of its row AND of its
-    column) — the value of the switch the shipped config does not use, built in round 5 (lcr_top1_matching_ex): correspondences exact,
+    """`fine_matching.mutual = True` (local_global_registration.py:84-87: a pair must be kept from its row AND from its column) and
+    `fine_matching.topk` > 1 (:56-82) — the values the shipped config does not use, built in round 5 (lcr_top1_matching_ex,
+    lcr_topk_matching): correspondences exact,
     scores 1e-6, refined transform 1e-4 against the imported reference module on the well-conditioned synthetic case; and the default
     (either side) still equals the reference's."""
     from make_golden_pose_chain import synthetic_lgr_case
@@ -256,16 +257,39 @@ def test_mutual_matching_branch_vs_reference_module(model):
     assert len(g["mutual_corr_bij"]) < len(g["either_corr_bij"])                      # the switch does something on this input
     was = model.mutual
     try:
-        for mutual, tag in ((True, "mutual_"), (False, "either_")):
-            model.mutual = mutual
+        for mutual, topk, tag in ((True, 1, "mutual_"), (False, 1, "either_"), (False, 2, "either_top2_"), (True, 3, "mutual_top3_")):
+            model.mutual, model.topk = mutual, topk
             with torch.no_grad():
                 rp, sp, sc, T = model._local_global_registration(cu(ref), cu(src), cu(rm), cu(sm), cu(logs))
-                bij, _ = F.top1_matching(cu(logs), cu(rm), cu(sm), mutual=mutual)
+                bij, _ = F.top1_matching(cu(logs), cu(rm), cu(sm), mutual=mutual, topk=topk)
+                if topk == 1:                                            # the K-general kernels at K = 1 give the top-1 kernels' rows
+                    nb = ctypes_topk(F, cu(logs), cu(rm), cu(sm), mutual)
+                    assert torch.equal(nb, bij)
             assert np.array_equal(bij.cpu().numpy().astype(np.int32), g[tag + "corr_bij"])
             assert np.array_equal(rp.cpu().numpy(), g[tag + "ref_corr_points"]) and np.array_equal(sp.cpu().numpy(), g[tag + "src_corr_points"])
             assert np.abs(sc.cpu().numpy() - g[tag + "corr_scores"]).max() < 1e-6
             e_T = np.abs(T.cpu().numpy() - g[tag + "transform"]).max()
-            print("mutual=%s: %d correspondences, T within %.2e of the reference module's" % (mutual, len(sc), e_T))
+            print("mutual=%s k=%d: %d correspondences, T within %.2e of the reference module's" % (mutual, topk, len(sc), e_T))
             assert e_T < TOL
     finally:
-        model.mutual = was
+        model.mutual, model.topk = was, 1
+
+
+def ctypes_topk(F, logs, rm, sm, mutual):
+    """lcr_topk_matching with K = 1 (F.top1_matching routes K = 1 to the top-1 kernels)"""
+    import ctypes
+    from lcrnet_amd import _lib
+    B, M1, N1 = logs.shape
+    nb = ctypes.c_size_t(0)
+    _lib.check(_lib.lib().lcr_topk_matching_ws_bytes(B, M1 - 1, N1 - 1, ctypes.byref(nb)), "ws")
+    ws = torch.empty(nb.value, dtype=torch.uint8, device="cuda")
+    tot = torch.zeros(1, dtype=torch.int64, device="cuda")
+    r8, c8 = rm.to(torch.uint8).contiguous(), sm.to(torch.uint8).contiguous()
+    args = (_lib.ptr(logs.contiguous()), B, M1 - 1, N1 - 1, _lib.ptr(r8), _lib.ptr(c8), 1, int(mutual))
+    sp = _lib.stream_ptr(logs.device)
+    _lib.check(_lib.lib().lcr_topk_matching(*args, _lib.ptr(tot), None, None, _lib.ptr(ws), ws.numel(), sp), "topk")
+    n = int(tot.item())
+    bij = torch.empty((n, 3), dtype=torch.int32, device="cuda")
+    sc = torch.empty((n,), dtype=torch.float32, device="cuda")
+    _lib.check(_lib.lib().lcr_topk_matching(*args, _lib.ptr(tot), _lib.ptr(bij), _lib.ptr(sc), _lib.ptr(ws), ws.numel(), sp), "topk")
+    return bij
