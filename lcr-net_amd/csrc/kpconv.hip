@@ -98,16 +98,32 @@ __global__ __launch_bounds__(KP_WAVES * 64) void k_kpconv_aggregate_vec(const fl
     int n = 0, cnt = 0;
     for (int h0 = 0; h0 < H; h0 += 64) {
       const int h = h0 + lane;
-      int64_t j = Ns;
-      if (h < H) j = static_cast<int64_t>(idx[m * H + h]);
-      const bool ok = j >= 0 && j < Ns;
-      const uint64_t mk = wave_ballot(ok);
-      bool positive = false;
-      if (ok) {
-        const int slot = n + mbcnt_lt(mk);
-        s_rel[w][slot] = make_float4(s_pts[3 * j] - qx, s_pts[3 * j + 1] - qy, s_pts[3 * j + 2] - qz,
-                                     __uint_as_float(OFF32 ? static_cast<uint32_t>(j) * static_cast<uint32_t>(C * 4) : static_cast<uint32_t>(j)));
-        positive = s_pos[j] != 0;
+      bool ok, positive = false;
+      uint64_t mk;
+      if (OFF32 && sizeof(IdxT) == 4) {
+        // 32-bit list building (host-checked: Ns * C * 4 < 2^32 and M * H < 2^30): one unsigned compare for the validity test, every gather
+        // as scalar base + 32-bit byte offset — the 64-bit form below spends ~25 more VALU instructions per chunk on address arithmetic
+        const uint32_t ju = h < H ? static_cast<uint32_t>(reinterpret_cast<const int32_t*>(idx)[static_cast<uint32_t>(m) * static_cast<uint32_t>(H) + static_cast<uint32_t>(h)])
+                                  : static_cast<uint32_t>(Ns);
+        ok = ju < static_cast<uint32_t>(Ns);
+        mk = wave_ballot(ok);
+        if (ok) {
+          const int slot = n + mbcnt_lt(mk);
+          const float* sp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(s_pts) + ju * 12u);
+          s_rel[w][slot] = make_float4(sp[0] - qx, sp[1] - qy, sp[2] - qz, __uint_as_float(ju * static_cast<uint32_t>(C * 4)));
+          positive = s_pos[ju] != 0;
+        }
+      } else {
+        int64_t j = Ns;
+        if (h < H) j = static_cast<int64_t>(idx[m * H + h]);
+        ok = j >= 0 && j < Ns;
+        mk = wave_ballot(ok);
+        if (ok) {
+          const int slot = n + mbcnt_lt(mk);
+          s_rel[w][slot] = make_float4(s_pts[3 * j] - qx, s_pts[3 * j + 1] - qy, s_pts[3 * j + 2] - qz,
+                                       __uint_as_float(OFF32 ? static_cast<uint32_t>(j) * static_cast<uint32_t>(C * 4) : static_cast<uint32_t>(j)));
+          positive = s_pos[j] != 0;
+        }
       }
       n += __popcll(mk);
       cnt += __popcll(wave_ballot(positive));      // scalar popcount of a lane mask instead of a six-step cross-lane sum
@@ -660,7 +676,7 @@ static int launch_aggregate(const float* s_feats, const uint8_t* s_pos, const fl
                             int64_t Ns, int H, int C, const KPoints& kp, float sigma, float* A, float* nn, const int32_t* order, int vf,
                             hipStream_t st) {
   dim3 grid(grid_for_xcd(M, KP_WAVES)), block(KP_WAVES * 64);
-  const bool off32 = Ns * C < (int64_t(1) << 30) && !g_agg_force_off64;          // feature rows addressable with 32-bit byte offsets
+  const bool off32 = Ns * C < (int64_t(1) << 30) && M * H < (int64_t(1) << 30) && !g_agg_force_off64;   // feature rows / index rows addressable with 32-bit byte offsets
 #define LCR_AGG(CC)                                                                                                                          \
   if (off32) LCR_LAUNCH_TIMED((k_kpconv_aggregate_vec<IdxT, CC, true>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order, vf); \
   else LCR_LAUNCH_TIMED((k_kpconv_aggregate_vec<IdxT, CC, false>), grid, block, 0, st, s_feats, s_pos, q_pts, s_pts, idx, M, Ns, H, kp, sigma, A, nn, order, vf);      \
