@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-5 closing job: the profile set and the bench line on the final code, more random parity evidence
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r05
 mkdir -p "$OUT"
 cd "$ROOT"

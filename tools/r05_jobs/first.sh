@@ -4,7 +4,7 @@
 #   2. pair model (configs[4]) kernel trace + MFMA counters at 8 pairs per call  -> r05_pair_model_kernel_summary.md, r05_pmc_mfma_pair.md
 #   3. float-parity fuzz, split form seeds 0..300, fp32 form seeds 300..520      -> r05_fuzz_float_parity.jsonl
 #   4. radius bench baseline (ten searches as single launches)                   -> r05_radius_bench_base.log
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r05
 mkdir -p "$OUT"
 cd "$ROOT"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-5 fuzz campaign over the final kernels (the search kernel's turn was refactored this round, the aggregation got its early exit)
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r05
 mkdir -p "$OUT"
 cd "$ROOT"

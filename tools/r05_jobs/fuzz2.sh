@@ -1,6 +1,6 @@
 #!/bin/bash
 # second fuzz campaign of round 5 (final kernels): longer runs, new seed ranges
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r05
 mkdir -p "$OUT"
 cd "$ROOT"

@@ -1,5 +1,5 @@
 #!/bin/bash
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r05
 mkdir -p "$OUT"
 cd "$ROOT"
