@@ -1629,9 +1629,10 @@ extern "C" int lcr_gemm_f32_strided_batched(const float* A, const float* B, floa
   GemmEpilogue ep{nullptr, nullptr, nullptr, 0, 0, nullptr};
   // K <= 256 (the 128 x 128 x 256 patch products: thousands of two-by-two-tile problems of eight K-steps each): the light form — one
   // register stage, six to eight workgroups per CU — like the un-batched Linears of that depth (LCR_GEMM_BATCH_SHORT=0: the deep-pipeline form)
-  // problems of at least 128 x 128 (the 128 x 128 x 256 patch products of the dense matching: thousands per call): ONE 128 x 128 tile per
-  // workgroup instead of four 64 x 64 ones — half the operand loads per flop; 590 -> 616 pairs/s at 16 pairs per call (LCR_GEMM_BATCH_TILE=64: off)
-  static const int batch_tile = getenv("LCR_GEMM_BATCH_TILE") ? atoi(getenv("LCR_GEMM_BATCH_TILE")) : 128;
+  // LCR_GEMM_BATCH_TILE=128: ONE 128 x 128 tile per problem instead of four 64 x 64 ones for the 128 x 128 x 256 patch products.  Looked like
+  // +4 % pairs/s across two gpurun sessions (590 -> 616), is -3 % in a same-session A/B (648 / 644 vs 632 / 623 pairs/s at 16 pairs per call) and
+  // 1.29 vs 0.96 ms per call alone: off by default, kept as the switch that measured it
+  static const int batch_tile = getenv("LCR_GEMM_BATCH_TILE") ? atoi(getenv("LCR_GEMM_BATCH_TILE")) : 64;
   if (batch_tile == 128 && M >= 128 && N >= 128) return launch_gemm<128, 128, 4, 1, true>(A, B, C, M, N, K, transA, transB, ep, static_cast<hipStream_t>(stream), &bt);
   static const bool batch_short = !(getenv("LCR_GEMM_BATCH_SHORT") && atoi(getenv("LCR_GEMM_BATCH_SHORT")) == 0);
   if (batch_short && K <= 256 && !transA) return launch_gemm<64, 64, 2, 2, true, true>(A, B, C, M, N, K, transA, transB, ep, static_cast<hipStream_t>(stream), &bt);
