@@ -84,7 +84,7 @@ def main():
     for P in args.pairs_per_call:
         workers = args.workers or (2 if P == 1 else 3)
         with PairPipeline(m, neighbor_limits=limits, workers=workers, pairs_per_call=P) as pp:
-            for _ in pp.run(work + work):                          # warm-up: TWO FULL untimed passes — the timed passes then see exactly the stack
+            for _ in pp.run(work * max(2, workers)):               # warm-up: as many FULL untimed passes as workers (at least two) — the timed passes then see exactly the stack
                 pass                                              # shapes the caching allocator already holds blocks for (a warm-up over a prefix, or one
                                                                   # pass only — two workers interleave differently the second time —
                                                                   # left the first timed pass growing the pool: round 3's 305 / 389 pairs/s minima)
