@@ -18,6 +18,27 @@
  *     utils/extensions/cpu/grid_subsampling/grid_subsampling.cpp:20-30);
  *   - return value: 0 ok, -1 bad argument, -2 workspace/output too small, -3 HIP launch error
  *     (text via lcr_last_error()).  Data-dependent conditions are reported through the `status` words.
+ *
+ * Shape domain (what the kernels are built for = every shape of the shipped configuration, experiments/lcrnet/config_model.py:33-43 with
+ * best-model-mixed.tar, and of BASELINE.json's configs; a call outside it returns LCR_EARG with a message, it never computes something else):
+ *   - clouds per call (B): 1..64 for the support grids / radius searches / lcr_precompute_batch (GRID_MAX_B); batches of more scans are
+ *     split by the caller (lcr-net_amd/pipeline.py feeds 8 per call, PairPipeline at most 32 pairs = 64 clouds);
+ *   - neighbour columns per row (`limit`, H): 1..128 for the KPConv aggregation / C_in = 1 KPConv / max-pool (KP_HMAX; the reference's
+ *     calibrated limits are 64..80); the radius search itself accepts any limit >= 1 (balls with more than 512 hits take an exact
+ *     storage-free path) and limit <= 0 = count-only;
+ *   - KPConv feature width (C_in = C_out = mid channels of a ResidualBlock): 32, 64, 128 or 256 (init_dim 64 -> 32..256), 15 kernel points;
+ *     C_in = 1 (encoder1_1) has its own fused kernel with any C_out <= 256;
+ *   - GroupNorm: channels % 4 == 0 and % groups == 0 (32 groups in the reference); segment tables (per scan or per pair) of S <= 256
+ *     segments with S * groups <= 2048;
+ *   - lcr_encoder_forward: exactly the KPEncoder of backbone4.py:11-89 — 4 stages, ConvBlock + 10 ResidualBlocks in that order, any
+ *     init_dim whose block widths fall in the KPConv domain above.  Other depths run block by block through the same building-block
+ *     entries (lcr-net_amd/modules/kpconv/modules.py does that when `native_encoder.eligible` says no);
+ *   - GEMMs: any M; N, K >= 1 (K % 4 == 0 for the vectorised forms, else the generic tile); the split-bf16 form needs K >= 288, K % 32 == 0, N >= 64;
+ *   - attention: head dim 32 (d_model 128 / 4 heads in the reference), <= 64 stacked problems per segmented call; dense form any key count,
+ *     top-k form <= 4096 keys per cloud (the scores of a row live in LDS: 70 KB of the 160 KB of a gfx950 CU — this library targets gfx950 only);
+ *   - retrieval: descriptor width % 4 == 0 (256 in the reference), k <= 128 (50 in the reference), any corpus size that fits HBM;
+ *   - pose tail: <= 4000 coarse nodes per cloud, patches of <= 128 points (+ dustbin: 129 x 129 transport problems; point_limit 128 in the
+ *     reference), 3 x 3 weighted Procrustes.
  */
 #ifndef LCR_HIP_H
 #define LCR_HIP_H
@@ -48,10 +69,10 @@ void lcr_ktimer_kinds(unsigned mask); /* time only the kinds whose bit is set (g
 int lcr_ktimer_read(int kind, int max_records, double* seconds, int64_t* meta);
 /* same, plus the kernel's own begin-to-end duration (what a profiler reports; < 0 where a launch site does not record it) */
 int lcr_ktimer_read2(int kind, int max_records, double* seconds, double* seconds_kernel, int64_t* meta);
-/* Diagnostic: one wavefront spinning for `microseconds` on `stream`.  The runtime deals streams to 4 hardware queues; two busy
+/* One wavefront spinning for `microseconds` on `stream`.  The runtime deals streams to 4 hardware queues; two busy
  * streams on one queue serialise each other.  A short kernel on stream B behind a spin on stream A tells whether A and B share
- * a queue (lcr-net_amd/pipeline.py picks four streams on four queues this way). */
-int lcr_debug_spin(int microseconds, void* stream);
+ * a queue (lcr-net_amd/pipeline.py picks its streams on distinct queues this way).  Test / tuning hooks live in lcr_hip_debug.h. */
+int lcr_stream_spin(int microseconds, void* stream);
 int lcr_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -203,14 +224,8 @@ int lcr_gemm_f32_bsplit(const float* A, const uint16_t* Bs_tiles, float* C, int6
 int lcr_gemm_f32_anorm(const float* A, const float* B, float* C, int64_t M, int N, int K, const float* bias,
                        const double* a_stats, const float* a_gamma, const float* a_beta, int a_groups, float a_eps,
                        float a_slope, const int64_t* seg_len, int S, int groups, double* stats, void* stream);
-/* Tuning hook for tools/gemm_bench.py: 0 = heuristic tile choice, 1..5 = force 128x128 / 128x64 / 128x32 / 64x64 / 64x128. */
-void lcr_gemm_debug_force_tile(int tile);
-/* K-deep problems (A [M,K] x B [K,N], K >= 480) whose 64x64 tiles do not divide evenly over the CUs can run as stream-K:
- * persistent workgroups with equal contiguous (tile, K-step) ranges, partial tiles parked and folded — in ascending workgroup
- * order, by whichever workgroup parks a tile's last piece — without anybody waiting.  Opt-in (+3..7 % on those shapes).
- * Test / tuning hook: -1 = LCR_GEMM_STREAMK (default 0 = off, 1 = heuristic), 0 = never, 2 = whenever the kernel is applicable.
- * The scratch (two 16-KB pieces per workgroup + one counter per tile) is library-owned, one per stream. */
-void lcr_gemm_debug_streamk(int mode);
+/* K-deep problems (A [M,K] x B [K,N], K >= 480) whose 64x64 tiles do not divide evenly over the CUs can run as stream-K (opt-in,
+ * environment LCR_GEMM_STREAMK; scratch library-owned, one per stream; hook: lcr_gemm_debug_streamk in lcr_hip_debug.h). */
 /* Batched C_z[M,N] = A_z^T · B_z with A_z stored [K_z, M] (per-entry K and element offsets, HOST arrays, count <= 64). */
 int lcr_gemm_f32_batched_ta(const float* A, const float* B, float* C, int64_t M, int N, int count, const int* k_host,
                             const int64_t* a_off_host, const int64_t* b_off_host, const int64_t* c_off_host, void* stream);
@@ -292,13 +307,23 @@ typedef struct LcrEncoderW {
   const float *c1_gn_w, *c1_gn_b;
   LcrBlockW blocks[LCR_ENC_BLOCKS];   /* encoder1_2, 2_1, 2_2, 2_3, 3_1, 3_2, 3_3, 4_1, 4_2, 4_3 */
 } LcrEncoderW;
-/* neighbors / subsampling: rows as a radius search emits them — valid entries first, padding (= number of support rows) behind them
- * (LCR_KP_VALID_FIRST of lcr_kpconv_aggregate_ex; environment LCR_KP_VALID_FIRST=0 lifts the requirement). */
+/* neighbors / subsampling: any [n, limit] index rows padded with the number of support rows (padding may sit anywhere in a row). */
 int lcr_encoder_ws_bytes(const LcrEncoderW* W, const int64_t* n_host, int S, size_t* bytes);
 int lcr_encoder_forward(const LcrEncoderW* W, const float* feats0, const float* const* points, const int32_t* const* neighbors,
                         const int32_t* const* subsampling, const int32_t* const* order, const int64_t* const* seg_len, int S,
                         const int64_t* n_host, const int64_t* seg_min_rows_host, const int* limits, float* const* out_feats, void* ws,
                         size_t ws_bytes, void* stream);
+/* Same with flags.  LCR_ENC_LISTS_VALID_FIRST: the caller guarantees that every row of neighbors / subsampling holds its valid entries
+ * first and the padding behind them — what a radius search emits (the reference's radius_neighbors and lcr_radius_search alike); the
+ * KPConv aggregation then stops reading a row at its first chunk with a hole (LCR_KP_VALID_FIRST of lcr_kpconv_aggregate_ex).  With
+ * rows that violate the promise the neighbours behind the first hole are silently ignored, hence opt-in (lcr_encoder_forward = flags 0).
+ * The Python host sets it for data dictionaries built by its own collate (`lists_valid_first`).  Environment LCR_KP_VALID_FIRST=0
+ * ignores the flag (A/B). */
+#define LCR_ENC_LISTS_VALID_FIRST 1u
+int lcr_encoder_forward_ex(const LcrEncoderW* W, const float* feats0, const float* const* points, const int32_t* const* neighbors,
+                           const int32_t* const* subsampling, const int32_t* const* order, const int64_t* const* seg_len, int S,
+                           const int64_t* n_host, const int64_t* seg_min_rows_host, const int* limits, float* const* out_feats,
+                           unsigned flags, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a-7  global descriptor head: F.normalize -> NetVLADLoupe2 -> GatingContext -> F.normalize

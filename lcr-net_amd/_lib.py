@@ -27,7 +27,7 @@ _SIGS = {
     "lcr_precompute_batch_rows": (c_int, [c_vp, c_int, c_vp, c_vp, c_float, c_float, c_float, c_int, c_vp, c_size_t, c_vp, c_size_t, c_vp, c_vp, c_vp]),
     "lcr_radius_query_multi": (c_int, [c_vp, c_int, c_int, c_vp]),
     "lcr_radius_query": (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_i64, c_float, c_int, c_vp, c_vp, c_vp, c_vp]),
-    "lcr_debug_spin": (c_int, [c_int, c_vp]),
+    "lcr_stream_spin": (c_int, [c_int, c_vp]),
     "lcr_radius_query_ordered": (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_i64, c_float, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "lcr_radius_search_ws_bytes": (c_int, [c_i64, c_i64, c_int, c_size_p]),
     "lcr_radius_search": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_float, c_int, c_vp, c_vp, c_vp, c_vp,
@@ -47,6 +47,7 @@ _SIGS = {
     "lcr_ktimer_read2": (c_int, [c_int, c_int, c_vp, c_vp, c_vp]),
     "lcr_encoder_ws_bytes": (c_int, [c_vp, c_vp, c_int, c_size_p]),
     "lcr_encoder_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_size_t, c_vp]),
+    "lcr_encoder_forward_ex": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, ctypes.c_uint, c_vp, c_size_t, c_vp]),
     "lcr_kpconv_aggregate": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_int, c_vp, c_float, c_vp, c_vp, c_vp, c_vp]),
     "lcr_kpconv_fused": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_int, c_vp, c_float, c_vp, c_vp, c_vp, c_vp, c_int,
                                  c_int, c_vp, c_vp, c_vp]),

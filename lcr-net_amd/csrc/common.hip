@@ -298,7 +298,7 @@ __global__ void k_spin(long long ticks) {
   const long long t0 = wall_clock64();
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
-extern "C" int lcr_debug_spin(int microseconds, void* stream) {
+extern "C" int lcr_stream_spin(int microseconds, void* stream) {
   if (microseconds < 0 || microseconds > 100000) return LCR_EARG;
   hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<long long>(microseconds) * 100);
   return hipGetLastError() == hipSuccess ? LCR_OK : LCR_EHIP;

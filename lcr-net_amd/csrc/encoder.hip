@@ -74,7 +74,7 @@ static int unary_raw(const LcrUnaryW& u, const float* x, int64_t n, int cin, int
 }
 
 static int residual_block(const LcrBlockW& b, const float* s_feats, const StageIO& q, const StageIO& sup, const void* idx, int H,
-                          StatsPool& sp, Arena& ws, float* out, hipStream_t s) {
+                          StatsPool& sp, Arena& ws, float* out, unsigned enc_flags, hipStream_t s) {
   const int mid = b.cout / 4, g = sp.groups;
   const int64_t M = q.n, Ns = sup.n;
   int rc;
@@ -101,9 +101,11 @@ static int residual_block(const LcrBlockW& b, const float* s_feats, const StageI
   float* kpo = ws.take<float>(static_cast<size_t>(M) * mid);
   double* stc = sp.take();
   if (!A || !nn || !kpo || !stc) return LCR_ESPACE;
-  // the lists of a data dictionary come from radius searches (the reference's radius_neighbors and ours alike): valid entries first, padding
-  // (= Ns) behind them — the aggregation may stop at the first chunk with a hole (LCR_KP_VALID_FIRST=0: scan every chunk)
-  static const int vf_flag = (getenv("LCR_KP_VALID_FIRST") && atoi(getenv("LCR_KP_VALID_FIRST")) == 0) ? 0 : LCR_KP_VALID_FIRST;
+  // lists that come from a radius search (the reference's radius_neighbors and ours alike) hold their valid entries first, padding (= Ns)
+  // behind them: the CALLER says so with LCR_ENC_LISTS_VALID_FIRST and the aggregation may then stop at the first chunk with a hole.
+  // Without the flag every chunk is scanned (rows with interior padding are legal input).  LCR_KP_VALID_FIRST=0 ignores the flag.
+  static const bool vf_env_off = getenv("LCR_KP_VALID_FIRST") && atoi(getenv("LCR_KP_VALID_FIRST")) == 0;
+  const int vf_flag = ((enc_flags & LCR_ENC_LISTS_VALID_FIRST) && !vf_env_off) ? LCR_KP_VALID_FIRST : 0;
   static const bool fused32 = getenv("LCR_KPCONV_FUSED") != nullptr;       // opt-in, like KPConv.forward_raw (LABNOTES.md §4.2)
   if (fused32 && mid == 32 && sp.S <= 64) {
     if ((rc = TURN(lcr_kpconv_fused(x, pos, q.pts, sup.pts, idx, 0, M, Ns, H, mid, b.kernel_points_host, b.sigma, b.kp_w, b.kp_b, kpo, q.seg, sp.S, g,
@@ -199,6 +201,14 @@ extern "C" int lcr_encoder_forward(const LcrEncoderW* W, const float* feats0, co
                                    const int32_t* const* subsampling, const int32_t* const* order, const int64_t* const* seg_len, int S,
                                    const int64_t* n_host, const int64_t* seg_min_rows_host, const int* limits, float* const* out_feats,
                                    void* ws, size_t ws_bytes, void* stream) {
+  return lcr_encoder_forward_ex(W, feats0, points, neighbors, subsampling, order, seg_len, S, n_host, seg_min_rows_host, limits, out_feats, 0u, ws,
+                                ws_bytes, stream);
+}
+
+extern "C" int lcr_encoder_forward_ex(const LcrEncoderW* W, const float* feats0, const float* const* points, const int32_t* const* neighbors,
+                                      const int32_t* const* subsampling, const int32_t* const* order, const int64_t* const* seg_len, int S,
+                                      const int64_t* n_host, const int64_t* seg_min_rows_host, const int* limits, float* const* out_feats,
+                                      unsigned flags, void* ws, size_t ws_bytes, void* stream) {
   if (!W || !feats0 || !points || !neighbors || !subsampling || !seg_len || !n_host || !limits || !out_feats || !ws || S < 1) {
     set_error("lcr_encoder_forward: bad argument");
     return LCR_EARG;
@@ -253,7 +263,7 @@ extern "C" int lcr_encoder_forward(const LcrEncoderW* W, const float* feats0, co
       if (STAGE_LAST[k] == i) out = out_feats[k];
     if (!out) out = (cur >= ping && cur < ping + pp / sizeof(float)) ? pong : ping;
     Arena scratch{static_cast<char*>(ws), scratch0, ws_bytes};
-    if ((rc = residual_block(W->blocks[i], cur, st[qs], st[ss], idx, H, sp, scratch, out, s))) {
+    if ((rc = residual_block(W->blocks[i], cur, st[qs], st[ss], idx, H, sp, scratch, out, flags, s))) {
       if (rc == LCR_ESPACE) set_error("lcr_encoder_forward: block %d ran out of workspace", i);
       return rc;
     }

@@ -88,8 +88,10 @@ class PrecomputedArena:
         neighbors = [view(lay.off_neighbors[i], tot[i], lay.limits[i], torch.int32, 4) for i in range(S)]
         subsampling = [view(lay.off_subsampling[i], tot[i + 1], lay.limits[i], torch.int32, 4) for i in range(S - 1)]
         upsamp = [view(lay.off_upsampling[i], tot[i], lay.limits[i + 1], torch.int32, 4) for i in range(S - 1)] if self.upsampling else []
+        # lists_valid_first: every row came out of a radius search (valid entries first, padding behind) — the native encoder driver may
+        # then stop reading a row at its first padded chunk (LCR_ENC_LISTS_VALID_FIRST); a hand-built dictionary without the key gets full scans
         return {"order": orders, "points": pts, "lengths": lens, "neighbors": neighbors, "subsampling": subsampling, "upsampling": upsamp,
-                "lengths_host": self.lengths_host, "segment_lengths": lens}
+                "lengths_host": self.lengths_host, "segment_lengths": lens, "lists_valid_first": True}
 
 
 _layout_cache = {}
@@ -218,7 +220,7 @@ def precompute_batch(points, lengths, num_stages, voxel_size, radius, neighbor_l
     upsamp = [upsamp[i][:tot[i]] for i in range(len(upsamp))]
     orders = [orders[i][:tot[i]] for i in range(num_stages)]
     return {"order": orders, "points": pts, "lengths": lens, "neighbors": neighbors, "subsampling": subsampling, "upsampling": upsamp,
-            "lengths_host": lengths_host, "segment_lengths": lens}
+            "lengths_host": lengths_host, "segment_lengths": lens, "lists_valid_first": True}
 
 
 def _merge_samples(data_dicts):

@@ -100,6 +100,9 @@ class _Key:
         return self.split == F.gemm_split_enabled() and len(ts) == len(self.stamps) and all(s.same(t) for s, t in zip(self.stamps, ts))
 
 
+LISTS_VALID_FIRST = 1        # LCR_ENC_LISTS_VALID_FIRST (include/lcr_hip.h)
+
+
 def table_for(enc):
     cached = getattr(enc, "_native_table", None)
     if cached is None or not cached[0].valid(enc):
@@ -161,6 +164,8 @@ def forward(enc, feats, data_dict):
     sg = vp4(*[t.data_ptr() for t in seg])
     of = vp4(*[t.data_ptr() for t in outs])
     f0 = feats.contiguous()
-    _lib.check(L.lcr_encoder_forward(ctypes.byref(tab.w), _lib.ptr(f0), pts, nb, sb, od, sg, nseg, n_host, min_rows, lim, of, _lib.ptr(ws), ws.numel(),
-                                     _lib.stream_ptr(dev)), "lcr_encoder_forward")
+    # rows known to come from a radius search (our collates mark their dictionaries) may be cut at their first padded chunk
+    flags = LISTS_VALID_FIRST if data_dict.get("lists_valid_first") else 0
+    _lib.check(L.lcr_encoder_forward_ex(ctypes.byref(tab.w), _lib.ptr(f0), pts, nb, sb, od, sg, nseg, n_host, min_rows, lim, of, flags, _lib.ptr(ws),
+                                        ws.numel(), _lib.stream_ptr(dev)), "lcr_encoder_forward_ex")
     return outs

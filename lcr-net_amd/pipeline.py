@@ -95,8 +95,8 @@ def _share_queue(a, b, spin_us=400):
         b.synchronize()
         t0, tb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0.record(b)                                                       # b's clock starts before a's spin is queued
-        _lib.check(L.lcr_debug_spin(spin_us, ctypes.c_void_p(a.cuda_stream)), "lcr_debug_spin")
-        _lib.check(L.lcr_debug_spin(1, ctypes.c_void_p(b.cuda_stream)), "lcr_debug_spin")
+        _lib.check(L.lcr_stream_spin(spin_us, ctypes.c_void_p(a.cuda_stream)), "lcr_stream_spin")
+        _lib.check(L.lcr_stream_spin(1, ctypes.c_void_p(b.cuda_stream)), "lcr_stream_spin")
         tb.record(b)
         a.synchronize()
         b.synchronize()
@@ -122,7 +122,7 @@ def distinct_queue_streams(device, n, priority=0, pool=10):
     import ctypes
     from . import _lib
     for c in cand:                                        # first launch on every candidate (code object load, queue creation)
-        _lib.check(_lib.lib().lcr_debug_spin(1, ctypes.c_void_p(c.cuda_stream)), "lcr_debug_spin")
+        _lib.check(_lib.lib().lcr_stream_spin(1, ctypes.c_void_p(c.cuda_stream)), "lcr_stream_spin")
     torch.cuda.synchronize(device)
     chosen = []
     for c in cand:
@@ -515,6 +515,14 @@ class DescriptorPipeline:
                             t.record_stream(es)
             else:
                 arena.out.record_stream(es)                 # every view shares this one allocation
+                if not arena.raw:
+                    # pre-voxelised mode: stage 0 (points[0] / lengths[0]) is NOT a view of `out` but the tensor handed in — for host
+                    # batches a clone made on the producer's stream.  The encoder reads it on `es`, asynchronously: without this the
+                    # block returns to the producer stream's pool when the consumer drops `dd` and a later batch's clone can
+                    # overwrite it under the running encoder (advisor r5).
+                    for t in (arena.points, arena.lengths):
+                        if torch.is_tensor(t) and t.is_cuda:
+                            t.record_stream(es)
             dd = self.finish(arena)                         # tensor views are built here, off the pre-processing thread
             es.wait_event(ev)
             if self.enc_streams is None:

@@ -10,12 +10,15 @@ def test_library_exports_every_declared_symbol():
     import lcrnet_amd._lib as L
     assert os.path.exists(L.LIB_PATH), "build first: python lcr-net_amd/csrc/build.py"
     lib = ctypes.CDLL(L.LIB_PATH)
-    hdr = open(os.path.join(ROOT, "include", "lcr_hip.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = re.findall(r"\b(lcr_[a-z0-9_]+)\s*\(", hdr)
-    assert len(names) >= 8
-    for n in sorted(set(names)):
-        assert hasattr(lib, n), f"{n} declared in include/lcr_hip.h but not exported"
+    for header, least in (("lcr_hip.h", 70), ("lcr_hip_debug.h", 5)):        # the product ABI, and the test / tuning hooks beside it
+        hdr = open(os.path.join(ROOT, "include", header)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        names = re.findall(r"\b(lcr_[a-z0-9_]+)\s*\(", hdr)
+        assert len(set(names)) >= least, (header, len(set(names)))
+        for n in sorted(set(names)):
+            assert hasattr(lib, n), f"{n} declared in include/{header} but not exported"
+        if header == "lcr_hip.h":
+            assert not [n for n in names if "debug" in n], "debug hooks belong in include/lcr_hip_debug.h"
     assert lib.lcr_version() >= 1
 
 

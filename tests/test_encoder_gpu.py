@@ -273,11 +273,17 @@ def test_native_encoder_driver_is_bit_identical_to_the_module_tree(model, monkey
     dd = precompute_batch(pts, lens, NUM_STAGES, VOXEL, RADIUS, LIMITS)
     feats = torch.ones(pts.shape[0], 1, device="cuda")
     enc = model.encoder
-    for variant in ("segments+order", "whole-stack"):
+    for variant in ("segments+order", "whole-stack", "interior-padding"):
         d = dict(dd)
         if variant == "whole-stack":
             d.pop("segment_lengths")
             d.pop("order")
+        if variant == "interior-padding":
+            # a hand-built dictionary: rows reversed (padding FIRST, valid entries behind it) and no `lists_valid_first` promise — the native
+            # driver must then scan every chunk of a row like the module tree does (advisor r5: the stricter contract is opt-in)
+            d.pop("lists_valid_first")
+            d["neighbors"] = [t.flip(1).contiguous() for t in dd["neighbors"]]
+            d["subsampling"] = [t.flip(1).contiguous() for t in dd["subsampling"]]
         monkeypatch.delenv("LCR_NATIVE_ENCODER", raising=False)
         enc.native = True
         with torch.no_grad():

@@ -83,6 +83,9 @@ def test_headline_batch_descriptors_vs_oracle(split):
     _note("headline batch: coarse features [N4,1024], %s" % tag, worst_f, scale_f)
     assert worst_d < 1e-4
     assert worst_f < 1e-4 * max(1.0, scale_f)
+    # north_star names descriptors / poses at 1e-4; the un-normalised coarse features (|x| up to ~80) are held RELATIVE to their magnitude
+    # above and pinned in absolute terms here: measured 1.9e-4 (fp32 re-association through 11 blocks), twice that is the bound
+    assert worst_f < 4e-4, "coarse features: absolute error %.3e (pinned: 1.9e-4 measured at magnitude %.1f)" % (worst_f, scale_f)
 
 
 def test_pair_model_dense_features_vs_reference_goldens():

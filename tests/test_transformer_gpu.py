@@ -70,8 +70,8 @@ def test_pair_model_transformer_and_descriptors():
 @pytest.mark.parametrize("n,kk", [(300, 150), (844, 211), (70, 0), (70, 70), (65, 1), (500, 499), (1300, 400)])
 def test_topk_attention_kernel(n, kk):
     """lcr_attention_topk_f32 (dynamic_attention with k != None, rpetransformer.py:19-39) against an fp64 restatement on the same fp32
-    q / k / v: rows whose kk-th and (kk+1)-th fp64 scores are closer than 1e-5 (either order is a legitimate top-k) are left out of the
-    comparison, every other row within 2e-5; kk = 0 gives zero rows, kk = m the dense soft-max.  Two stacked problems in one launch."""
+    q / k / v: rows whose kk-th and (kk+1)-th fp64 scores are closer than 1e-5 (either order is a legitimate top-k) must equal ONE of the
+    two selections, every other row the oracle's, within 2e-5; kk = 0 gives zero rows, kk = m the dense soft-max.  Two stacked problems in one launch."""
     from lcrnet_amd import functional as F
     g = torch.Generator().manual_seed(n * 7 + kk)
     m2 = max(n // 3, 2)
@@ -80,20 +80,30 @@ def test_topk_attention_kernel(n, kk):
     v = torch.randn(n + m2, 128, generator=g)
     kk2 = min(kk, m2)
     got = F.attention_topk(q.cuda(), k.cuda(), v.cuda(), 4, [n, m2], [n, m2], [kk, kk2]).cpu().double()
-    worst, skipped = 0.0, 0
+    worst, worst_tie, skipped = 0.0, 0.0, 0
     for lo, hi, kx in ((0, n, kk), (n, n + m2, kk2)):
         hq, hk, hv = (t[lo:hi].reshape(hi - lo, 4, 32).permute(1, 0, 2).double() for t in (q, k, v))
         want = torch_ref.topk_attention(hq, hk, hv, kx).permute(1, 0, 2).reshape(hi - lo, 128)
         ok = torch.ones(hi - lo, 4, dtype=torch.bool)
+        err = (got[lo:hi] - want).abs().reshape(hi - lo, 4, 32).amax(-1)
         if 0 < kx < hi - lo:
             sc = torch.einsum("hnd,hmd->hnm", hq, hk) / math.sqrt(32)
-            top = sc.topk(kx + 1, dim=-1).values
+            srt = torch.sort(sc, dim=-1, descending=True, stable=True)
+            top = srt.values
             ok = ((top[..., kx - 1] - top[..., kx]) > 1e-5).permute(1, 0)              # (rows, heads)
-        err = (got[lo:hi] - want).abs().reshape(hi - lo, 4, 32).amax(-1)
+            # the near-tie rows are NOT waved through: the kernel must have produced the OTHER legitimate selection — the kk - 1 clear
+            # winners plus the (kk+1)-th key instead of the kk-th — to the same 2e-5 (explicit criterion instead of a 2 % allowance)
+            for r, h in (~ok).nonzero().tolist():
+                order = torch.cat([srt.indices[h, r, :kx - 1], srt.indices[h, r, kx:kx + 1]])
+                p = torch.softmax(sc[h, r, order], dim=-1)
+                alt = (p[:, None] * hv[h, order]).sum(0)
+                e_alt = float((got[lo + r, 32 * h:32 * h + 32] - alt).abs().max())
+                worst_tie = max(worst_tie, min(float(err[r, h]), e_alt))
         skipped += int((~ok).sum())
         worst = max(worst, float(err[ok].max()) if ok.any() else 0.0)
-    print("topk attention n=%d kk=%d: max err %.2e on the well-separated rows (%d (row, head) pairs left out)" % (n, kk, worst, skipped))
-    assert worst < 2e-5 and skipped <= 0.02 * (n + m2) * 4
+    print("topk attention n=%d kk=%d: max err %.2e on the well-separated rows; %d (row, head) pairs with a k-th gap < 1e-5 match one of the two "
+          "legitimate selections to %.2e" % (n, kk, worst, skipped, worst_tie))
+    assert worst < 2e-5 and worst_tie < 2e-5
 
 
 def test_topk_attention_ties_take_the_lowest_indices():
