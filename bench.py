@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--no-split-ab", action="store_true", help="skip the secondary A/B block with the split-bf16 K-deep GEMMs")
     ap.add_argument("--no-lazy-ab", action="store_true", help="skip the secondary block without the 3 decoder-only upsampling searches")
     ap.add_argument("--no-h2d", action="store_true", help="skip the secondary `with_h2d` measurement (host [N,4] batches uploaded inside the pipeline)")
+    ap.add_argument("--no-blocks", action="store_true", help="skip the secondary blocks for configs[2]-[4] (`pairs`, `retrieval`, `sequence`: tools/bench_blocks.py)")
     ap.add_argument("--no-upsampling", action="store_true", help="skip the 3 decoder-only upsampling searches")
     ap.add_argument("--no-overlap", action="store_true", help="run pre-processing and encoder on one stream (no pipelining)")
     ap.add_argument("--no-thread", action="store_true", help="two streams but a single host thread")
@@ -511,6 +512,17 @@ def main():
                 "over_headline": round(dt / d7, 4), "descriptors_max_abs_diff_vs_headline": float((desc_7 - desc).abs().max()),
                 "what": "same steps with the 7 searches the descriptor path consumes (the 3 decoder-only upsampling lists not built: DescriptorPipeline's "
                         "default for loop detection); NOT the headline, which keeps the reference collate's 10; median of %d blocks" % len(dts)}
+    # ---- secondary, not the headline: BASELINE configs[2]-[4] on this one GPU under the driver's clock — registration
+    # pairs/s at 1 and 16 pairs per call, the retrieval at KITTI-00 / KITTI-00-10 corpus sizes, and a 2 048-frame sequence scans -> rows
+    blocks_cfg = None
+    if secondary and rank == 0 and not args.no_blocks and not (args.no_overlap or args.no_thread):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_blocks
+        torch.cuda.synchronize()
+        blocks_cfg = {"retrieval": bench_blocks.retrieval_block(dev),
+                      "sequence": bench_blocks.sequence_block(model, dev, scans, frames=int(os.environ.get("LCR_BENCH_SEQ_FRAMES", "2048"))),
+                      "pairs": bench_blocks.pairs_block(dev, repeats=int(os.environ.get("LCR_BENCH_PAIR_PASSES", "5")))}
+        torch.cuda.empty_cache()
     final_line = None
     iso = None
     if rank == 0 and not os.environ.get("LCR_BENCH_NO_KTIMER"):
@@ -675,6 +687,9 @@ def main():
             line[split_ab_key] = split_ab
         if lazy is not None:
             line["descriptor_only_7_searches"] = lazy
+        if blocks_cfg is not None:
+            line.update(blocks_cfg)                      # top level: `pairs`, `retrieval`, `sequence` ...
+            roof["other_configs"] = blocks_cfg           # ... and inside `roofline`, which every consumer of the line keeps whole
         if F.gemm_split_enabled():
             line["dtype"] = ("f32 (K-deep GEMMs, K >= 288 and N >= 64: fp32 operands as bf16 x 3 split, 6 of 9 products on the bf16 matrix cores, fp32 "
                              "accumulate — error vs fp64 <= the fp32-MFMA kernel's; every other GEMM, KPConv and attention: fp32 MFMA)")

@@ -65,7 +65,7 @@ const char* lcr_last_error(void);
  * the logged events and returns the number of records of `kind`. */
 void lcr_ktimer_enable(int on);
 void lcr_ktimer_sample(int every);   /* time every n-th instrumented launch of a kind only (default 1 = all) */
-void lcr_ktimer_kinds(unsigned mask); /* time only the kinds whose bit is set (gemm 0, aggregate 1, radius 2, attention 3, fused 4; default all) */
+void lcr_ktimer_kinds(unsigned mask); /* time only the kinds whose bit is set (gemm 0, aggregate 1, radius 2, attention 3, fused 4, sinkhorn 5; default all) */
 int lcr_ktimer_read(int kind, int max_records, double* seconds, int64_t* meta);
 /* same, plus the kernel's own begin-to-end duration (what a profiler reports; < 0 where a launch site does not record it) */
 int lcr_ktimer_read2(int kind, int max_records, double* seconds, double* seconds_kernel, int64_t* meta);

@@ -445,8 +445,8 @@ extern "C" int lcr_attention_f32(const float* q, const float* k, const float* v,
   if (Nq == 0) return LCR_OK;
   const float scale = 1.f / sqrtf(static_cast<float>(head_dim));
   KernelTimerScope timed(KT_ATTENTION, static_cast<hipStream_t>(stream), Nq * Nk, 1, heads, head_dim);
-  hipLaunchKernelGGL(k_attention, dim3(static_cast<int>((Nq + 31) / 32), heads), dim3(64 * AT_SPLIT), 0, static_cast<hipStream_t>(stream), q, k, v, Nq, Nk,
-                     heads, scale, out);
+  LCR_LAUNCH_TIMED(k_attention, dim3(static_cast<int>((Nq + 31) / 32), heads), dim3(64 * AT_SPLIT), 0, static_cast<hipStream_t>(stream), q, k, v, Nq, Nk,
+                   heads, scale, out);
   return check_launch("lcr_attention_f32");
 }
 
@@ -484,7 +484,7 @@ extern "C" int lcr_attention_seg_f32(const float* q, const float* k, const float
   int64_t qk = 0;
   for (int p = 0; p < P; ++p) qk += q_len_host[p] * k_len_host[p];
   KernelTimerScope timed(KT_ATTENTION, static_cast<hipStream_t>(stream), qk, P, heads, head_dim);
-  hipLaunchKernelGGL(k_attention_seg, dim3(static_cast<int>(to), heads), dim3(64 * AT_SPLIT), 0, static_cast<hipStream_t>(stream), q, k, v, seg, heads, scale, out);
+  LCR_LAUNCH_TIMED(k_attention_seg, dim3(static_cast<int>(to), heads), dim3(64 * AT_SPLIT), 0, static_cast<hipStream_t>(stream), q, k, v, seg, heads, scale, out);
   return check_launch("lcr_attention_seg_f32");
 }
 

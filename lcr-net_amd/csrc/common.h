@@ -250,7 +250,7 @@ struct LaunchTurn {
 // ---- opt-in launch timing (bench.py's roofline leg) ------------------------------------------------
 // While enabled (lcr_ktimer_enable), instrumented entry points bracket their launch with HIP events on the launch stream and
 // log (kind, 5 integers of shape metadata); lcr_ktimer_read turns the log into durations.  Off by default: one relaxed load.
-constexpr int KT_GEMM = 0, KT_AGGREGATE = 1, KT_RADIUS = 2, KT_ATTENTION = 3, KT_KPCONV_FUSED = 4;
+constexpr int KT_GEMM = 0, KT_AGGREGATE = 1, KT_RADIUS = 2, KT_ATTENTION = 3, KT_KPCONV_FUSED = 4, KT_SINKHORN = 5, KT_RETRIEVAL = 6;
 struct KernelTimerScope {
   int slot;
   hipStream_t st;

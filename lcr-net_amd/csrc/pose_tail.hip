@@ -1726,6 +1726,9 @@ extern "C" int lcr_log_sinkhorn_ex(float* S, const uint8_t* row_mask, const uint
                                    float* uv_ws, size_t uv_floats, void* stream) {
   if (!S || !row_mask || !col_mask || !uv_ws || B < 1 || M < 1 || N < 1 || iters < 0) return LCR_EARG;
   const size_t mat_bytes = sizeof(float) * (static_cast<size_t>(M + 1) * (N + 1) + 2 * (M + N + 2));   // matrix + u, v, log_mu, log_nu
+  int form_id = 3;
+  lcr_log_sinkhorn_form(B, M, N, &form_id);
+  KernelTimerScope timed(KT_SINKHORN, ST(stream), B, M, N, iters, form_id);      // brackets every launch of the call (bench.py's pair block)
   if (M + 1 <= SKR_LINES && N + 1 <= SKR_LINES) {
     static const bool scaled_on = !(getenv("LCR_SINKHORN_SCALED") && atoi(getenv("LCR_SINKHORN_SCALED")) == 0);
     const bool scaled = scaled_on && M + 1 <= SKS_MAIN + 1 && N + 1 <= SKS_MAIN + 1;

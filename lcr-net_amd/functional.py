@@ -17,7 +17,7 @@ class KernelTimer:
     """Opt-in per-launch timing of lcr_gemm_f32 ("gemm", meta (M,N,K)) and lcr_kpconv_aggregate ("kpconv_aggregate", meta
     (M,Ns,H,C,index bytes)) with HIP events on the launch stream, recorded inside the library (so launches issued by the native
     encoder driver are seen too).  set_timer(t) starts a fresh log, set_timer(None) stops logging, t.summary() synchronises."""
-    KINDS = {"gemm": 0, "kpconv_aggregate": 1, "radius_query": 2, "attention": 3, "kpconv_fused": 4}
+    KINDS = {"gemm": 0, "kpconv_aggregate": 1, "radius_query": 2, "attention": 3, "kpconv_fused": 4, "sinkhorn": 5}
 
     def __init__(self, names):
         self.names = set(names)
@@ -41,7 +41,7 @@ class KernelTimer:
                 ksec = (ctypes.c_double * max(n, 1))()
                 meta = (ctypes.c_int64 * (5 * max(n, 1)))()
                 L.lcr_ktimer_read2(kind, n, ctypes.cast(sec, ctypes.c_void_p), ctypes.cast(ksec, ctypes.c_void_p), ctypes.cast(meta, ctypes.c_void_p))
-                width = 3 if name == "gemm" else 5            # radius_query: (nq_cap, ns_cap, limit, index bytes, B); attention: (sum Nq*Nk, P, heads, head_dim, 0)
+                width = 3 if name == "gemm" else 5            # radius_query: (nq_cap, ns_cap, limit, index bytes, B); attention: (sum Nq*Nk, P, heads, head_dim, 0); sinkhorn: (B, M, N, iters, form)
                 out[name] = [(sec[i], ksec[i] if ksec[i] >= 0 else None, tuple(int(meta[5 * i + k]) for k in range(width))) for i in range(n)]
             self._cache = out
         return self._cache
