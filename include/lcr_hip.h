@@ -367,6 +367,35 @@ int lcr_add_layernorm(const float* a, const float* b, const float* gamma, const 
                       float* y, void* stream);
 int lcr_relu_inplace(float* x, int64_t n, void* stream);
 
+/* The whole ThDRoFormer.forward (thdroformer_linear.py:60-97: position embedding, in_proj, [self, cross] x num_layers, out_proj) as ONE native
+ * call: the host-side sequencer over the entries above (same launches, arguments and order as lcr-net_amd/modules/thdroformer, so the
+ * outputs are bit-identical to the module tree).  Dense attention only (cfg.GAT.k = None, the shipped configuration; the top-k form runs
+ * through the module tree).  Weights are device pointers into the model's own parameters (nn.Linear layout [out,in]).
+ *   points f32[n,3], feats f32[n,d_in]: the rows of all FIRST clouds of the P pairs stacked, then those of all SECOND clouds
+ *   (n = sum lens0 + sum lens1; lens*_host: P entries each, 1 <= P <= 32);
+ *   out f32[n,d_out] (same row order), theta_out f32[n,d_model/2] (the rotary angles, thdroformer_linear.py:94-95). */
+#define LCR_ROFORMER_MAX_BLOCKS 16
+typedef struct LcrLinearW {
+  const float *w, *b;          /* nn.Linear weight [out,in], bias [out] */
+} LcrLinearW;
+typedef struct LcrRoformerLayerW {   /* _TransformerLayer: attention (proj_q/k/v, linear, norm) + output (expand, squeeze, norm) */
+  LcrLinearW   q, k, v, lin;
+  const float *ln1_w, *ln1_b;
+  float        ln1_eps;
+  LcrLinearW   expand, squeeze;
+  const float *ln2_w, *ln2_b;
+  float        ln2_eps;
+} LcrRoformerLayerW;
+typedef struct LcrRoformerW {
+  int        d_in, d_model, d_out, heads, num_blocks;
+  int        block_is_self[LCR_ROFORMER_MAX_BLOCKS];   /* 1 = rotary self layer over both clouds, 0 = sequential cross layer */
+  LcrLinearW emb1, emb2, in_proj, out_proj;
+  LcrRoformerLayerW layers[LCR_ROFORMER_MAX_BLOCKS];
+} LcrRoformerW;
+int lcr_roformer_ws_bytes(const LcrRoformerW* W, int64_t n_rows, size_t* bytes);
+int lcr_roformer_forward(const LcrRoformerW* W, const float* points, const float* feats, const int64_t* lens0_host, const int64_t* lens1_host,
+                         int P, float* out, float* theta_out, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * a-9  descriptor retrieval: exhaustive squared-L2 top-k with the temporal exclusion window — replaces the per-query
  *      faiss IndexIVFFlat(nlist=1) loop of experiments/loop_detection/eval_loop_detection_overlap_dataset.py:183-214.
@@ -441,6 +470,14 @@ int lcr_top1_matching_ex(const float* logS, int64_t B, int M, int N, const uint8
 int lcr_topk_matching_ws_bytes(int64_t B, int M, int N, size_t* bytes);
 int lcr_topk_matching(const float* logS, int64_t B, int M, int N, const uint8_t* row_mask, const uint8_t* col_mask, int K, int mutual,
                       int64_t* total, int32_t* out_bij, float* out_score, void* ws, size_t ws_bytes, void* stream);
+/* Every switch of LocalGlobalRegistration.compute_correspondence_matrix (local_global_registration.py:48-93):
+ *   use_dustbin = 0 (:62-65, :74-77; LCRNet.py:256-257 strips the dustbin first): the K largest are taken over the M x N interior, the selected
+ *     values are scattered into a zero matrix and kept where that exceeds `confidence_threshold` (an unselected entry counts as 0);
+ *   global_scores f32[B] or NULL (use_global_score, :236-237): emitted scores of patch pair b are multiplied by global_scores[b].
+ * logS is the (M+1) x (N+1) transport output in both forms.  use_dustbin = 1, threshold ignored, NULL = lcr_topk_matching. */
+int lcr_topk_matching_ex(const float* logS, int64_t B, int M, int N, const uint8_t* row_mask, const uint8_t* col_mask, int K, int mutual,
+                         int use_dustbin, float confidence_threshold, const float* global_scores, int64_t* total, int32_t* out_bij,
+                         float* out_score, void* ws, size_t ws_bytes, void* stream);
 /* out[n] = [ x[idx[n,0]] (zeros for the shadow index), skip[n] ]  (nearest_upsample + cat, backbone4.py:355-367) */
 int lcr_upsample_concat(const float* x, int64_t Nx, int C1, const void* idx, int idx_is_64, int H, const float* skip, int C2,
                         int64_t N, float* out, void* stream);
@@ -462,6 +499,13 @@ int lcr_lgr_ws_bytes(int64_t n, int H, int S, size_t* bytes);
 int lcr_local_global_registration(const float* src, const float* ref, const float* score, int64_t n, const int32_t* hyp_start, int H,
                                   const int32_t* seg_hyp_start, int S, float radius, int min_count, int steps, float* T_out,
                                   float* hyp_out, int32_t* counts_out, int32_t* best_out, void* ws, size_t ws_bytes, void* stream);
+/* Same with LocalGlobalRegistration(correspondence_limit=L) (:152-160): a pair with more than L correspondences verifies (inlier counts, the
+ * degenerate-branch fit and every refit) on its L highest-scoring ones only — ties at the L-th score in row order — while the hypotheses
+ * still come from all rows of their patch correspondence.  L = 0: no limit (= lcr_local_global_registration).  Same workspace size. */
+int lcr_local_global_registration_ex(const float* src, const float* ref, const float* score, int64_t n, const int32_t* hyp_start, int H,
+                                     const int32_t* seg_hyp_start, int S, float radius, int min_count, int steps, int correspondence_limit,
+                                     float* T_out, float* hyp_out, int32_t* counts_out, int32_t* best_out, void* ws, size_t ws_bytes,
+                                     void* stream);
 /* w_out = score * [ |ref - T src| < radius ], T = T_all[sel ? *sel : 0]  (recompute_correspondence_scores, LGR :127-132) */
 int lcr_inlier_weights(const float* T_all, const int32_t* sel, const float* src, const float* ref, const float* score, int n,
                        float radius, float* w_out, void* stream);

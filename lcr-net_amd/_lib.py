@@ -47,6 +47,8 @@ _SIGS = {
     "lcr_ktimer_read2": (c_int, [c_int, c_int, c_vp, c_vp, c_vp]),
     "lcr_encoder_ws_bytes": (c_int, [c_vp, c_vp, c_int, c_size_p]),
     "lcr_encoder_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_size_t, c_vp]),
+    "lcr_roformer_ws_bytes": (c_int, [c_vp, c_i64, c_size_p]),
+    "lcr_roformer_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_size_t, c_vp]),
     "lcr_encoder_forward_ex": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, ctypes.c_uint, c_vp, c_size_t, c_vp]),
     "lcr_kpconv_aggregate": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_int, c_vp, c_float, c_vp, c_vp, c_vp, c_vp]),
     "lcr_kpconv_fused": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_int, c_vp, c_float, c_vp, c_vp, c_vp, c_vp, c_int,
@@ -87,6 +89,10 @@ _SIGS = {
     "lcr_top1_matching_ex": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "lcr_topk_matching_ws_bytes": (c_int, [c_i64, c_int, c_int, c_size_p]),
     "lcr_topk_matching": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "lcr_topk_matching_ex": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t,
+                                     c_vp]),
+    "lcr_local_global_registration_ex": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_int, c_float, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
+                                                 c_vp, ctypes.c_size_t, c_vp]),
     "lcr_upsample_concat": (c_int, [c_vp, c_i64, c_int, c_vp, c_int, c_int, c_vp, c_int, c_i64, c_vp, c_vp]),
     "lcr_gather_rows": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_vp]),
     "lcr_procrustes_batched": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_float, c_vp, c_vp]),
@@ -98,6 +104,12 @@ _SIGS = {
     "lcr_netvlad_ws_bytes": (c_int, [c_i64, c_int, c_size_p]),
     "lcr_netvlad_forward": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
 }
+
+
+# entry points that synchronise, compute on the host or issue long launch sequences: called with the interpreter lock RELEASED
+_RELEASES_GIL = {"lcr_roformer_forward", "lcr_precompute_batch", "lcr_precompute_batch_rows", "lcr_encoder_forward", "lcr_encoder_forward_ex", "lcr_ktimer_read",
+                 "lcr_ktimer_read2", "lcr_hashmap_order_host", "lcr_netvlad_forward", "lcr_log_sinkhorn", "lcr_log_sinkhorn_ex",
+                 "lcr_local_global_registration", "lcr_local_global_registration_ex", "lcr_retrieval_topk", "lcr_stream_spin"}
 
 
 def build():
@@ -124,6 +136,20 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get("LCR_CTYPES_KEEP_GIL", "1") != "0":
+            # Entry points that only enqueue a few launches (5-10 us) are bound a second time through PyDLL, i.e. called WITHOUT releasing
+            # the interpreter lock: with two host threads each issuing ~1000 such calls per registration pair, the release / re-acquire
+            # around every call turned into a lock hand-off per launch (a futex wake each) and two workers ran SLOWER than one (100 vs
+            # 136 pairs/s at one pair per call, profiles/r06_pair_host_profile.log).  Calls that block or issue long launch sequences
+            # (_RELEASES_GIL) keep releasing it — those are what the pipelines' threads overlap on.
+            K = ctypes.PyDLL(LIB_PATH)
+            for name, (res, args) in _SIGS.items():
+                if name in _RELEASES_GIL or not hasattr(K, name):
+                    continue
+                fn = getattr(K, name)
+                fn.restype = res
+                fn.argtypes = args
+                setattr(L, name, fn)
         _lib = L
     return _lib
 
@@ -140,7 +166,12 @@ def ptr(t):
 
 
 def stream_ptr(device=None):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    """hipStream_t of torch's current stream on `device` as a void pointer.  Straight from the C binding: torch.cuda.current_stream
+    builds a Stream object per call (4.5 us, ~200 calls per registration pair)."""
+    idx = device.index if isinstance(device, torch.device) else None
+    if idx is None:
+        idx = torch.cuda.current_device() if not isinstance(device, int) else device
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(idx))
 
 
 def require_cuda(*tensors):

@@ -12,7 +12,7 @@ def make_cfg():
         "GAT": {"input_dim": 1024, "hidden_dim": 128, "output_dim": 256, "num_heads": 4, "num_layers": 4, "k": None},
         "model": {"num_points_in_patch": 128, "num_sinkhorn_iterations": 100, "ground_truth_matching_radius": 0.45},
         "Vote": {"MAX_TRANSLATE_RANGE": 4.2, "MLPS": [512, 256], "NMS_radius": 2.4},
-        "fine_matching": {"acceptance_radius": 0.45, "mutual": False, "topk": 1, "use_dustbin": True, "correspondence_threshold": 3,
-                          "correspondence_limit": None, "num_refinement_steps": 5},
+        "fine_matching": {"acceptance_radius": 0.45, "mutual": False, "topk": 1, "confidence_threshold": 0, "use_dustbin": True,
+                          "use_global_score": False, "correspondence_threshold": 3, "correspondence_limit": None, "num_refinement_steps": 5},
         "neighbor_limits": [64, 65, 74, 80],     # dataset_loop_detection.py:25,80 (training default)
     }

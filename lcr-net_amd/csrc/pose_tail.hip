@@ -1080,20 +1080,23 @@ __global__ __launch_bounds__(256) void k_top1_emit(const float* __restrict__ log
 // A pair (i, j) is kept from the row side if P[i][j] is among the K largest of row i (over the N + 1 columns, dustbin included) and beats the
 // row's dustbin P[i][N]; from the column side likewise.  "Among the K largest" in the order (value descending, index ascending) — torch.topk
 // leaves the order of equal values open — so the row keeps the K-th element (value, index) and membership is one comparison.
-__global__ __launch_bounds__(256) void k_topk_stats(const float* __restrict__ logS, int M, int N, int K, float* __restrict__ rowv, int32_t* __restrict__ rowj,
-                                                    float* __restrict__ colv, int32_t* __restrict__ coli) {
+// dust = 0 (LocalGlobalRegistration(use_dustbin=False), :62-65 / :74-77 / LCRNet.py:256-257): the dustbin row and column are stripped before the
+// selection — the K largest are taken over the M x N interior only (Mr = M rows, Nr = N columns take part).
+__global__ __launch_bounds__(256) void k_topk_stats(const float* __restrict__ logS, int M, int N, int K, int dust, float* __restrict__ rowv,
+                                                    int32_t* __restrict__ rowj, float* __restrict__ colv, int32_t* __restrict__ coli) {
   const int b = blockIdx.x, slice = blockIdx.y, nslices = gridDim.y;
   const int M1 = M + 1, N1 = N + 1;
+  const int Mr = dust ? M1 : M, Nr = dust ? N1 : N;
   const float* s = logS + static_cast<int64_t>(b) * M1 * N1;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  for (int i = slice * 4 + w; i < M1; i += 4 * nslices) {
+  for (int i = slice * 4 + w; i < Mr; i += 4 * nslices) {
     float pv = INFINITY;                                     // the previous pick: everything is "after" (+inf, -1)
     int pj = -1;
     bool exhausted = false;
     for (int t = 0; t < K; ++t) {
       float best = -INFINITY;
       int bj = 0x7fffffff;
-      for (int j = lane; j < N1; j += 64) {
+      for (int j = lane; j < Nr; j += 64) {
         const float p = expf(s[i * N1 + j]);
         const bool after = p < pv || (p == pv && j > pj);
         if (after && (p > best || (p == best && j < bj))) {
@@ -1122,14 +1125,14 @@ __global__ __launch_bounds__(256) void k_topk_stats(const float* __restrict__ lo
       rowj[static_cast<int64_t>(b) * M1 + i] = exhausted ? 0x7fffffff : pj;
     }
   }
-  for (int j = slice * 256 + threadIdx.x; j < N1; j += 256 * nslices) {
+  for (int j = slice * 256 + threadIdx.x; j < Nr; j += 256 * nslices) {
     float pv = INFINITY;
     int pi = -1;
     bool exhausted = false;
     for (int t = 0; t < K; ++t) {
       float best = -INFINITY;
       int bi = 0x7fffffff;
-      for (int i = 0; i < M1; ++i) {
+      for (int i = 0; i < Mr; ++i) {
         const float p = expf(s[i * N1 + j]);
         const bool after = p < pv || (p == pv && i > pi);
         if (after && (p > best || (p == best && i < bi))) {
@@ -1154,7 +1157,7 @@ __global__ __launch_bounds__(256) void k_topk_emit(const float* __restrict__ log
                                                    const int32_t* __restrict__ rowj, const float* __restrict__ colv, const int32_t* __restrict__ coli,
                                                    const uint8_t* __restrict__ row_mask, const uint8_t* __restrict__ col_mask, int32_t* __restrict__ counts,
                                                    const int32_t* __restrict__ offsets, int32_t* __restrict__ out_bij, float* __restrict__ out_score,
-                                                   int mutual) {
+                                                   int mutual, int dust, float thr, const float* __restrict__ gscore) {
   const int M1 = M + 1, N1 = N + 1;
   const int64_t rows = B * M;
   for (int64_t t = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; t < rows; t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
@@ -1164,20 +1167,24 @@ __global__ __launch_bounds__(256) void k_topk_emit(const float* __restrict__ log
     if (!row_mask || row_mask[b * M + i]) {
       const float* srow = logS + (b * M1 + i) * N1;
       const float rv = rowv[b * M1 + i], rdust = expf(srow[N]);
+      const float gs = gscore ? gscore[b] : 1.f;               // use_global_score: the patch pair's node-level score (:236-237)
       const int rj = rowj[b * M1 + i];
       const int64_t o = PHASE ? offsets[t] : 0;
       for (int j = 0; j < N; ++j) {
         if (col_mask && !col_mask[b * N + j]) continue;
         const float p = expf(srow[j]);
         const float cv = colv[b * N1 + j];
-        const bool from_row = (p > rv || (p == rv && j <= rj)) && p > rdust;
-        const bool from_col = (p > cv || (p == cv && i <= coli[b * N1 + j])) && p > expf(logS[(b * M1 + M) * N1 + j]);
+        const bool top_row = p > rv || (p == rv && j <= rj), top_col = p > cv || (p == cv && i <= coli[b * N1 + j]);
+        // dustbin form: a selected entry must beat its row's / column's dustbin.  Without the dustbin the reference scatters the selected
+        // values into a ZERO matrix and compares that with confidence_threshold (:61-65): an unselected entry counts as 0 (> a negative threshold)
+        const bool from_row = dust ? (top_row && p > rdust) : ((top_row ? p : 0.f) > thr);
+        const bool from_col = dust ? (top_col && p > expf(logS[(b * M1 + M) * N1 + j])) : ((top_col ? p : 0.f) > thr);
         if (mutual ? (from_row && from_col) : (from_row || from_col)) {
           if (PHASE) {
             out_bij[3 * (o + c) + 0] = static_cast<int32_t>(b);
             out_bij[3 * (o + c) + 1] = i;
             out_bij[3 * (o + c) + 2] = j;
-            out_score[o + c] = p;
+            out_score[o + c] = p * gs;
           }
           ++c;
         }
@@ -1473,7 +1480,8 @@ __global__ void k_lgr_seg_rows(const int32_t* __restrict__ hyp_start, const int3
 
 __global__ __launch_bounds__(256) void k_inlier_count_seg(const float* __restrict__ T, const float* __restrict__ src, const float* __restrict__ ref,
                                                           float radius, const int32_t* __restrict__ hyp_start, const int32_t* __restrict__ seg_hyp_start,
-                                                          const int32_t* __restrict__ seg_row_start, int S, int min_count, int32_t* __restrict__ counts) {
+                                                          const int32_t* __restrict__ seg_row_start, int S, int min_count, int32_t* __restrict__ counts,
+                                                          const uint8_t* __restrict__ ver_mask) {
   __shared__ int s_c, s_lo, s_hi;
   const int h = blockIdx.x;
   if (hyp_start[h + 1] - hyp_start[h] < min_count) {       // hypothesis from too few correspondences: never the best
@@ -1495,11 +1503,82 @@ __global__ __launch_bounds__(256) void k_inlier_count_seg(const float* __restric
     const float dx = ref[3 * i] - (t[0] * x + t[1] * y + t[2] * z + t[3]);
     const float dy = ref[3 * i + 1] - (t[4] * x + t[5] * y + t[6] * z + t[7]);
     const float dz = ref[3 * i + 2] - (t[8] * x + t[9] * y + t[10] * z + t[11]);
-    c += sqrtf(dx * dx + dy * dy + dz * dz) < radius ? 1 : 0;
+    c += (sqrtf(dx * dx + dy * dy + dz * dz) < radius && (!ver_mask || ver_mask[i])) ? 1 : 0;     // rows of the verification set only
   }
   atomicAdd(&s_c, c);
   __syncthreads();
   if (threadIdx.x == 0) counts[h] = s_c;
+}
+
+// correspondence_limit (local_global_registration.py:152-160): the VERIFICATION set of a pair = its `limit` highest-scoring correspondences
+// (all of them when it has no more than that); hypotheses still come from all correspondences, inlier counting and the refinement use the
+// verification set only.  One workgroup per pair: 4-pass radix select of the limit-th largest score, ties at the threshold admitted in index
+// order (torch.topk leaves that open).  Writes ver_mask[i] and score_ver[i] = mask ? score : 0 — a zero weight takes a row out of every
+// weighted Procrustes sum exactly, so the set never has to be compacted.
+__global__ __launch_bounds__(256) void k_lgr_topl(const float* __restrict__ score, const int32_t* __restrict__ seg_row_start, int limit,
+                                                  uint8_t* __restrict__ ver_mask, float* __restrict__ score_ver) {
+  __shared__ unsigned s_hist[256];
+  __shared__ unsigned s_prefix, s_need, s_base;
+  __shared__ uint8_t s_flag[256];
+  const int lo = seg_row_start[blockIdx.x], hi = seg_row_start[blockIdx.x + 1];
+  const int n = hi - lo, tid = threadIdx.x;
+  if (n <= limit) {
+    for (int i = lo + tid; i < hi; i += 256) {
+      ver_mask[i] = 1;
+      score_ver[i] = score[i];
+    }
+    return;
+  }
+  auto key_of = [&](int i) {                                  // order-preserving map of a float onto unsigned
+    const unsigned u = __float_as_uint(score[i]);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  };
+  if (tid == 0) {
+    s_prefix = 0;
+    s_need = static_cast<unsigned>(limit);
+  }
+  __syncthreads();
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    s_hist[tid] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix, hmask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
+    for (int i = lo + tid; i < hi; i += 256) {
+      const unsigned k = key_of(i);
+      if ((k & hmask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned need = s_need, acc = 0;
+      int bin = 255;
+      for (; bin > 0; --bin) {                                // from the largest digit down: the bin holding the need-th largest key
+        if (acc + s_hist[bin] >= need) break;
+        acc += s_hist[bin];
+      }
+      s_need = need - acc;
+      s_prefix = prefix | (static_cast<unsigned>(bin) << shift);
+    }
+    __syncthreads();
+  }
+  const unsigned thr = s_prefix;                              // the limit-th largest key; s_need of the keys EQUAL to it are admitted
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int c0 = lo; c0 < hi; c0 += 256) {
+    const int i = c0 + tid;
+    const unsigned k = i < hi ? key_of(i) : 0u;
+    const bool eq = i < hi && k == thr;
+    s_flag[tid] = eq ? 1 : 0;
+    __syncthreads();
+    unsigned rank = s_base;
+    for (int t = 0; t < tid; ++t) rank += s_flag[t];
+    const bool in = i < hi && (k > thr || (eq && rank < s_need));
+    if (i < hi) {
+      ver_mask[i] = in ? 1 : 0;
+      score_ver[i] = in ? score[i] : 0.f;
+    }
+    __syncthreads();
+    if (tid == 255) s_base = rank + s_flag[255];
+    __syncthreads();
+  }
 }
 
 // per pair: the first hypothesis with the most inliers (torch.argmax order), or — when no chunk of the pair reached min_count
@@ -1855,6 +1934,15 @@ extern "C" int lcr_topk_matching_ws_bytes(int64_t B, int M, int N, size_t* bytes
 // dustbin top-K matching (K >= 1), two-phase like lcr_top1_matching; for K = 1 the rows equal lcr_top1_matching_ex's
 extern "C" int lcr_topk_matching(const float* logS, int64_t B, int M, int N, const uint8_t* row_mask, const uint8_t* col_mask, int K, int mutual,
                                  int64_t* total, int32_t* out_bij, float* out_score, void* ws, size_t ws_bytes, void* stream) {
+  return lcr_topk_matching_ex(logS, B, M, N, row_mask, col_mask, K, mutual, 1, 0.f, nullptr, total, out_bij, out_score, ws, ws_bytes, stream);
+}
+
+// every switch of LocalGlobalRegistration.compute_correspondence_matrix (local_global_registration.py:48-93) + use_global_score (:236-237):
+// use_dustbin = 0 takes the K largest over the M x N interior and keeps what exceeds confidence_threshold; global_scores [B] (or NULL)
+// multiplies the emitted scores of patch pair b
+extern "C" int lcr_topk_matching_ex(const float* logS, int64_t B, int M, int N, const uint8_t* row_mask, const uint8_t* col_mask, int K, int mutual,
+                                    int use_dustbin, float confidence_threshold, const float* global_scores, int64_t* total, int32_t* out_bij,
+                                    float* out_score, void* ws, size_t ws_bytes, void* stream) {
   if (!logS || !ws || B < 1 || M < 1 || N < 1 || K < 1 || (!out_bij && !total)) return LCR_EARG;
   size_t need = 0;
   lcr_topk_matching_ws_bytes(B, M, N, &need);
@@ -1868,17 +1956,18 @@ extern "C" int lcr_topk_matching(const float* logS, int64_t B, int M, int N, con
   int32_t* offsets = c.take<int32_t>(B * M + 1);
   void* sws = c.take<char>(scan_ws_bytes(B * M + 1));
   hipStream_t st = ST(stream);
+  const int dust = use_dustbin ? 1 : 0;
   if (!out_bij) {
     const int slices = B >= 64 ? 1 : std::max(1, std::min(32, (M + 1 + 15) / 16));
-    hipLaunchKernelGGL(k_topk_stats, dim3(static_cast<int>(B), slices), dim3(256), 0, st, logS, M, N, K, rowv, rowj, colv, coli);
+    hipLaunchKernelGGL(k_topk_stats, dim3(static_cast<int>(B), slices), dim3(256), 0, st, logS, M, N, K, dust, rowv, rowj, colv, coli);
     hipLaunchKernelGGL((k_topk_emit<0>), dim3(blocks_for(B * M)), dim3(256), 0, st, logS, B, M, N, rowv, rowj, colv, coli, row_mask, col_mask, counts,
-                       offsets, out_bij, out_score, mutual);
+                       offsets, out_bij, out_score, mutual, dust, confidence_threshold, global_scores);
     hipMemsetAsync(counts + B * M, 0, sizeof(int32_t), st);
     int rc = exclusive_scan_i32(counts, offsets, B * M + 1, total, sws, st);
     if (rc) return rc;
   } else {
     hipLaunchKernelGGL((k_topk_emit<1>), dim3(blocks_for(B * M)), dim3(256), 0, st, logS, B, M, N, rowv, rowj, colv, coli, row_mask, col_mask, counts,
-                       offsets, out_bij, out_score, mutual);
+                       offsets, out_bij, out_score, mutual, dust, confidence_threshold, global_scores);
   }
   return check_launch("lcr_topk_matching");
 }
@@ -1945,6 +2034,8 @@ extern "C" int lcr_lgr_ws_bytes(int64_t n, int H, int S, size_t* bytes) {
   c.take<float>(static_cast<size_t>(S) * 16);      // fit over all rows of a pair
   c.take<float>(static_cast<size_t>(S) * 16);      // current transform of a pair
   c.take<float>(static_cast<size_t>(n > 0 ? n : 1));   // current weights
+  c.take<float>(static_cast<size_t>(n > 0 ? n : 1));   // scores of the verification set (correspondence_limit)
+  c.take<uint8_t>(static_cast<size_t>(n > 0 ? n : 1)); // its membership flags
   *bytes = c.off;
   return LCR_OK;
 }
@@ -1952,6 +2043,15 @@ extern "C" int lcr_local_global_registration(const float* src, const float* ref,
                                              const int32_t* seg_hyp_start, int S, float radius, int min_count, int steps, float* T_out /*[S,4,4]*/,
                                              float* hyp_out /*[H,4,4] or NULL*/, int32_t* counts_out /*[H] or NULL*/, int32_t* best_out /*[S] or NULL*/,
                                              void* ws, size_t ws_bytes, void* stream) {
+  return lcr_local_global_registration_ex(src, ref, score, n, hyp_start, H, seg_hyp_start, S, radius, min_count, steps, 0, T_out, hyp_out, counts_out,
+                                          best_out, ws, ws_bytes, stream);
+}
+// correspondence_limit > 0: the per-pair verification set of local_global_registration.py:152-160 (k_lgr_topl); 0 = every correspondence
+extern "C" int lcr_local_global_registration_ex(const float* src, const float* ref, const float* score, int64_t n, const int32_t* hyp_start, int H,
+                                                const int32_t* seg_hyp_start, int S, float radius, int min_count, int steps, int correspondence_limit,
+                                                float* T_out, float* hyp_out, int32_t* counts_out, int32_t* best_out, void* ws, size_t ws_bytes,
+                                                void* stream) {
+  if (correspondence_limit < 0) return LCR_EARG;
   if (!src || !ref || !score || !hyp_start || !seg_hyp_start || !T_out || !ws || n < 1 || H < 1 || S < 1 || steps < 1 || n > 2147483647) {
     set_error("lcr_local_global_registration: bad argument");
     return LCR_EARG;
@@ -1966,15 +2066,24 @@ extern "C" int lcr_local_global_registration(const float* src, const float* ref,
   float* T_rows = c.take<float>(static_cast<size_t>(S) * 16);
   float* T_cur = c.take<float>(static_cast<size_t>(S) * 16);
   float* cur = c.take<float>(static_cast<size_t>(n));
+  float* score_ver = c.take<float>(static_cast<size_t>(n));
+  uint8_t* ver_mask = c.take<uint8_t>(static_cast<size_t>(n));
   hipStream_t st = ST(stream);
   const int ni = static_cast<int>(n);
   hipLaunchKernelGGL(k_lgr_seg_rows, dim3(1), dim3(64), 0, st, hyp_start, seg_hyp_start, S, seg_rows);
-  hipLaunchKernelGGL(k_procrustes, dim3(H), dim3(64), 0, st, src, ref, score, hyp_start, 1e-5f, hyp);
-  hipLaunchKernelGGL(k_procrustes, dim3(S), dim3(64), 0, st, src, ref, score, seg_rows, 1e-5f, T_rows);
-  hipLaunchKernelGGL(k_inlier_count_seg, dim3(H), dim3(256), 0, st, hyp, src, ref, radius, hyp_start, seg_hyp_start, seg_rows, S, min_count, counts);
+  const float* vscore = score;                     // scores of the verification set (zero outside it)
+  const uint8_t* vmask = nullptr;
+  if (correspondence_limit > 0) {
+    hipLaunchKernelGGL(k_lgr_topl, dim3(S), dim3(256), 0, st, score, seg_rows, correspondence_limit, ver_mask, score_ver);
+    vscore = score_ver;
+    vmask = ver_mask;
+  }
+  hipLaunchKernelGGL(k_procrustes, dim3(H), dim3(64), 0, st, src, ref, score, hyp_start, 1e-5f, hyp);        // hypotheses: ALL correspondences (:175-178)
+  hipLaunchKernelGGL(k_procrustes, dim3(S), dim3(64), 0, st, src, ref, vscore, seg_rows, 1e-5f, T_rows);     // degenerate branch (:186-190)
+  hipLaunchKernelGGL(k_inlier_count_seg, dim3(H), dim3(256), 0, st, hyp, src, ref, radius, hyp_start, seg_hyp_start, seg_rows, S, min_count, counts, vmask);
   hipLaunchKernelGGL(k_lgr_select, dim3(S), dim3(64), 0, st, hyp, counts, seg_hyp_start, T_rows, T_cur, best_out);
   for (int it = 0; it < steps; ++it) {
-    hipLaunchKernelGGL(k_inlier_weights_seg, dim3(blocks_for(n)), dim3(256), 0, st, T_cur, seg_rows, S, src, ref, score, ni, radius, cur);
+    hipLaunchKernelGGL(k_inlier_weights_seg, dim3(blocks_for(n)), dim3(256), 0, st, T_cur, seg_rows, S, src, ref, vscore, ni, radius, cur);
     hipLaunchKernelGGL(k_procrustes, dim3(S), dim3(64), 0, st, src, ref, cur, seg_rows, 1e-5f, it + 1 == steps ? T_out : T_cur);
   }
   if (hyp_out) hipMemcpyAsync(hyp_out, hyp, sizeof(float) * 16 * H, hipMemcpyDeviceToDevice, st);

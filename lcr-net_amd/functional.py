@@ -65,8 +65,23 @@ def _timed(name, fn, meta=None):
 def _seg(seg_len, n, device):
     """GroupNorm segment lengths: None = the reference's behaviour (one segment = the whole stack)."""
     if seg_len is None:
-        return torch.tensor([n], dtype=torch.int64, device=device)
+        # a fill launch, NOT torch.tensor([n], device=...): that is a pageable host-to-device copy, after which torch synchronises the
+        # stream — 25 pipeline drains per registration pair (profiles/r06_pair_host_profile.log)
+        return torch.full((1,), int(n), dtype=torch.int64, device=device)
     return seg_len
+
+
+def host_values(values, dtype, device):
+    """A small host list as a device tensor without draining the stream: staged in pinned memory (torch's caching host allocator) and
+    copied asynchronously on the current stream."""
+    return torch.tensor(values, dtype=dtype).pin_memory().to(device, non_blocking=True)
+
+
+def host_tensor(t, device):
+    """same for a host tensor / numpy array"""
+    if not torch.is_tensor(t):
+        t = torch.from_numpy(t)
+    return t.pin_memory().to(device, non_blocking=True)
 
 
 def _idx_args(idx):
@@ -584,23 +599,30 @@ def log_optimal_transport(raw_scores, row_masks, col_masks, alpha, scale=1.0, it
     return S
 
 
-def top1_matching(log_scores, row_masks=None, col_masks=None, mutual=False, topk=1):
+def top1_matching(log_scores, row_masks=None, col_masks=None, mutual=False, topk=1, use_dustbin=True, confidence_threshold=0.0,
+                  global_scores=None):
     """(bij int32 [C,3], scores f32 [C], per-row offsets are internal) — dustbin top-k matching (k = 1 in the shipped configuration),
     row-major order.  mutual: keep a pair only if it is kept from its row AND from its column (local_global_registration.py:84-85)
     instead of either.  topk > 1: the k largest of a row / column, dustbin included, each against the dustbin (:56-82; lcr_topk_matching).
-    One host sync for the (data-dependent) number of correspondences."""
+    use_dustbin=False: selection over the interior, kept where the selected value exceeds confidence_threshold (:62-65); global_scores [B]:
+    use_global_score (:236-237) — both through lcr_topk_matching_ex.  One host sync for the (data-dependent) number of correspondences."""
     B, M1, N1 = log_scores.shape
     M, N, dev = M1 - 1, N1 - 1, log_scores.device
     topk = int(topk)
     assert topk >= 1
     nbytes = ctypes.c_size_t(0)
-    ws_fn = _L().lcr_top1_matching_ws_bytes if topk == 1 else _L().lcr_topk_matching_ws_bytes
+    ws_fn = _L().lcr_top1_matching_ws_bytes if (topk == 1 and use_dustbin and global_scores is None) else _L().lcr_topk_matching_ws_bytes
     _lib.check(ws_fn(B, M, N, ctypes.byref(nbytes)), "lcr_top1_matching_ws_bytes")
     ws = _lib.workspace(nbytes.value, dev)
     rm = row_masks.to(torch.uint8).contiguous() if row_masks is not None else None
     cm = col_masks.to(torch.uint8).contiguous() if col_masks is not None else None
     total = torch.zeros(1, dtype=torch.int64, device=dev)
-    if topk == 1:
+    if not use_dustbin or global_scores is not None:
+        gs = global_scores.float().contiguous() if global_scores is not None else None
+        assert gs is None or gs.numel() == B
+        fn, args = _L().lcr_topk_matching_ex, (_lib.ptr(log_scores.contiguous()), B, M, N, _lib.ptr(rm), _lib.ptr(cm), topk, int(bool(mutual)),
+                                               int(bool(use_dustbin)), float(confidence_threshold), _lib.ptr(gs))
+    elif topk == 1:
         fn, args = _L().lcr_top1_matching_ex, (_lib.ptr(log_scores.contiguous()), B, M, N, _lib.ptr(rm), _lib.ptr(cm), int(bool(mutual)))
     else:
         fn, args = _L().lcr_topk_matching, (_lib.ptr(log_scores.contiguous()), B, M, N, _lib.ptr(rm), _lib.ptr(cm), topk, int(bool(mutual)))
@@ -647,7 +669,7 @@ def procrustes(src, ref, w, start=None):
     """Batched weighted Procrustes: problems = ranges [start[p], start[p+1]) (int32 device) or one problem over all rows."""
     dev = src.device
     if start is None:
-        start = torch.tensor([0, src.shape[0]], dtype=torch.int32, device=dev)
+        start = host_values([0, src.shape[0]], torch.int32, dev)
     P = start.numel() - 1
     T = torch.empty((P, 4, 4), dtype=torch.float32, device=dev)
     _lib.check(_L().lcr_procrustes_batched(_lib.ptr(src.contiguous()), _lib.ptr(ref.contiguous()), _lib.ptr(w.contiguous()), _lib.ptr(start), P, 1e-5,
@@ -664,10 +686,11 @@ def inlier_count(T, src, ref, radius, start=None, min_count=0):
     return counts, best
 
 
-def local_global_registration(src, ref, score, hyp_start, seg_hyp_start, radius, min_count, steps, want_details=False):
+def local_global_registration(src, ref, score, hyp_start, seg_hyp_start, radius, min_count, steps, want_details=False, correspondence_limit=None):
     """local_to_global_registration (local_global_registration.py:134-201) for S pairs in one native call: correspondences stacked
     pair-major, hyp_start int32 [H+1] (one chunk per patch correspondence), seg_hyp_start int32 [S+1] (the chunks of every pair)
-    -> T [S,4,4] (and, with want_details, the hypotheses [H,4,4], their inlier counts [H] and the winner per pair [S])."""
+    -> T [S,4,4] (and, with want_details, the hypotheses [H,4,4], their inlier counts [H] and the winner per pair [S]).
+    correspondence_limit (:152-160): a pair with more correspondences verifies and refits on its highest-scoring `limit` ones only."""
     dev = src.device
     n, H, S = src.shape[0], hyp_start.numel() - 1, seg_hyp_start.numel() - 1
     nbytes = ctypes.c_size_t(0)
@@ -677,9 +700,10 @@ def local_global_registration(src, ref, score, hyp_start, seg_hyp_start, radius,
     hyp = torch.empty((H, 4, 4), dtype=torch.float32, device=dev) if want_details else None
     counts = torch.empty((H,), dtype=torch.int32, device=dev) if want_details else None
     best = torch.empty((S,), dtype=torch.int32, device=dev) if want_details else None
-    _lib.check(_L().lcr_local_global_registration(_lib.ptr(src.contiguous()), _lib.ptr(ref.contiguous()), _lib.ptr(score.contiguous()), n,
-                                                  _lib.ptr(hyp_start.contiguous()), H, _lib.ptr(seg_hyp_start.contiguous()), S, float(radius), int(min_count),
-                                                  int(steps), _lib.ptr(T), _lib.ptr(hyp), _lib.ptr(counts), _lib.ptr(best), _lib.ptr(ws), ws.numel(), _sp(src)),
+    _lib.check(_L().lcr_local_global_registration_ex(_lib.ptr(src.contiguous()), _lib.ptr(ref.contiguous()), _lib.ptr(score.contiguous()), n,
+                                                     _lib.ptr(hyp_start.contiguous()), H, _lib.ptr(seg_hyp_start.contiguous()), S, float(radius),
+                                                     int(min_count), int(steps), int(correspondence_limit or 0), _lib.ptr(T), _lib.ptr(hyp),
+                                                     _lib.ptr(counts), _lib.ptr(best), _lib.ptr(ws), ws.numel(), _sp(src)),
                "lcr_local_global_registration")
     return (T, hyp, counts, best) if want_details else T
 

@@ -129,9 +129,13 @@ class LCRNet(nn.Module):
         self.num_refinement_steps = fm.get("num_refinement_steps", 5)
         self.mutual = bool(fm.get("mutual", False))                  # LocalGlobalRegistration(mutual=...), local_global_registration.py:84-87
         self.topk = int(fm.get("topk", 1))                           # LocalGlobalRegistration(k=...), :56-82
-        if self.topk < 1 or not fm.get("use_dustbin", True) or fm.get("correspondence_limit") is not None:
-            raise NotImplementedError("fine_matching: use_dustbin=True and correspondence_limit=None (the reference's shipped config_model.py) "
-                                      "are the only values built; mutual and topk may be anything")
+        # the switches the shipped config_model.py:85-93 leaves off, all built (lcr_topk_matching_ex / lcr_local_global_registration_ex)
+        self.use_dustbin = bool(fm.get("use_dustbin", True))         # :62-65, :74-77, LCRNet.py:256-257
+        self.confidence_threshold = float(fm.get("confidence_threshold", 0.0))
+        self.use_global_score = bool(fm.get("use_global_score", False))   # :236-237
+        self.correspondence_limit = fm.get("correspondence_limit")   # :152-160
+        if self.topk < 1 or (self.correspondence_limit is not None and int(self.correspondence_limit) < 1):
+            raise ValueError("fine_matching: topk and correspondence_limit must be positive")
         self.proj_node_overlap_score = nn.Linear(g["output_dim"] * 2, 1)
         self.transformer = ThDRoFormer(g["input_dim"], g["output_dim"], g["hidden_dim"], g["num_heads"], g["num_layers"], g["k"])
         self.kpdecoder = KPDecoder(b["init_dim"], b["group_norm"])
@@ -141,7 +145,7 @@ class LCRNet(nn.Module):
             self.netvlad = NetVLADLoupe2(feature_size=1024, cluster_size=64, output_dim=256, gating=True, add_norm=True, is_training=False)
 
     # ---- LocalGlobalRegistration (geotransformer/local_global_registration.py:134-246; k=1, dustbin; mutual from the config) --------
-    def _local_global_registration_group(self, ref_knn_points, src_knn_points, ref_masks, src_masks, log_scores, patch_off):
+    def _local_global_registration_group(self, ref_knn_points, src_knn_points, ref_masks, src_masks, log_scores, patch_off, global_scores=None):
         """The registration tail of S pairs at once.  Patch correspondences of all pairs are stacked (pair s owns patches
         [patch_off[s], patch_off[s+1])): ONE dustbin top-1 matching over all patches, the matched points gathered once, and the
         hypothesis / inlier-count / refit sequence as one native call whose launches do not depend on S (`lcr_local_global_registration`:
@@ -149,7 +153,8 @@ class LCRNet(nn.Module):
         One host read-back of the per-pair correspondence counts (output shapes) on top of top-1 matching's own."""
         Pn, K = ref_masks.shape
         S = len(patch_off) - 1
-        bij, sc = F.top1_matching(log_scores, ref_masks, src_masks, mutual=self.mutual, topk=self.topk)
+        bij, sc = F.top1_matching(log_scores, ref_masks, src_masks, mutual=self.mutual, topk=self.topk, use_dustbin=self.use_dustbin,
+                                  confidence_threshold=self.confidence_threshold, global_scores=global_scores if self.use_global_score else None)
         if bij.shape[0] == 0:
             raise RuntimeError("no dense correspondences (the reference fails here as well)")
         b, i, j = bij[:, 0].long(), bij[:, 1].long(), bij[:, 2].long()
@@ -157,15 +162,17 @@ class LCRNet(nn.Module):
         sp = F.gather_rows(src_knn_points.reshape(-1, 3), b * K + j)
         start = torch.zeros(Pn + 1, dtype=torch.int32, device=rp.device)
         start[1:] = torch.cumsum(torch.bincount(b, minlength=Pn), 0).int()           # rows are patch-major: chunk p = [start[p], start[p+1])
-        seg = torch.tensor(list(patch_off), dtype=torch.int32, device=rp.device)
+        seg = F.host_values(list(patch_off), torch.int32, rp.device)                 # pinned + asynchronous: no stream drain
         rows = start[seg.long()].tolist()                                             # host sync: first correspondence row of every pair
         if any(rows[s + 1] == rows[s] for s in range(S)):
             raise RuntimeError("no dense correspondences (the reference fails here as well)")
-        T = F.local_global_registration(sp, rp, sc, start, seg, self.acceptance_radius, self.correspondence_threshold, self.num_refinement_steps)
+        T = F.local_global_registration(sp, rp, sc, start, seg, self.acceptance_radius, self.correspondence_threshold, self.num_refinement_steps,
+                                        correspondence_limit=self.correspondence_limit)
         return [(rp[rows[s]:rows[s + 1]], sp[rows[s]:rows[s + 1]], sc[rows[s]:rows[s + 1]], T[s]) for s in range(S)]
 
-    def _local_global_registration(self, ref_knn_points, src_knn_points, ref_masks, src_masks, log_scores):
-        return self._local_global_registration_group(ref_knn_points, src_knn_points, ref_masks, src_masks, log_scores, [0, ref_masks.shape[0]])[0]
+    def _local_global_registration(self, ref_knn_points, src_knn_points, ref_masks, src_masks, log_scores, global_scores=None):
+        return self._local_global_registration_group(ref_knn_points, src_knn_points, ref_masks, src_masks, log_scores, [0, ref_masks.shape[0]],
+                                                     global_scores)[0]
 
     def forward(self, data_dict, pose=True):
         """Pair stack [pos(ref), anc(src)] (data.py:110-113) -> the reference's output_dict (LCRNet.py:274-321).  GroupNorm
@@ -215,8 +222,8 @@ class LCRNet(nn.Module):
             emb = [(t0, t1)]
         else:
             # rows of all first clouds / all second clouds, stacked: every Linear and LayerNorm of the transformer runs once
-            idx0 = torch.cat([torch.arange(off_c[2 * p], off_c[2 * p + 1]) for p in range(P)]).to(feats_c.device, non_blocking=True)
-            idx1 = torch.cat([torch.arange(off_c[2 * p + 1], off_c[2 * p + 2]) for p in range(P)]).to(feats_c.device, non_blocking=True)
+            idx0 = F.host_tensor(torch.cat([torch.arange(off_c[2 * p], off_c[2 * p + 1]) for p in range(P)]), feats_c.device)
+            idx1 = F.host_tensor(torch.cat([torch.arange(off_c[2 * p + 1], off_c[2 * p + 2]) for p in range(P)]), feats_c.device)
             e0, e1, t0, t1 = self.transformer(points_c[idx0], points_c[idx1], feats_c[idx0], feats_c[idx1], pos_lens, anc_lens, return_pos_emb=True)
             enhanced = torch.empty((n_c, e0.shape[1]), dtype=e0.dtype, device=e0.device)
             enhanced[idx0] = e0
@@ -308,9 +315,9 @@ class LCRNet(nn.Module):
         dst = (cloud >> 1) * np.where(side == 0, Mx, Nx) + local                      # row in the flattened (P * Mx) / (P * Nx) batch
         n_f = np.asarray(off_f[1:]) - np.asarray(off_f[:-1])
         host = np.stack([dst, np.asarray(off_f[:-1])[cloud], n_f[cloud], side]).astype(np.int64)
-        tab = torch.from_numpy(host).to(dev, non_blocking=True)
-        rows_pos = torch.from_numpy(np.nonzero(side == 0)[0]).to(dev, non_blocking=True)
-        rows_anc = torch.from_numpy(np.nonzero(side == 1)[0]).to(dev, non_blocking=True)
+        tab = F.host_tensor(host, dev)
+        rows_pos = F.host_tensor(np.nonzero(side == 0)[0], dev)
+        rows_anc = F.host_tensor(np.nonzero(side == 1)[0], dev)
         fp = torch.zeros((P * Mx, fc.shape[1]), dtype=fc.dtype, device=dev)
         fa = torch.zeros((P * Nx, fc.shape[1]), dtype=fc.dtype, device=dev)
         rm = torch.zeros((P * Mx,), dtype=torch.bool, device=dev)
@@ -331,8 +338,8 @@ class LCRNet(nn.Module):
             q_off.append(q_off[-1] + x)
         # patch point indices of the matched nodes as rows of the WHOLE stack (pad = n_all), every pair and side in one pass
         knn_g = torch.where(knn_all == tab[2][:, None], torch.full_like(knn_all, n_all), knn_all + tab[1][:, None])
-        off_even = torch.tensor([off_m[2 * p] - off_m[0] for p in range(P)], dtype=torch.int64).to(dev, non_blocking=True)
-        off_odd = torch.tensor([off_m[2 * p + 1] - off_m[0] for p in range(P)], dtype=torch.int64).to(dev, non_blocking=True)
+        off_even = F.host_values([off_m[2 * p] - off_m[0] for p in range(P)], torch.int64, dev)
+        off_odd = F.host_values([off_m[2 * p + 1] - off_m[0] for p in range(P)], torch.int64, dev)
         gi, gj = nb[:, 1] + off_even[nb[:, 0]], nb[:, 2] + off_odd[nb[:, 0]]
         pk_g, ak_g, pkm, akm = knn_g[gi], knn_g[gj], km_all[gi], km_all[gj]
         node_idx = [(nb[q_off[p]:q_off[p + 1], 1], nb[q_off[p]:q_off[p + 1], 2]) for p in range(P)]
@@ -341,7 +348,7 @@ class LCRNet(nn.Module):
         pkf, akf = F.gather_rows(feats_f, pk_g), F.gather_rows(feats_f, ak_g)
         ms = F.log_optimal_transport(F.bmm_nt(pkf, akf), pkm, akm, self.optimal_transport.alpha,
                                      scale=1.0 / feats_f.shape[1] ** 0.5, iters=self.optimal_transport.num_iterations)
-        lgr = self._local_global_registration_group(pkp, akp, pkm, akm, ms, q_off)      # all pairs: one matching, one registration sequence
+        lgr = self._local_global_registration_group(pkp, akp, pkm, akm, ms, q_off, nscore)      # all pairs: one matching, one registration sequence
         for p in range(P):
             q = slice(q_off[p], q_off[p + 1])
             c = 2 * p
@@ -377,7 +384,7 @@ class LCRNet(nn.Module):
         pkf, akf = F.gather_rows(pos_ff, pk), F.gather_rows(anc_ff, ak)
         ms = F.log_optimal_transport(F.bmm_nt(pkf, akf), pkm, akm, self.optimal_transport.alpha,
                                      scale=1.0 / pos_ff.shape[1] ** 0.5, iters=self.optimal_transport.num_iterations)
-        rp, sp, sc, T = self._local_global_registration(pkp, akp, pkm, akm, ms)
+        rp, sp, sc, T = self._local_global_registration(pkp, akp, pkm, akm, ms, node_corr_scores)
         out.update({
             "pos_points_c": pos_nodes, "anc_points_c": anc_nodes, "pos_feats_c": pos_fc, "anc_feats_c": anc_fc,
             "pos_points_f": pos_f, "anc_points_f": anc_f,

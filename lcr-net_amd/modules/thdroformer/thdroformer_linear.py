@@ -122,6 +122,19 @@ class ThDRoFormer(nn.Module):
         self.in_proj = nn.Linear(input_dim, hidden_dim)
         self.transformer = RPEConditionalTransformer(["self", "cross"] * num_layers, hidden_dim, num_heads, k=k)
         self.out_proj = nn.Linear(hidden_dim, output_dim)
+        # forward through lcr_roformer_forward (one native call, csrc/roformer.hip) when the configuration allows it (dense attention);
+        # LCR_NATIVE_ROFORMER=0: the module tree below (bit-identical)
+        import os
+        self.native = os.environ.get("LCR_NATIVE_ROFORMER", "1") != "0"
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop("_native_table", None)        # raw device pointers: every .to() / .cuda() replaces the tensors
+        return super()._apply(fn, *args, **kwargs)
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop("_native_table", None)
+        return d
 
     def forward(self, ref_points, src_points, ref_feats, src_feats, ref_lens=None, src_lens=None, return_pos_emb=False):
         """(N,3), (M,3), (N,C), (M,C)  [a leading batch dim of 1 as in the reference is accepted] -> (N,out), (M,out).
@@ -132,6 +145,15 @@ class ThDRoFormer(nn.Module):
             ref_points, src_points, ref_feats, src_feats = ref_points[0], src_points[0], ref_feats[0], src_feats[0]
         import torch
         n0 = ref_points.shape[0]
+        from ... import native_roformer
+        if self.native and native_roformer.eligible(self, ref_feats):
+            lens0 = list(ref_lens) if ref_lens is not None else [n0]
+            lens1 = list(src_lens) if src_lens is not None else [src_points.shape[0]]
+            f, t = native_roformer.forward(self, torch.cat([ref_points, src_points]), torch.cat([ref_feats, src_feats]), lens0, lens1)
+            f0, f1, t0, t1 = f[:n0], f[n0:], t[:n0], t[n0:]
+            if return_pos_emb:
+                return (f0[None], f1[None], t0[None], t1[None]) if squeeze else (f0, f1, t0, t1)
+            return (f0[None], f1[None]) if squeeze else (f0, f1)
         t = self.embedding(torch.cat([ref_points, src_points]).contiguous())          # row-wise: both clouds in one pass
         f = F.linear(torch.cat([ref_feats, src_feats]), self.in_proj.weight, self.in_proj.bias)
         t0, t1 = t[:n0], t[n0:]

@@ -87,17 +87,40 @@ class EncoderTable:
 
 
 class _Key:
-    """the table's validity: the split switch and a WeightStamp of every parameter and buffer (object identity + address + version)"""
+    """the table's validity: the split switch and a WeightStamp of every parameter and buffer (object identity + address + version).
+    The module tree is walked ONCE: the key keeps (container dict, name) of every tensor and of every sub-module, so that a check is a
+    few hundred dictionary lookups (0.05 ms) instead of a named_parameters() traversal (0.7 ms per forward, a tenth of a registration
+    pair's host time).  A tensor or sub-module replaced, added or removed anywhere under the encoder fails the check."""
 
     def __init__(self, enc):
         from . import functional as F
         self.split = F.gemm_split_enabled()
-        self.stamps = [F.WeightStamp(t) for t in list(enc.parameters()) + list(enc.buffers())]
+        self.tensors, self.children, self.sizes = [], [], []
+        for m in enc.modules():
+            for d in (m._parameters, m._buffers):
+                self.sizes.append((d, len(d)))
+                for name, t in d.items():
+                    if t is not None:
+                        self.tensors.append((d, name, F.WeightStamp(t)))
+            self.sizes.append((m._modules, len(m._modules)))
+            for name, c in m._modules.items():
+                self.children.append((m._modules, name, c))
 
     def valid(self, enc):
         from . import functional as F
-        ts = list(enc.parameters()) + list(enc.buffers())
-        return self.split == F.gemm_split_enabled() and len(ts) == len(self.stamps) and all(s.same(t) for s, t in zip(self.stamps, ts))
+        if self.split != F.gemm_split_enabled():
+            return False
+        for d, n in self.sizes:
+            if len(d) != n:
+                return False
+        for d, name, c in self.children:
+            if d.get(name) is not c:
+                return False
+        for d, name, st in self.tensors:
+            t = d.get(name)
+            if t is None or not st.same(t):
+                return False
+        return True
 
 
 LISTS_VALID_FIRST = 1        # LCR_ENC_LISTS_VALID_FIRST (include/lcr_hip.h)
@@ -140,7 +163,7 @@ def forward(enc, feats, data_dict):
     from .backbone4 import segment_min_rows
     rows = [r or 0 for r in segment_min_rows(data_dict)]
     if seg is None:
-        seg = [torch.tensor([k], dtype=torch.int64, device=dev) for k in n]
+        seg = [torch.full((1,), int(k), dtype=torch.int64, device=dev) for k in n]      # fill launches: no host-to-device copy, no stream drain
         rows = list(n)                                   # one segment = the whole stack
     seg = [s.contiguous() for s in seg]
     nseg = int(seg[0].numel())

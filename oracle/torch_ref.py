@@ -396,40 +396,55 @@ def _apply(T, p):
 
 
 def local_global_registration(ref_knn_pts, src_knn_pts, ref_masks, src_masks, log_scores, acceptance_radius=0.45, threshold=3, steps=5, mutual=False,
-                              topk=1):
-    """geotransformer/local_global_registration.py:204-246 with use_dustbin=True, no correspondence limit; mutual (:84-87) and k (:56-82) as
-    given.  Equal values are taken in index order (a stable descending sort; torch.topk leaves it open)."""
+                              topk=1, use_dustbin=True, confidence_threshold=0.0, global_scores=None, correspondence_limit=None):
+    """geotransformer/local_global_registration.py:204-246 with every switch: mutual (:84-87), k (:56-82), use_dustbin (:62-65, :74-77, :86-87 —
+    False: the caller's (K+1) x (K+1) transport output loses its dustbin row / column first, as model_family/LCRNet.py:256-257 does),
+    global_scores (use_global_score, :236-237) and correspondence_limit (:152-160).  Equal values are taken in index order (a stable
+    descending sort; torch.topk leaves it open)."""
     S = torch.exp(log_scores)
-    B, M1, N1 = S.shape
+    if not use_dustbin:
+        S = S[:, :-1, :-1]
+    B = S.shape[0]
     ri = torch.sort(S, dim=2, descending=True, stable=True).indices[:, :, :topk]
     rtop = torch.zeros_like(S).scatter_(2, ri, torch.gather(S, 2, ri))
-    ref_c = rtop > S[:, :, -1][:, :, None]
     si = torch.sort(S, dim=1, descending=True, stable=True).indices[:, :topk, :]
     stop = torch.zeros_like(S).scatter_(1, si, torch.gather(S, 1, si))
-    src_c = stop > S[:, -1, :][:, None, :]
-    corr = ((ref_c & src_c) if mutual else (ref_c | src_c))[:, :-1, :-1] & (ref_masks[:, :, None] & src_masks[:, None, :])
-    S = S[:, :-1, :-1] * corr.float()
+    if use_dustbin:
+        ref_c, src_c = rtop > S[:, :, -1][:, :, None], stop > S[:, -1, :][:, None, :]
+    else:
+        ref_c, src_c = rtop > confidence_threshold, stop > confidence_threshold
+    corr = (ref_c & src_c) if mutual else (ref_c | src_c)
+    if use_dustbin:
+        corr, S = corr[:, :-1, :-1], S[:, :-1, :-1]
+    corr = corr & (ref_masks[:, :, None] & src_masks[:, None, :])
+    if global_scores is not None:
+        S = S * global_scores.view(-1, 1, 1)
+    S = S * corr.float()
     b, i, j = corr.nonzero(as_tuple=True)
     rp, sp, sc = ref_knn_pts[b, i], src_knn_pts[b, j], S[b, i, j]
-    # per-patch hypotheses (chunks of >= threshold correspondences), best by inlier count over ALL correspondences
+    # verification set (:152-160): the `limit` highest scores (stable: ties in row order); hypotheses still come from ALL correspondences
+    vr, vs, vc = rp, sp, sc
+    if correspondence_limit is not None and sc.shape[0] > correspondence_limit:
+        sel = torch.sort(sc, descending=True, stable=True).indices[:correspondence_limit]
+        vr, vs, vc = rp[sel], sp[sel], sc[sel]
+    # per-patch hypotheses (chunks of >= threshold correspondences), best by inlier count over the verification set
     counts = torch.bincount(b, minlength=B)
-    best_T, best_inl = None, -1
     Ts = []
     for p in torch.nonzero(counts >= threshold)[:, 0].tolist():
         m = b == p
         Ts.append(weighted_procrustes(sp[m], rp[m], sc[m]))
     if Ts:
         Ts = torch.stack(Ts)
-        res = torch.linalg.norm(rp[None] - _apply(Ts, sp[None]), dim=2)
+        res = torch.linalg.norm(vr[None] - _apply(Ts, vs[None]), dim=2)
         inl = res < acceptance_radius
-        cur = sc * inl[inl.sum(1).argmax()].float()
+        cur = vc * inl[inl.sum(1).argmax()].float()
     else:
-        T = weighted_procrustes(sp, rp, sc)
-        cur = sc * (torch.linalg.norm(rp - _apply(T, sp), dim=1) < acceptance_radius).float()
-    T = weighted_procrustes(sp, rp, cur)
+        T = weighted_procrustes(vs, vr, vc)
+        cur = vc * (torch.linalg.norm(vr - _apply(T, vs), dim=1) < acceptance_radius).float()
+    T = weighted_procrustes(vs, vr, cur)
     for _ in range(steps - 1):
-        cur = sc * (torch.linalg.norm(rp - _apply(T, sp), dim=1) < acceptance_radius).float()
-        T = weighted_procrustes(sp, rp, cur)
+        cur = vc * (torch.linalg.norm(vr - _apply(T, vs), dim=1) < acceptance_radius).float()
+        T = weighted_procrustes(vs, vr, cur)
     return rp, sp, sc, T
 
 

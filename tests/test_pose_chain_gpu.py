@@ -275,6 +275,37 @@ def test_mutual_matching_branch_vs_reference_module(model):
         model.mutual, model.topk = was, 1
 
 
+def test_lgr_option_switches_vs_reference_module(model):
+    """`use_dustbin=False` (+ confidence threshold), `use_global_score`, `correspondence_limit` of LocalGlobalRegistration
+    (local_global_registration.py:62-90, :153-160, :234-237) — off in the shipped config, built in round 6 (lcr_topk_matching_ex,
+    lcr_local_global_registration_ex) — against the imported reference module with each switch set (make_golden_lgr_options.py):
+    correspondences and their points exact, scores 1e-6, refined transform 1e-4."""
+    import json
+    from make_golden_pose_chain import synthetic_lgr_case
+    g = np.load(os.path.join(GOLDEN, "lgr_options_golden.npz"))
+    cases = json.loads(str(g["cases_json"]))
+    ref, src, rm, sm, logs, T_true = synthetic_lgr_case()
+    gs = cu(g["global_scores"])
+    names = ("topk", "mutual", "use_dustbin", "confidence_threshold", "use_global_score", "correspondence_limit")
+    was = {k: getattr(model, k) for k in names}
+    assert len(g["limit300/corr_bij"]) > 300 and np.abs(g["limit300/transform"] - g["limit5000/transform"]).max() > 1e-5   # the limit bites
+    assert not np.array_equal(g["gscore/corr_scores"], g["limit5000/corr_scores"])
+    try:
+        for tag, vals in cases.items():
+            for k, v in zip(names, vals):
+                setattr(model, k, v)
+            with torch.no_grad():
+                rp, sp, sc, T = model._local_global_registration(cu(ref), cu(src), cu(rm), cu(sm), cu(logs), gs)
+            assert np.array_equal(rp.cpu().numpy(), g[tag + "/ref_corr_points"]) and np.array_equal(sp.cpu().numpy(), g[tag + "/src_corr_points"]), tag
+            e_s = np.abs(sc.cpu().numpy() - g[tag + "/corr_scores"]).max()
+            e_T = np.abs(T.cpu().numpy() - g[tag + "/transform"]).max()
+            print("%-26s %5d correspondences, scores within %.1e, T within %.2e of the reference module's" % (tag, len(sc), e_s, e_T))
+            assert e_s < 1e-6 and e_T < TOL, tag
+    finally:
+        for k, v in was.items():
+            setattr(model, k, v)
+
+
 def ctypes_topk(F, logs, rm, sm, mutual):
     """lcr_topk_matching with K = 1 (F.top1_matching routes K = 1 to the top-1 kernels)"""
     import ctypes

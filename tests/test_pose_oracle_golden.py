@@ -59,3 +59,23 @@ def test_partition_matching_and_pose(oracle_run, pose_golden):
     assert abs(oracle_run["corr_scores"].shape[0] - n_corr) <= 0.03 * n_corr
     T, Tw = oracle_run["estimated_transform"].numpy(), pose_golden["estimated_transform"]
     assert np.allclose(T, Tw, atol=5e-2), (T, Tw)
+
+
+def test_oracle_lgr_switches_vs_reference_module():
+    """The oracle's restatement of every LocalGlobalRegistration switch (use_dustbin=False + confidence threshold, use_global_score,
+    correspondence_limit, with k and mutual) against the imported reference module's outputs (make_golden_lgr_options.py)."""
+    import json
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from make_golden_pose_chain import synthetic_lgr_case
+    g = np.load(os.path.join(GOLDEN, "lgr_options_golden.npz"))
+    ref, src, rm, sm, logs, _ = synthetic_lgr_case()
+    t = lambda x: torch.from_numpy(x)
+    for tag, (topk, mutual, dust, thr, use_gs, limit) in json.loads(str(g["cases_json"])).items():
+        with torch.no_grad():
+            rp, sp, sc, T = torch_ref.local_global_registration(t(ref), t(src), t(rm), t(sm), t(logs), mutual=mutual, topk=topk, use_dustbin=dust,
+                                                                confidence_threshold=thr, global_scores=t(g["global_scores"]) if use_gs else None,
+                                                                correspondence_limit=limit)
+        assert np.array_equal(rp.numpy(), g[tag + "/ref_corr_points"]) and np.array_equal(sp.numpy(), g[tag + "/src_corr_points"]), tag
+        assert np.abs(sc.numpy() - g[tag + "/corr_scores"]).max() < 1e-7, tag
+        assert np.abs(T.numpy() - g[tag + "/transform"]).max() < 1e-4, tag

@@ -155,3 +155,31 @@ def test_transformer_with_topk_fractions_vs_reference_golden():
             assert row_err.max() < 1e-4 * scale
         else:
             assert frac >= 0.99 and row_err.max() < 0.05 * scale
+
+
+@pytest.mark.parametrize("lens0,lens1", [([401], [396]), ([300, 17, 250], [280, 333, 1]), ([64] * 8, [70] * 8)])
+def test_native_roformer_driver_is_bit_identical_to_the_module_tree(lens0, lens1):
+    """lcr_roformer_forward (csrc/roformer.hip) issues the module tree's launches in the module tree's order: identical features and
+    rotary angles for one pair and for stacked pairs (rows of all first clouds, then all second clouds), and after a reload of the
+    weights (the table's validity key)."""
+    from lcrnet_amd.modules.thdroformer import ThDRoFormer
+    from lcrnet_amd.weights import seeded_state_dict
+    tf = ThDRoFormer(1024, 256, 128, 4, 4).eval()
+    tf.load_state_dict(seeded_state_dict(tf.state_dict(), 11))
+    tf = tf.cuda()
+    g = torch.Generator().manual_seed(sum(lens0) + 7 * sum(lens1))
+    n0, n1 = sum(lens0), sum(lens1)
+    p0, p1 = (torch.randn(n0, 3, generator=g) * 20).cuda(), (torch.randn(n1, 3, generator=g) * 20).cuda()
+    f0, f1 = torch.randn(n0, 1024, generator=g).cuda(), torch.randn(n1, 1024, generator=g).cuda()
+    args = (p0, p1, f0, f1) if len(lens0) == 1 else (p0, p1, f0, f1, lens0, lens1)
+    for round_ in range(2):
+        with torch.no_grad():
+            tf.native = True
+            nat = [t.clone() for t in tf(*args, return_pos_emb=True)]
+            assert "_native_table" in tf.__dict__
+            tf.native = False
+            ref = tf(*args, return_pos_emb=True)
+        torch.cuda.synchronize()
+        for a, b in zip(nat, ref):
+            assert a.shape == b.shape and torch.equal(a, b)
+        tf.load_state_dict(seeded_state_dict(tf.state_dict(), 12 + round_))          # in-place reload: versions change, the table is rebuilt
