@@ -116,3 +116,54 @@ def load_registration(path):
     if "estimated_transform" not in d and "estimated_transform_lgr" in d:
         d["estimated_transform"] = d["estimated_transform_lgr"]
     return d
+
+
+# ---- loop detection -> registration hand-off (experiments/inference/infer_loop_detection_find_top1.py, infer_registration.py) -----------
+def renormalise_descriptors(desc):
+    """`emb_list_map / np.linalg.norm(emb_list_map, axis=1, keepdims=True)` (infer_loop_detection_find_top1.py:75): the inference flow
+    re-normalises the stored descriptors on the host before the search."""
+    d = np.asarray(desc, dtype=np.float32)
+    return d / np.linalg.norm(d, axis=1, keepdims=True)
+
+
+def top1_with_threshold(rows, n_frames, thres):
+    """find_top1 (:13-26): for every query frame idx in [0, n_frames - 1) ALL of its rows (i, j, d2) whose distance is below `thres`, in row
+    order — despite its name the reference keeps every candidate under the threshold, not only the nearest.  rows: the float32 [R,3] view of
+    predicted_des_L2_dis.npz (:108-109).  -> float32 [K,3]."""
+    r = np.asarray(rows, dtype=np.float32).reshape(-1, 3)
+    keep = (r[:, 2] < thres) & (r[:, 0] >= 0) & (r[:, 0] < n_frames - 1)
+    r = r[keep]
+    return r[np.argsort(r[:, 0], kind="stable")]           # the reference walks idx upwards and appends each query's rows in file order
+
+
+def top1_lines(rows3):
+    """The text of `top1_with_thres_%.2f/%02d.txt` (:36-39): `{int(i)} {int(j)} {d}  \\n` with d a numpy float32 printed by an f-string."""
+    return "".join(f"{int(r[0])} {int(r[1])} {(r[2])}  \n" for r in np.asarray(rows3, dtype=np.float32).reshape(-1, 3))
+
+
+def save_top1_with_threshold(dataset_root, seq, rows3, thres):
+    """-> path of `{dataset_root}/result/top1_with_thres_{thres:.2f}/{seq:02d}.txt` (appended to, like the reference's open(..., 'a'))."""
+    path = "%s/result/top1_with_thres_%.2f" % (dataset_root, thres)
+    os.makedirs(path, exist_ok=True)
+    name = "%s/%02d.txt" % (path, seq)
+    with open(name, "a") as f:
+        f.write(top1_lines(rows3))
+    return name
+
+
+def load_loop_pairs(path):
+    """The reference's reader of that file (datasets/loop_closure/kitti/dataset.py:48-57): per line anc_idx = field 0 (the query frame),
+    pos_idx = field 1 (its match) -> [(pos_idx, anc_idx)] = (ref frame, src frame) of the registration pair."""
+    out = []
+    with open(path) as f:
+        for line in f.readlines():
+            s = line.split()
+            if s:
+                out.append((int(s[1]), int(s[0])))
+    return out
+
+
+def pose_line(pos_idx, anc_idx, estimated_transform):
+    """One line of `{seq}_pose` (infer_registration.py:77-78): pos anc and the first 12 entries of the 4x4 transform at 6 decimals."""
+    m = np.asarray(estimated_transform, dtype=np.float32).reshape(-1)[:12]
+    return f"{pos_idx} {anc_idx} " + " ".join(f"{v:.6f}" for v in m) + " \n"

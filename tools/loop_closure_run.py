@@ -1,0 +1,142 @@
+#!/usr/bin/env python
+"""Loop detection chained into registration on ONE GPU, end to end, on synthetic stand-in data, writing the reference's files; one JSON line.
+
+    python tools/loop_closure_run.py [--frames 600] [--thres 0.22] [--unique 8] [--azimuth 1900] [--pairs-per-call 16] [--out DIR]
+
+    raw scans -> 0.3 m voxels -> descriptors (`{seq}_{idx}.npz`)                      infer_loop_detection_descriptor_generation.py
+      -> host re-normalisation, masked top-50 search, predicted_des_L2_dis.npz,
+         every row under the threshold -> result/top1_with_thres_%.2f/NN.txt           infer_loop_detection_find_top1.py:9-116
+      -> the listed pairs (ref = match, src = query) through the pair model -> `{seq}_pose`   infer_registration.py
+
+Frames: `--unique` synthetic scans under a per-frame rigid motion; frame i >= K (K = --revisit-every) with (i // 7) % 3 == 0 REVISITS frame
+i - K: the same cloud moved by a small planted motion (yaw 4 deg, 0.8 m) plus 1 cm noise, so that detected loops have a known relative pose.
+With seeded random weights the descriptor distances carry no place-recognition meaning; the point is the chain, its formats and its timing.
+--thres 0 picks the threshold that lets --target-pairs loop rows through (printed in the line)."""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def planted():
+    a = np.deg2rad(4.0)
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], dtype=np.float32)
+    T[:3, 3] = [0.8, -0.3, 0.0]
+    return T
+
+
+def make_frames(base, n, revisit_every, dev):
+    """-> (list of raw device clouds, dict frame -> revisited frame).  Frame i: base[i % U] under yaw i * 2.39996 rad and a +-2 m shift; a
+    revisit is the revisited frame's cloud moved by planted()^-1 (so that T(revisit -> original) = planted) plus 1 cm noise."""
+    frames, rev = [], {}
+    Tp = planted()
+    Tinv = np.linalg.inv(Tp).astype(np.float32)
+    for i in range(n):
+        src = i - revisit_every if (revisit_every and i >= revisit_every and (i // 7) % 3 == 0) else i
+        rng = np.random.default_rng(src)
+        yaw = src * 2.39996
+        R = np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1]], dtype=np.float32)
+        pts = base[src % len(base)] @ R.T + np.append(rng.uniform(-2, 2, 2), 0).astype(np.float32)
+        if src != i:
+            pts = pts @ Tinv[:3, :3].T + Tinv[:3, 3]
+            pts = pts + np.random.default_rng(i).standard_normal(pts.shape).astype(np.float32) * 0.01
+            rev[i] = src
+        frames.append(torch.from_numpy(np.ascontiguousarray(pts, dtype=np.float32)).to(dev))
+    return frames, rev
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=600)
+    ap.add_argument("--unique", type=int, default=8)
+    ap.add_argument("--azimuth", type=int, default=1900, help="azimuth steps of the synthetic sensor (1900 = ~120 k returns per scan)")
+    ap.add_argument("--revisit-every", type=int, default=250)
+    ap.add_argument("--thres", type=float, default=0.0)
+    ap.add_argument("--target-pairs", type=int, default=64)
+    ap.add_argument("--pairs-per-call", type=int, default=16)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    import lcrnet_amd.synthetic as synthetic
+    from lcrnet_amd import io_formats as io
+    from lcrnet_amd import loop_closure as lc
+    from lcrnet_amd.config import make_cfg
+    from lcrnet_amd.model_family import LCRNet, create_model
+    from lcrnet_amd.weights import seeded_state_dict
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    desc_model = create_model().eval()
+    desc_model.load_state_dict(seeded_state_dict(desc_model.state_dict(), 7351))
+    desc_model = desc_model.to(dev)
+    cfg = make_cfg()
+    cfg["neighbor_limits"] = [74, 68, 70, 67]
+    pair_model = LCRNet(cfg).eval()
+    pair_model.load_state_dict(seeded_state_dict(pair_model.state_dict(), 7351))
+    pair_model = pair_model.to(dev)
+    base = [synthetic.synthetic_scan(1000 + u, n_azimuth=args.azimuth) for u in range(args.unique)]
+    frames, rev = make_frames(base, args.frames, args.revisit_every, dev)
+    out_dir = args.out or tempfile.mkdtemp(prefix="lcr_lc_")
+    torch.cuda.synchronize()
+    t = {}
+    t0 = time.perf_counter()
+    clouds = lc.voxelise_frames(frames)
+    torch.cuda.synchronize()
+    t["voxelise_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    desc = lc.sequence_descriptors(desc_model, clouds, [64, 65, 74, 80])
+    torch.cuda.synchronize()
+    t["descriptors_s"] = time.perf_counter() - t0
+    thres = args.thres
+    t0 = time.perf_counter()
+    rows, kept = lc.detect_loops(desc, thres if thres > 0 else np.inf)
+    if thres <= 0:                                         # the threshold that lets the target number of rows through
+        d = np.sort(kept[:, 2])
+        thres = float(d[min(args.target_pairs, len(d) - 1)]) if len(d) else 1.0
+        kept = io.top1_with_threshold(rows, len(clouds), thres)
+    t["retrieval_and_rule_s"] = time.perf_counter() - t0
+    feat_dir = os.path.join(out_dir, "features")
+    os.makedirs(feat_dir, exist_ok=True)
+    io.save_pair_dist(feat_dir, rows)
+    name = io.save_top1_with_threshold(out_dir, 0, kept, thres)
+    pairs = io.load_loop_pairs(name)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = lc.register_pairs(pair_model, clouds, pairs, cfg["neighbor_limits"], args.pairs_per_call) if pairs else []
+    torch.cuda.synchronize()
+    t["registration_s"] = time.perf_counter() - t0
+    os.makedirs(os.path.join(out_dir, "registration"), exist_ok=True)
+    with open(os.path.join(out_dir, "registration", "0_pose"), "a") as f:
+        for (pos, anc), o in zip(pairs, outs):
+            f.write(io.pose_line(pos, anc, o["estimated_transform"].cpu().numpy()))
+    # detected pairs that are planted revisits: the estimated transform (src = query -> ref = match) against the planted motion
+    Tp = planted()
+    errs = []
+    for (pos, anc), o in zip(pairs, outs):
+        if rev.get(anc) == pos:
+            T = o["estimated_transform"].cpu().numpy()
+            errs.append((float(np.abs(T[:3, :3] - Tp[:3, :3]).max()), float(np.linalg.norm(T[:3, 3] - Tp[:3, 3]))))
+    print(json.dumps({"metric": "loop detection -> registration, chained on one GPU", "frames": args.frames, "raw_points_per_frame": int(np.mean([len(f) for f in frames])),
+                      "voxel_points_per_frame": int(np.mean([len(c) for c in clouds])), "threshold": round(thres, 6), "loop_rows": int(len(kept)),
+                      "pairs_registered": len(outs), "pairs_per_call": args.pairs_per_call, **{k: round(v, 4) for k, v in t.items()},
+                      "descriptor_scans_per_s": round(args.frames / t["descriptors_s"], 1),
+                      "registration_pairs_per_s": round(len(outs) / t["registration_s"], 1) if outs else None,
+                      "planted_revisits_among_detected": len(errs),
+                      "planted_motion_max_rotation_entry_err": round(max(e[0] for e in errs), 5) if errs else None,
+                      "planted_motion_max_translation_err_m": round(max(e[1] for e in errs), 4) if errs else None,
+                      "files": "features/predicted_des_L2_dis.npz, result/top1_with_thres_%.2f/00.txt, registration/0_pose in %s" % (thres, out_dir if args.out else "a temporary directory"),
+                      "data": "synthetic (%d unique scans, a rigid motion per frame, planted revisits); seeded random weights" % args.unique}), flush=True)
+    if not args.out:
+        import shutil
+        shutil.rmtree(out_dir, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
