@@ -10,12 +10,12 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o stats -- python "$ROOT/bench.py" --steps 50 --repeats 2 --no-cpu-baseline > "$OUT/stats_bench.log" 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o stats -- python "$ROOT/bench.py" --steps 50 --repeats 2 --no-cpu-baseline --no-blocks > "$OUT/stats_bench.log" 2>&1
 python "$ROOT/tools/rocprof_summary.py" "$(find /tmp/prof_s -name "*.db" | head -1)" --bench-log "$OUT/stats_bench.log" \
-  --note "rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --repeats 2 --no-cpu-baseline (timed region + the clocked kernel-alone passes behind it)" > "$OUT/kernel_summary.md"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f -o fetch -- python "$ROOT/bench.py" --steps 25 --repeats 1 --no-cpu-baseline > "$OUT/fetch_bench.log" 2>&1
+  --note "rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --repeats 2 --no-cpu-baseline --no-blocks (timed region + the clocked kernel-alone passes behind it)" > "$OUT/kernel_summary.md"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f -o fetch -- python "$ROOT/bench.py" --steps 25 --repeats 1 --no-cpu-baseline --no-blocks > "$OUT/fetch_bench.log" 2>&1
 cp $(find /tmp/prof_f -name "fetch_counter_collection.csv" | head -1) "$OUT/"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w -o write -- python "$ROOT/bench.py" --steps 25 --repeats 1 --no-cpu-baseline > "$OUT/write_bench.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w -o write -- python "$ROOT/bench.py" --steps 25 --repeats 1 --no-cpu-baseline --no-blocks > "$OUT/write_bench.log" 2>&1
 cp $(find /tmp/prof_w -name "write_counter_collection.csv" | head -1) "$OUT/"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
   --kernel-trace --output-format csv -d /tmp/prof_m -o m -- python "$ROOT/tools/enc_profile.py" 3 > "$OUT/mfma_enc.log" 2>&1
