@@ -39,6 +39,7 @@ LIMITS = [64, 65, 74, 80]          # reference training/eval default (dataset_lo
 ISO_PASSES = 3                     # clocked passes per distinct batch for the kernel-alone figures
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3           # dense fp32 MFMA/vector peak
+BF16_PEAK_TFLOPS = 2500.0          # dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
 RS_VALU_PER_QUERY = 354            # SQ_INSTS_VALU per query of the search kernel (rocprofv3 --pmc)
 RS_VALU_SOURCE = "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU per query, profiles/r02_radius_pmc.md; 256 CUs at 2.4 GHz"
 PMC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # written by tools/pmc_summary.py from separate rocprofv3 --pmc passes
@@ -529,7 +530,9 @@ def main():
         # Every distinct batch once more with NOTHING else on the GPU (one stream, one batch in flight, outside the timed region) and
         # EVERY launch clocked: the kernels' own durations as a kernel trace of the encoder alone reports them
         # (profiles/rNN_encoder_alone_kernel_summary.md), and the exact flops / launches of a step (no sampling).
-        iso = {"t_gemm": 0.0, "t_agg": 0.0, "t_rs": 0.0, "flops": [], "flops_agg": [], "n_gemm": 0, "n_agg": 0, "n_rs": 0, "passes": 0}
+        iso = {"t_gemm": 0.0, "t_agg": 0.0, "t_rs": 0.0, "flops": [], "flops_agg": [], "n_gemm": 0, "n_agg": 0, "n_rs": 0, "passes": 0,
+               "t_split": 0.0, "n_split": 0, "fl_split": 0.0, "t_light": 0.0, "n_light": 0, "fl_light": 0.0}
+        is_split = lambda m: F.gemm_split_enabled() and F.gemm_split_ok(m[1], m[2])     # the shapes the encoder driver sends to lcr_gemm_f32_bsplit
         for pts_k, lens_k in inputs:
             pipe.encode(pipe.preprocess(pts_k, lens_k))                # warm: this batch's allocations and cache lines
             torch.cuda.synchronize()
@@ -548,6 +551,11 @@ def main():
                 iso["n_agg"] += len(r["kpconv_aggregate"])
                 iso["n_rs"] += len(r["radius_query"])
                 iso["passes"] += 1
+                for b_, k_, m_ in r["gemm"]:
+                    cls = "split" if is_split(m_) else "light"
+                    iso["t_" + cls] += k_ if k_ is not None else b_
+                    iso["n_" + cls] += 1
+                    iso["fl_" + cls] += 2.0 * m_[0] * m_[1] * m_[2]
             iso["flops"].append(sum(2.0 * m[0] * m[1] * m[2] for _, _, m in r["gemm"]))
             iso["flops_agg"].append(sum(2.0 * 15 * nnz.get((M, Ns), M * H) * C for _, _, (M, Ns, H, C, isz) in r["kpconv_aggregate"]))
     if rank == 0 and os.environ.get("LCR_BENCH_NO_KTIMER"):            # A/B run without per-launch events: the headline only
@@ -609,6 +617,21 @@ def main():
                          "batches, encoder + pre-processing alone on the GPU, after the timed region; reproducible from "
                          "profiles/*_encoder_alone_kernel_summary.md (launches x avg us of the k_gemm_f32* rows)" % (ISO_PASSES, nb_in),
                 "launches_timed": iso["n_gemm"],
+                # the two GEMM families apart, each against the ceiling of the unit it runs on (VERDICT r5 / advisor r5): the split form
+                # executes 6 bf16 products per fp32 product on the bf16 matrix cores, so its fp32-EQUIVALENT ceiling is 2 500 / 6 = 417 TFLOP/s
+                "by_form": {
+                    "split_bf16x3": None if not iso["n_split"] else {
+                        "kernel": "k_gemm_f32_bsplit_p (K >= 288, N >= 64)", "launches_per_step": round(iso["n_split"] / iso["passes"], 1),
+                        "kernel_ms_per_step": round(iso["t_split"] / iso["passes"] * 1e3, 4),
+                        "fp32_equivalent_tflops": round(iso["fl_split"] / iso["t_split"] / 1e12, 2),
+                        "frac_of_fp32_mfma_peak": round(iso["fl_split"] / iso["t_split"] / 1e12 / FP32_PEAK_TFLOPS, 4),
+                        "executed_bf16_tflops": round(6 * iso["fl_split"] / iso["t_split"] / 1e12, 1),
+                        "own_ceiling_fp32_equivalent_tflops": round(BF16_PEAK_TFLOPS / 6, 1),
+                        "frac_of_own_ceiling": round(6 * iso["fl_split"] / iso["t_split"] / 1e12 / BF16_PEAK_TFLOPS, 4)},
+                    "fp32_mfma": {"kernel": "k_gemm_f32 / k_gemm_f32_deep (v_mfma_f32_32x32x2_f32)", "launches_per_step": round(iso["n_light"] / iso["passes"], 1),
+                                  "kernel_ms_per_step": round(iso["t_light"] / iso["passes"] * 1e3, 4),
+                                  "tflops": round(iso["fl_light"] / max(iso["t_light"], 1e-12) / 1e12, 2),
+                                  "frac_of_fp32_mfma_peak": round(iso["fl_light"] / max(iso["t_light"], 1e-12) / 1e12 / FP32_PEAK_TFLOPS, 4)}},
                 "avg_launch_us": round(iso["t_gemm"] / max(iso["n_gemm"], 1) * 1e6, 2),
                 "kernel_ms_per_step": round(iso["t_gemm"] / iso["passes"] * 1e3, 4),
                 "gflop_per_launch": round(flops_step / gemm_per_step / 1e9, 3),
@@ -635,6 +658,10 @@ def main():
                                              "ms_per_step": round(rs_launch * 1e3, 4),
                                              "ms_per_step_event_bracketed": round(t_rs / max(len(rsq), 1) * 1e3, 4)},
                              "north_star_target_frac": 0.6,
+                             "north_star_target_status": "NOT MET and not reachable by this algorithm: 0.60 of 8 TB/s over 143 MB is 30 us per batch = ~16 "
+                                                         "wavefront instructions per query; an exact (d2, idx)-sorted radius search spends ~300 VALU "
+                                                         "per query on ~98 distance tests + a 51-key sort (traffic 1.01x the algorithmic bytes: no wasted "
+                                                         "bytes).  Five lane mappings built and measured over rounds 2-5; the stage's roofline is `issue_bound`",
                              # the search is bound by instruction issue, not by HBM (LABNOTES.md §4.4): VALU wavefront-instructions per query
                              # (rocprofv3 --pmc, profiles/) at 4 cycles each on a SIMD
                              "instruction_floor": {"valu_cycles_per_query_per_cu": RS_VALU_PER_QUERY, "queries_per_step": int(n_queries),

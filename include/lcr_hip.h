@@ -177,12 +177,14 @@ typedef struct LcrPrecomputeLayout {
   size_t  off_order[LCR_MAX_STAGES];           /* i32[cap]  cell-sorted processing order */
   size_t  off_neighbors[LCR_MAX_STAGES];       /* i32[cap, limits[i]] */
   size_t  off_subsampling[LCR_MAX_STAGES];     /* i32[cap, limits[i]]   rows = stage i+1 points (i < num_stages-1) */
-  size_t  off_upsampling[LCR_MAX_STAGES];      /* i32[cap, limits[i+1]] rows = stage i points   (i < num_stages-1, if enabled) */
+  size_t  off_upsampling[LCR_MAX_STAGES];      /* i32[cap, limits[i+1]] rows = stage i points   (i < num_stages-1, if enabled); upsampling == 2: i32[cap, 1] */
   size_t  out_bytes, ws_bytes;
 } LcrPrecomputeLayout;
 /* n_raw > 0: raw-scan mode — the input of lcr_precompute_batch is then f32[n_raw,3] raw points + i64[B] raw lengths, voxelised
  * with `raw_voxel` (replaces the offline Open3D step) into stage 0 inside the same call; n0 is the CAPACITY
- * assumed for the voxel count (LCR_STATUS_LEN_MISMATCH in status_host if it was too small: retry with n0 = n_raw). */
+ * assumed for the voxel count (LCR_STATUS_LEN_MISMATCH in status_host if it was too small: retry with n0 = n_raw).
+ * upsampling: 0 = no upsampling lists (descriptor-only deployment), 1 = the reference collate's full rows [n_i, limits[i+1]], 2 = NEAREST-ONLY
+ * lists [n_i, 1]: column 0 of the full rows, which is all KPDecoder reads (nearest_upsample, backbone4.py:355-367; modules/kpconv/functional.py:21). */
 int lcr_precompute_layout(int64_t n0, int B, int num_stages, const int* limits, int upsampling, int64_t n_raw,
                           LcrPrecomputeLayout* layout);
 int lcr_precompute_batch(const float* points0, const int64_t* lengths0, const LcrPrecomputeLayout* layout, float voxel_size,

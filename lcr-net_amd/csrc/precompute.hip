@@ -136,7 +136,7 @@ extern "C" int lcr_precompute_layout(int64_t n0, int B, int num_stages, const in
   std::memset(L, 0, sizeof(*L));
   L->num_stages = num_stages;
   L->B = B;
-  L->upsampling = upsampling ? 1 : 0;
+  L->upsampling = upsampling == 2 ? 2 : (upsampling ? 1 : 0);     // 2: nearest-only lists (one column)
   L->n_raw = n_raw;
   const int64_t cap = n0 > 0 ? n0 : 1;
   Carver c(nullptr, ~size_t(0));
@@ -163,7 +163,7 @@ extern "C" int lcr_precompute_layout(int64_t n0, int B, int num_stages, const in
       c.take<int32_t>(cap * limits[i]);
       if (upsampling) {
         L->off_upsampling[i] = c.off;
-        c.take<int32_t>(cap * limits[i + 1]);
+        c.take<int32_t>(cap * (upsampling == 2 ? 1 : limits[i + 1]));
       }
     }
   }
@@ -275,7 +275,8 @@ extern "C" int lcr_precompute_batch_rows(const float* points0, int raw_row_float
     rc = search(pts[i], lens[i], L->cap[i], W.grid_ws[i], L->cap[i], r, L->limits[i], i32(L->off_neighbors[i]), i32(L->off_order[i]), s);
     if (rc) return rc;
     if (i > 0 && L->upsampling) {
-      rc = search(pts[i - 1], lens[i - 1], L->cap[i - 1], W.grid_ws[i], L->cap[i], r, L->limits[i], i32(L->off_upsampling[i - 1]),
+      // upsampling == 2: the decoder reads column 0 only (nearest_upsample, backbone4.py:355-367) — a limit-1 search takes the arg-min path
+      rc = search(pts[i - 1], lens[i - 1], L->cap[i - 1], W.grid_ws[i], L->cap[i], r, L->upsampling == 2 ? 1 : L->limits[i], i32(L->off_upsampling[i - 1]),
                   no_fork ? i32(L->off_order[i - 1]) : nullptr, s);   // forked: order[i-1] is written on another side stream
       if (rc) return rc;
     }

@@ -418,6 +418,22 @@ __device__ __forceinline__ void rq_turn(const RqSearch& A, int B, const int32_t*
 
       if (n == 0) {
         // nothing in range: the row is all padding
+      } else if (limit == 1 && n <= RQ_CAP) {
+        // nearest-only rows (the decoder's upsampling lists: only column 0 is ever read): the smallest (d², idx) key of the compacted
+        // candidates — no bin scan, no slot dealing, no rank loop
+        cnt[lane] = 0;                                         // bin counts taken during compaction: clean for the next query
+        uint64_t best = ~0ull;
+        for (int e = lane; e < n; e += 64) best = min(best, keys[e]);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+          const uint32_t lo = __shfl_xor(static_cast<uint32_t>(best), d), hi = __shfl_xor(static_cast<uint32_t>(best >> 32), d);
+          best = min(best, (static_cast<uint64_t>(hi) << 32) | lo);
+        }
+        if (lane == 0) {
+          const int64_t v = static_cast<int64_t>(static_cast<uint32_t>(best));
+          if (HAS64) row64[0] = v;
+          if (HAS32) row32[0] = static_cast<int32_t>(v);
+        }
       } else if (n <= RQ_CAP) {
         // counting sort on RQ_BINS monotone bins of d²: bin counts (taken while the keys were compacted) -> wavefront scan -> key
         // SLOTS dealt into bin order (an atomic per key hands out the positions of a bin; order inside a bin is arbitrary; 16-bit

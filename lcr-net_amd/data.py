@@ -87,11 +87,17 @@ class PrecomputedArena:
         orders = [out[lay.off_order[i]:lay.off_order[i] + 4 * tot[i]].view(torch.int32) for i in range(S)]
         neighbors = [view(lay.off_neighbors[i], tot[i], lay.limits[i], torch.int32, 4) for i in range(S)]
         subsampling = [view(lay.off_subsampling[i], tot[i + 1], lay.limits[i], torch.int32, 4) for i in range(S - 1)]
-        upsamp = [view(lay.off_upsampling[i], tot[i], lay.limits[i + 1], torch.int32, 4) for i in range(S - 1)] if self.upsampling else []
+        # upsampling == "nearest" (layout flag 2): one column per row — all the decoder reads
+        upsamp = [view(lay.off_upsampling[i], tot[i], 1 if self.upsampling == 2 else lay.limits[i + 1], torch.int32, 4) for i in range(S - 1)] if self.upsampling else []
         # lists_valid_first: every row came out of a radius search (valid entries first, padding behind) — the native encoder driver may
         # then stop reading a row at its first padded chunk (LCR_ENC_LISTS_VALID_FIRST); a hand-built dictionary without the key gets full scans
         return {"order": orders, "points": pts, "lengths": lens, "neighbors": neighbors, "subsampling": subsampling, "upsampling": upsamp,
                 "lengths_host": self.lengths_host, "segment_lengths": lens, "lists_valid_first": True}
+
+
+def _ups_flag(upsampling):
+    """True / 1: the reference collate's full upsampling rows; "nearest" / 2: column 0 only (what KPDecoder reads); False / 0: none."""
+    return 2 if upsampling in ("nearest", 2) else int(bool(upsampling))
 
 
 _layout_cache = {}
@@ -99,12 +105,12 @@ _ws_cache = threading.local()
 
 
 def _layout_for(n0, B, S, neighbor_limits, upsampling, n_raw):
-    key = (n0, B, S, tuple(int(x) for x in neighbor_limits), bool(upsampling), n_raw)
+    key = (n0, B, S, tuple(int(x) for x in neighbor_limits), _ups_flag(upsampling), n_raw)
     lay = _layout_cache.get(key)
     if lay is None:
         lay = PrecomputeLayout()
         lim = (ctypes.c_int * S)(*key[3])
-        _lib.check(_lib.lib().lcr_precompute_layout(n0, B, S, ctypes.cast(lim, ctypes.c_void_p), int(bool(upsampling)), n_raw,
+        _lib.check(_lib.lib().lcr_precompute_layout(n0, B, S, ctypes.cast(lim, ctypes.c_void_p), _ups_flag(upsampling), n_raw,
                                                     ctypes.addressof(lay)), "lcr_precompute_layout")
         if len(_layout_cache) > 64:
             _layout_cache.clear()
@@ -158,7 +164,7 @@ def precompute_batch_arena(points, lengths, num_stages, voxel_size, radius, neig
     if st:
         raise RuntimeError("precompute_batch: device status 0x%x" % st)
     flat = list(lens_host)
-    return PrecomputedArena(out, lay, [flat[i * B:(i + 1) * B] for i in range(S)], points, lengths, raw, bool(upsampling))
+    return PrecomputedArena(out, lay, [flat[i * B:(i + 1) * B] for i in range(S)], points, lengths, raw, _ups_flag(upsampling))
 
 
 def precompute_batch_native(points, lengths, num_stages, voxel_size, radius, neighbor_limits, upsampling=True, key_bits_hint=32,
@@ -205,7 +211,7 @@ def precompute_batch(points, lengths, num_stages, voxel_size, radius, neighbor_l
         if i < num_stages - 1:
             subsampling.append(grids[i].query(pts[i + 1], lens[i + 1], neighbor_limits[i], dtype=index_dtype))
             if upsampling:
-                upsamp.append(grids[i + 1].query(pts[i], lens[i], neighbor_limits[i + 1], dtype=index_dtype))
+                upsamp.append(grids[i + 1].query(pts[i], lens[i], 1 if _ups_flag(upsampling) == 2 else neighbor_limits[i + 1], dtype=index_dtype))
     host = torch.stack(lens + [torch.cat([s.long() for s in statuses] + [g.status.long() for g in grids]).sum().expand(lengths.numel())]).cpu()
     status = int(host[-1][0])
     if status & STATUS_KEY_OVERFLOW and key_bits_hint:

@@ -558,9 +558,14 @@ class PairPipeline:
     (pairs_per_call >= 8: most of a call is native launch sequences that release the lock) a third worker fills the latency-bound tail:
     584 / 628 / 629 pairs/s with 2 / 3 / 4 workers at 16 pairs per call (round 5)."""
 
-    def __init__(self, model, voxel_size=0.3, radius=1.275, num_stages=4, neighbor_limits=(74, 68, 70, 67), workers=2, pairs_per_call=1):
+    def __init__(self, model, voxel_size=0.3, radius=1.275, num_stages=4, neighbor_limits=(74, 68, 70, 67), workers=2, pairs_per_call=1,
+                 upsampling="nearest"):
         """pairs_per_call > 1: consecutive pairs are stacked and go through `LCRNet.forward_pairs` together (one collate, one encoder /
-        transformer / vote-encoder / decoder pass for all of them; only the matching + registration tail runs pair by pair)."""
+        transformer / vote-encoder / decoder pass for all of them; only the matching + registration tail runs pair by pair).
+        upsampling: "nearest" (default) builds the three decoder-only upsampling lists as ONE column per row — KPDecoder reads column 0 only
+        (nearest_upsample, backbone4.py:355-367), a limit-1 search takes the arg-min path of the kernel and writes 1/70th of the rows; True
+        builds the reference collate's full rows (identical model outputs: tests/test_pairs_batched_gpu.py)."""
+        self.upsampling = upsampling
         self.model, self.workers = model, max(1, int(workers))
         self.pairs_per_call = max(1, min(32, int(pairs_per_call)))
         self.voxel_size, self.radius, self.num_stages, self.limits = voxel_size, radius, num_stages, list(neighbor_limits)
@@ -583,7 +588,7 @@ class PairPipeline:
 
     def one(self, points, lengths):
         """points f32[N,3] = the two clouds of a pair stacked (already voxelised), lengths i64[2] -> the model's output dict."""
-        dd = precompute_batch(points.contiguous(), lengths, self.num_stages, self.voxel_size, self.radius, self.limits, upsampling=True)
+        dd = precompute_batch(points.contiguous(), lengths, self.num_stages, self.voxel_size, self.radius, self.limits, upsampling=self.upsampling)
         del dd["segment_lengths"]            # pair semantics of the reference: GroupNorm statistics over BOTH clouds
         dd["features"] = torch.ones(points.shape[0], 1, device=points.device)
         dd["lengths_c_host"] = dd["lengths_host"][-1]
@@ -596,7 +601,7 @@ class PairPipeline:
             return [self.one(*pairs[0])]
         points = torch.cat([p for p, _ in pairs]).contiguous()
         lengths = torch.cat([l for _, l in pairs])
-        dd = precompute_batch(points, lengths, self.num_stages, self.voxel_size, self.radius, self.limits, upsampling=True)
+        dd = precompute_batch(points, lengths, self.num_stages, self.voxel_size, self.radius, self.limits, upsampling=self.upsampling)
         del dd["segment_lengths"]            # forward_pairs takes GroupNorm statistics per PAIR (both clouds), not per cloud
         dd["features"] = torch.ones(points.shape[0], 1, device=points.device)
         dd["lengths_c_host"] = dd["lengths_host"][-1]

@@ -72,3 +72,45 @@ def test_forward_pairs_equals_one_call_per_pair():
         print("pair %d: descriptor diff %.1e, enhanced %.1e, fine feats %.1e, node corr %d/%d, point corr %d vs %d" % (
             i, rel(b["pos_feature_global"], o["pos_feature_global"]), rel(b["pos_feats_c_enhanced"], o["pos_feats_c_enhanced"]),
             rel(b["pos_feats_f"], o["pos_feats_f"]), len(sb & so), len(so), b["corr_scores"].shape[0], n))
+
+
+def test_nearest_only_upsampling_lists_are_column_zero_and_change_nothing():
+    """PairPipeline's default builds the three decoder-only upsampling lists as ONE column (limit-1 search, arg-min path of the kernel):
+    that column equals column 0 of the reference collate's full rows (bit for bit, ties by index like the sorted rows), and the pair model's
+    outputs are identical with either form — KPDecoder reads column 0 only (backbone4.py:355-367)."""
+    from lcrnet_amd.config import make_cfg
+    from lcrnet_amd.data import precompute_batch
+    from lcrnet_amd.model_family import LCRNet
+    from lcrnet_amd.pipeline import PairPipeline
+    from lcrnet_amd.weights import seeded_state_dict
+    work = []
+    for a, b in PAIRS:
+        pa, pb = torch.from_numpy(load_scan(a)).cuda(), torch.from_numpy(load_scan(b)).cuda()
+        work.append((torch.cat([pa, pb]), torch.tensor([len(pa), len(pb)], dtype=torch.int64, device="cuda")))
+    pts, lens = torch.cat([w[0] for w in work]), torch.cat([w[1] for w in work])
+    full = precompute_batch(pts, lens, NUM_STAGES, VOXEL, RADIUS, LIMITS, upsampling=True)
+    near = precompute_batch(pts, lens, NUM_STAGES, VOXEL, RADIUS, LIMITS, upsampling="nearest")
+    for i in range(NUM_STAGES - 1):
+        assert near["upsampling"][i].shape == (full["upsampling"][i].shape[0], 1)
+        assert torch.equal(near["upsampling"][i][:, 0], full["upsampling"][i][:, 0]), i
+        assert torch.equal(near["subsampling"][i], full["subsampling"][i]) and torch.equal(near["neighbors"][i], full["neighbors"][i])
+    # a tiny radius: most rows have NO neighbour (padding = the number of support rows) and many exactly one
+    from lcrnet_amd.modules.ops import radius_search
+    q, s = pts[:5000].contiguous(), pts[5000:9000].contiguous()
+    ql, sl = torch.tensor([5000], device="cuda"), torch.tensor([4000], device="cuda")
+    one = radius_search(q, s, ql, sl, 0.4, 1, check=False)
+    many = radius_search(q, s, ql, sl, 0.4, 16, check=False)
+    assert torch.equal(one[:, 0], many[:, 0]) and int((one[:, 0] == 4000).sum()) > 100
+    cfg = make_cfg()
+    cfg["neighbor_limits"] = LIMITS
+    m = LCRNet(cfg).eval()
+    m.load_state_dict(seeded_state_dict(m.state_dict(), 7351), strict=True)
+    m = m.cuda()
+    with PairPipeline(m, VOXEL, RADIUS, NUM_STAGES, LIMITS, workers=1, pairs_per_call=3, upsampling=True) as a, \
+            PairPipeline(m, VOXEL, RADIUS, NUM_STAGES, LIMITS, workers=1, pairs_per_call=3) as b:
+        assert b.upsampling == "nearest"
+        fa = [{k: v.cpu() for k, v in o.items() if torch.is_tensor(v)} for o in a.run(work)]
+        fb = [{k: v.cpu() for k, v in o.items() if torch.is_tensor(v)} for o in b.run(work)]
+    for oa, ob in zip(fa, fb):
+        for k in ("pos_feats_f", "anc_feats_f", "pos_corr_points", "corr_scores", "estimated_transform", "pos_feature_global"):
+            assert oa[k].shape == ob[k].shape and torch.allclose(oa[k], ob[k], atol=1e-6), k
