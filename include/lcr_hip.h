@@ -466,6 +466,14 @@ int lcr_top1_matching(const float* logS, int64_t B, int M, int N, const uint8_t*
  * its row's and its column's maximum (each beating its dustbin); 0 = either, the shipped configuration. */
 int lcr_top1_matching_ex(const float* logS, int64_t B, int M, int N, const uint8_t* row_mask, const uint8_t* col_mask, int mutual,
                          int64_t* total, int32_t* out_bij, float* out_score, void* ws, size_t ws_bytes, void* stream);
+/* The patch score matrices of the dense point matching (model_family/LCRNet.py:236-250 + the padding of learnable_sinkhorn.py:38-49) in one
+ * kernel: S[p] f32[(K+1),(K+1)] = scale * gather(feats_a, idx_a[p]) . gather(feats_b, idx_b[p])^T over C channels on the fp32 matrix cores,
+ * dustbin row / column = *alpha, entries of masked rows / columns = -inf_val — what lcr_build_padded_scores makes of the batched product of
+ * two lcr_gather_rows results, without the gathered copies.  idx_* i64[P,K] with the shadow index (== N*) for a zero row, mask_* u8[P,K];
+ * K = 128 (cfg.model.num_points_in_patch), C % 32 == 0, feats 16-byte aligned.  feats_a / feats_b may be the same tensor. */
+int lcr_patch_scores(const float* feats_a, int64_t Na, const float* feats_b, int64_t Nb, int C, const int64_t* idx_a, const int64_t* idx_b,
+                     const uint8_t* mask_a, const uint8_t* mask_b, int64_t P, int K, float scale, const float* alpha, float inf_val, float* S,
+                     void* stream);
 /* Dustbin top-K matching for K >= 1 (LocalGlobalRegistration(k=K), local_global_registration.py:56-82; K = 1 in the shipped configuration):
  * (i, j) is kept from the row side if P[i][j] is among the K largest of row i — dustbin column included, equal values in index order — and
  * beats the row's dustbin; from the column side likewise; `mutual` as above.  Two-phase and row-major like lcr_top1_matching. */

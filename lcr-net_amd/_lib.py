@@ -89,6 +89,7 @@ _SIGS = {
     "lcr_top1_matching_ex": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "lcr_topk_matching_ws_bytes": (c_int, [c_i64, c_int, c_int, c_size_p]),
     "lcr_topk_matching": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "lcr_patch_scores": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_float, c_vp, c_float, c_vp, c_vp]),
     "lcr_topk_matching_ex": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t,
                                      c_vp]),
     "lcr_local_global_registration_ex": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_int, c_float, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,

@@ -570,6 +570,36 @@ def log_optimal_transport(raw_scores, row_masks, col_masks, alpha, scale=1.0, it
     S = torch.empty((B, M + 1, N + 1), dtype=torch.float32, device=dev)
     _lib.check(_L().lcr_build_padded_scores(_lib.ptr(raw_scores.contiguous()), _lib.ptr(rm), _lib.ptr(cm), B, M, N, float(scale),
                                             _lib.ptr(alpha.reshape(1).float()), float(inf), _lib.ptr(S), _sp(S)), "lcr_build_padded_scores")
+    return _transport_padded(S, rm, cm, iters, inf)
+
+
+PATCH_SCORES_FUSED = [os.environ.get("LCR_PATCH_SCORES_FUSED", "1") != "0"]      # A/B switch (tests, tools): 0 = gather + batched product + padding
+
+
+def patch_log_optimal_transport(feats_a, idx_a, feats_b, idx_b, mask_a, mask_b, alpha, scale=1.0, iters=100, inf=1e12):
+    """The patch-level transport of DenseMatchingHEAD (LCRNet.py:236-250): log scores [P,K+1,K+1] of P patch pairs whose point features are
+    rows idx_a[p] of feats_a / idx_b[p] of feats_b (index == number of rows: the zero row of the padded tensor).  The gathers, the batched
+    product, the scaling and the dustbin / mask padding are ONE kernel (lcr_patch_scores); LCR_PATCH_SCORES_FUSED=0 runs them apart."""
+    P, K = idx_a.shape
+    if not PATCH_SCORES_FUSED[0] or K != 128 or feats_a.shape[1] % 32 != 0 or P == 0:
+        fa, fb = gather_rows(feats_a, idx_a.contiguous()), gather_rows(feats_b, idx_b.contiguous())
+        return log_optimal_transport(bmm_nt(fa, fb), mask_a, mask_b, alpha, scale=scale, iters=iters, inf=inf)
+    dev = feats_a.device
+    fa, fb = feats_a.contiguous(), feats_b.contiguous()
+    ia, ib = idx_a.contiguous(), idx_b.contiguous()
+    assert ia.dtype == torch.int64 and ib.dtype == torch.int64 and fa.dtype == torch.float32 and fa.shape[1] == fb.shape[1]
+    rm, cm = mask_a.to(torch.uint8).contiguous(), mask_b.to(torch.uint8).contiguous()
+    S = torch.empty((P, K + 1, K + 1), dtype=torch.float32, device=dev)
+    _lib.check(_L().lcr_patch_scores(_lib.ptr(fa), fa.shape[0], _lib.ptr(fb), fb.shape[0], fa.shape[1], _lib.ptr(ia), _lib.ptr(ib), _lib.ptr(rm),
+                                     _lib.ptr(cm), P, K, float(scale), _lib.ptr(alpha.reshape(1).float()), float(inf), _lib.ptr(S), _sp(S)),
+               "lcr_patch_scores")
+    return _transport_padded(S, rm, cm, iters, inf)
+
+
+def _transport_padded(S, rm, cm, iters, inf):
+    """Sinkhorn on padded scores S [B,M+1,N+1] in place -> log scores (the second half of LearnableLogOptimalTransport)."""
+    B, M, N = S.shape[0], S.shape[1] - 1, S.shape[2] - 1
+    dev = S.device
     nfl = ctypes.c_size_t(0)
     _lib.check(_L().lcr_log_sinkhorn_ws_floats(B, M, N, ctypes.byref(nfl)), "lcr_log_sinkhorn_ws_floats")
     uv = torch.empty((nfl.value,), dtype=torch.float32, device=dev)

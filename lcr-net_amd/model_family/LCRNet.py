@@ -345,9 +345,9 @@ class LCRNet(nn.Module):
         node_idx = [(nb[q_off[p]:q_off[p + 1], 1], nb[q_off[p]:q_off[p + 1], 2]) for p in range(P)]
         pk_g, ak_g, pkm, akm = pk_g.contiguous(), ak_g.contiguous(), pkm.contiguous(), akm.contiguous()
         pkp, akp = F.gather_rows(pts_f, pk_g), F.gather_rows(pts_f, ak_g)
-        pkf, akf = F.gather_rows(feats_f, pk_g), F.gather_rows(feats_f, ak_g)
-        ms = F.log_optimal_transport(F.bmm_nt(pkf, akf), pkm, akm, self.optimal_transport.alpha,
-                                     scale=1.0 / feats_f.shape[1] ** 0.5, iters=self.optimal_transport.num_iterations)
+        # feature gathers + batched product + scaling + dustbin / mask padding: one kernel straight from feats_f (lcr_patch_scores)
+        ms = F.patch_log_optimal_transport(feats_f, pk_g, feats_f, ak_g, pkm, akm, self.optimal_transport.alpha,
+                                           scale=1.0 / feats_f.shape[1] ** 0.5, iters=self.optimal_transport.num_iterations)
         lgr = self._local_global_registration_group(pkp, akp, pkm, akm, ms, q_off, nscore)      # all pairs: one matching, one registration sequence
         for p in range(P):
             q = slice(q_off[p], q_off[p + 1])
@@ -381,9 +381,8 @@ class LCRNet(nn.Module):
         pk, ak = pos_knn[pi].contiguous(), anc_knn[ai].contiguous()    # (P, K) point indices of the matched patches
         pkm, akm = pos_km[pi].contiguous(), anc_km[ai].contiguous()
         pkp, akp = F.gather_rows(pos_f, pk), F.gather_rows(anc_f, ak)
-        pkf, akf = F.gather_rows(pos_ff, pk), F.gather_rows(anc_ff, ak)
-        ms = F.log_optimal_transport(F.bmm_nt(pkf, akf), pkm, akm, self.optimal_transport.alpha,
-                                     scale=1.0 / pos_ff.shape[1] ** 0.5, iters=self.optimal_transport.num_iterations)
+        ms = F.patch_log_optimal_transport(pos_ff, pk, anc_ff, ak, pkm, akm, self.optimal_transport.alpha,
+                                           scale=1.0 / pos_ff.shape[1] ** 0.5, iters=self.optimal_transport.num_iterations)
         rp, sp, sc, T = self._local_global_registration(pkp, akp, pkm, akm, ms, node_corr_scores)
         out.update({
             "pos_points_c": pos_nodes, "anc_points_c": anc_nodes, "pos_feats_c": pos_fc, "anc_feats_c": anc_fc,

@@ -397,3 +397,55 @@ def test_planted_motion_pose_end_to_end(case):
     with torch.no_grad():
         out = m(dd)
     check_planted_pose(out, gold)
+
+
+@pytest.mark.parametrize("P,same", [(37, True), (5, False), (300, True)])
+def test_fused_patch_scores_equal_gather_product_padding(P, same):
+    """lcr_patch_scores (gathers + batched product + scaling + dustbin / mask padding of LCRNet.py:236-250 in one kernel) against the three
+    separate steps (lcr_gather_rows x 2, the batched MFMA product, lcr_build_padded_scores) and an fp64 product: same -inf pattern, same
+    dustbins, products within fp32 re-association of each other and of fp64; shadow indices (== N) give zero rows."""
+    from lcrnet_amd import functional as F
+    g = torch.Generator().manual_seed(P)
+    Na, Nb, C, K = 3000, (3000 if same else 1777), 256, 128
+    fa = torch.randn(Na, C, generator=g).cuda()
+    fb = fa if same else torch.randn(Nb, C, generator=g).cuda()
+    ia = torch.randint(0, Na + 1, (P, K), generator=g).cuda()                 # Na itself = the shadow index
+    ib = torch.randint(0, Nb + 1, (P, K), generator=g).cuda()
+    ma = (torch.rand(P, K, generator=g) < 0.8).cuda() & (ia < Na)
+    mb = (torch.rand(P, K, generator=g) < 0.8).cuda() & (ib < Nb)
+    alpha = torch.tensor(0.37).cuda()
+    scale = 1.0 / C ** 0.5
+    raw = F.bmm_nt(F.gather_rows(fa, ia), F.gather_rows(fb, ib))
+    L = F._L()
+    from lcrnet_amd import _lib
+    want = torch.empty((P, K + 1, K + 1), device="cuda")
+    r8, c8 = ma.to(torch.uint8).contiguous(), mb.to(torch.uint8).contiguous()
+    _lib.check(L.lcr_build_padded_scores(_lib.ptr(raw), _lib.ptr(r8), _lib.ptr(c8), P, K, K, scale, _lib.ptr(alpha.reshape(1)), 1e12, _lib.ptr(want),
+                                         _lib.stream_ptr(want.device)), "pad")
+    got = torch.empty_like(want)
+    _lib.check(L.lcr_patch_scores(_lib.ptr(fa), Na, _lib.ptr(fb), Nb, C, _lib.ptr(ia), _lib.ptr(ib), _lib.ptr(r8), _lib.ptr(c8), P, K, scale,
+                                  _lib.ptr(alpha.reshape(1)), 1e12, _lib.ptr(got), _lib.stream_ptr(got.device)), "fused")
+    torch.cuda.synchronize()
+    neg = want < -1e11
+    assert torch.equal(neg, got < -1e11)
+    assert torch.equal(got[:, K, :], want[:, K, :]) and torch.equal(got[:, :, K], want[:, :, K])
+    ga = torch.cat([fa, torch.zeros(1, C, device="cuda")])[ia].double()
+    gb = torch.cat([fb, torch.zeros(1, C, device="cuda")])[ib].double()
+    ref = torch.einsum("pnd,pmd->pnm", ga, gb) * scale
+    live = ~neg[:, :K, :K]
+    e_fused = (got[:, :K, :K].double() - ref)[live].abs().max().item()
+    e_apart = (want[:, :K, :K].double() - ref)[live].abs().max().item()
+    print("patch scores P=%d: fused vs fp64 %.2e, separate steps vs fp64 %.2e, fused vs separate %.2e" % (
+        P, e_fused, e_apart, (got - want)[~neg].abs().max().item()))
+    assert e_fused < 2e-5 and e_fused <= 2 * e_apart + 1e-6
+    # and the whole transport through either path
+    was = F.PATCH_SCORES_FUSED[0]
+    try:
+        F.PATCH_SCORES_FUSED[0] = True
+        a = F.patch_log_optimal_transport(fa, ia, fb, ib, ma, mb, alpha, scale=scale, iters=100)
+        F.PATCH_SCORES_FUSED[0] = False
+        b = F.patch_log_optimal_transport(fa, ia, fb, ib, ma, mb, alpha, scale=scale, iters=100)
+    finally:
+        F.PATCH_SCORES_FUSED[0] = was
+    keep = b > -1e11
+    assert torch.equal(keep, a > -1e11) and (a - b)[keep].abs().max().item() < 1e-4
