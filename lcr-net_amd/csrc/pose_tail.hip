@@ -988,6 +988,9 @@ __global__ __launch_bounds__(SKC_T) void k_log_sinkhorn_coop(float* __restrict__
   }
 }
 
+// logs below this cannot reach the exp value of a line whose largest log is m (see k_top1_stats)
+__device__ __forceinline__ float top1_floor(float m) { return m < -80.f ? -INFINITY : m - 1e-5f * fmaxf(1.f, fabsf(m)); }
+
 // ---- dustbin top-1 matching (exp domain): row / column maxima vs the dustbins -------------------------------------------------
 // rowarg[b][i] = argmax_j P[i][:], rowbeat = P[i][rowarg] > P[i][N];  colarg[b][j] = argmax_i P[:][j], colbeat = P[colarg][j] > P[M][j].
 __global__ __launch_bounds__(256) void k_top1_stats(const float* __restrict__ logS, int M, int N, int32_t* __restrict__ rowarg,
@@ -998,14 +1001,27 @@ __global__ __launch_bounds__(256) void k_top1_stats(const float* __restrict__ lo
   const int M1 = M + 1, N1 = N + 1;
   const float* s = logS + static_cast<int64_t>(b) * M1 * N1;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
+  // The reference takes exp of the whole matrix and then the arg-max (local_global_registration.py:222, superpoint_matching.py:137): the
+  // winner is the largest EXP value, the lowest index among equal ones.  exp is evaluated here for the CANDIDATES only — the entries within
+  // top1_floor() of the line's largest log (two logs further apart than 1e-5 relative cannot round to one exp value; below -80, where exp
+  // underflows and its values get coarse, every entry is a candidate) — so the decision is taken on the same exp values as before
+  // (129 expf per line -> typically 1: the kernel was 0.7 ms of a 16-pair call).
   for (int i = slice * 4 + w; i < M1; i += 4 * nslices) {
+    float m = -INFINITY;
+    for (int j = lane; j < N1; j += 64) m = fmaxf(m, s[i * N1 + j]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    const float thr = top1_floor(m);
     float best = -INFINITY;
     int bj = 0;
     for (int j = lane; j < N1; j += 64) {
-      const float p = expf(s[i * N1 + j]);
-      if (p > best) {
-        best = p;
-        bj = j;
+      const float x = s[i * N1 + j];
+      if (x >= thr) {
+        const float p = expf(x);
+        if (p > best) {
+          best = p;
+          bj = j;
+        }
       }
     }
 #pragma unroll
@@ -1023,13 +1039,19 @@ __global__ __launch_bounds__(256) void k_top1_stats(const float* __restrict__ lo
     }
   }
   for (int j = slice * 256 + threadIdx.x; j < N1; j += 256 * nslices) {
+    float m = -INFINITY;
+    for (int i = 0; i < M1; ++i) m = fmaxf(m, s[i * N1 + j]);
+    const float thr = top1_floor(m);
     float best = -INFINITY;
     int bi = 0;
     for (int i = 0; i < M1; ++i) {
-      const float p = expf(s[i * N1 + j]);
-      if (p > best) {
-        best = p;
-        bi = i;
+      const float x = s[i * N1 + j];
+      if (x >= thr) {
+        const float p = expf(x);
+        if (p > best) {
+          best = p;
+          bi = i;
+        }
       }
     }
     colarg[static_cast<int64_t>(b) * N1 + j] = bi;

@@ -324,3 +324,40 @@ def ctypes_topk(F, logs, rm, sm, mutual):
     sc = torch.empty((n,), dtype=torch.float32, device="cuda")
     _lib.check(_lib.lib().lcr_topk_matching(*args, _lib.ptr(tot), _lib.ptr(bij), _lib.ptr(sc), _lib.ptr(ws), ws.numel(), sp), "topk")
     return bij
+
+
+def test_top1_candidate_rule_equals_exp_of_everything():
+    """k_top1_stats evaluates exp only for the entries within a hair of a line's largest log; lcr_topk_matching (K = 1) still takes exp of
+    every entry.  Same rows on inputs built to break a log-domain shortcut: logs one ulp apart (equal after exp), exact duplicates, lines whose
+    largest entry underflows (-90 .. -104: coarse exp values), fully masked lines (-1e12) and ordinary transport outputs."""
+    from lcrnet_amd import functional as F
+    g = torch.Generator().manual_seed(77)
+    B, K = 40, 128
+    logs = torch.randn(B, K + 1, K + 1, generator=g) * 3 - 4
+    for b in range(B):
+        for _ in range(60):                                              # near-ties: a copy of the line's maximum one or two ulps away
+            i = int(torch.randint(0, K + 1, (1,), generator=g))
+            j = int(torch.argmax(logs[b, i]))
+            j2 = int(torch.randint(0, K + 1, (1,), generator=g))
+            x = logs[b, i, j]
+            steps = int(torch.randint(-2, 3, (1,), generator=g))
+            y = x.clone()
+            for _s in range(abs(steps)):
+                y = torch.nextafter(y, torch.tensor(float("inf") if steps > 0 else float("-inf")))
+            logs[b, i, j2] = y
+            jj = int(torch.randint(0, K + 1, (1,), generator=g))     # and the same down a column
+            i1 = int(torch.argmax(logs[b, :, jj]))
+            i2 = int(torch.randint(0, K + 1, (1,), generator=g))
+            logs[b, i2, jj] = logs[b, i1, jj]
+    logs[3] = torch.rand(K + 1, K + 1, generator=g) * 14 - 104           # exp underflows / denormal range
+    logs[4, 5:40] = -1e12                                                # masked rows
+    logs[4, :, 7:30] = -1e12                                             # masked columns
+    logs[5] = -1e12
+    rm = torch.ones(B, K, dtype=torch.bool)
+    cm = torch.ones(B, K, dtype=torch.bool)
+    rm[4, 5:40] = False
+    cm[4, 7:30] = False
+    for mutual in (False, True):
+        a, sa = F.top1_matching(logs.cuda(), rm.cuda(), cm.cuda(), mutual=mutual)
+        nb = ctypes_topk(F, logs.cuda(), rm.cuda(), cm.cuda(), mutual)
+        assert a.shape[0] > 1000 and torch.equal(a, nb)
