@@ -1059,6 +1059,111 @@ __global__ __launch_bounds__(256) void k_top1_stats(const float* __restrict__ lo
   }
 }
 
+// The same for matrices of up to 192 x 192 (the 129 x 129 patch problems: 7 716 of them per 16-pair call), ONE pass over the matrix per
+// phase for rows AND columns: wavefront w takes rows w, w + 4, ...; a lane holds three columns (lane, lane + 64, lane + 128) and carries their
+// running maxima / candidates down its rows, the four wavefronts' column partials meet in LDS.  The generic kernel reads the matrix four times
+// and walks every column serially in one thread (2 x 129 dependent steps): 0.85 ms of a 16-pair call (profiles/r06_pair16_one_worker_kernel_summary.md).
+constexpr int T1S_MAX = 192;
+__global__ __launch_bounds__(256) void k_top1_stats_small(const float* __restrict__ logS, int M, int N, int32_t* __restrict__ rowarg,
+                                                          uint8_t* __restrict__ rowbeat, int32_t* __restrict__ colarg, uint8_t* __restrict__ colbeat) {
+  __shared__ float s_rm[T1S_MAX];
+  __shared__ float s_cv[4][T1S_MAX];
+  __shared__ int s_ci[4][T1S_MAX];
+  const int64_t b = blockIdx.x;
+  const int M1 = M + 1, N1 = N + 1;
+  const float* s = logS + b * M1 * N1;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float cm[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = w; i < M1; i += 4) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int j = lane + 64 * c;
+      const float x = j < N1 ? s[i * N1 + j] : -INFINITY;
+      m = fmaxf(m, x);
+      cm[c] = fmaxf(cm[c], x);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if (lane == 0) s_rm[i] = m;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) s_cv[w][lane + 64 * c] = cm[c];
+  __syncthreads();
+  float cthr[3], cb[3] = {-INFINITY, -INFINITY, -INFINITY};
+  int ci[3] = {0, 0, 0};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int j = lane + 64 * c;
+    cthr[c] = top1_floor(fmaxf(fmaxf(s_cv[0][j], s_cv[1][j]), fmaxf(s_cv[2][j], s_cv[3][j])));
+  }
+  __syncthreads();                                       // s_cv is reused for the candidates below
+  for (int i = w; i < M1; i += 4) {
+    const float rthr = top1_floor(s_rm[i]);
+    float best = -INFINITY;
+    int bj = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {                        // ascending j inside the lane, ascending i down the loop: first index among equal values
+      const int j = lane + 64 * c;
+      if (j < N1) {
+        const float x = s[i * N1 + j];
+        const bool rc = x >= rthr, cc = x >= cthr[c];
+        if (rc || cc) {
+          const float pv = expf(x);
+          if (rc && pv > best) {
+            best = pv;
+            bj = j;
+          }
+          if (cc && pv > cb[c]) {
+            cb[c] = pv;
+            ci[c] = i;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const float ob = __shfl_xor(best, d);
+      const int oj = __shfl_xor(bj, d);
+      if (ob > best || (ob == best && oj < bj)) {
+        best = ob;
+        bj = oj;
+      }
+    }
+    if (lane == 0) {
+      rowarg[b * M1 + i] = bj;
+      rowbeat[b * M1 + i] = best > expf(s[i * N1 + N]) ? 1 : 0;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    s_cv[w][lane + 64 * c] = cb[c];
+    s_ci[w][lane + 64 * c] = ci[c];
+  }
+  __syncthreads();
+  if (w == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int j = lane + 64 * c;
+      if (j < N1) {
+        float best = s_cv[0][j];
+        int bi = s_ci[0][j];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+          const float ob = s_cv[q][j];
+          const int oi = s_ci[q][j];
+          if (ob > best || (ob == best && oi < bi)) {
+            best = ob;
+            bi = oi;
+          }
+        }
+        colarg[b * N1 + j] = bi;
+        colbeat[b * N1 + j] = best > expf(s[M * N1 + j]) ? 1 : 0;
+      }
+    }
+  }
+}
+
 // count / emit the (i, j) pairs of every row in row-major order: (rowarg hit) OR — AND with `mutual` — (column hits with colarg == i), i < M, j < N,
 // optionally gated by validity masks.  PHASE 0 = count per (b, i); PHASE 1 = write at the scanned offsets.
 template <int PHASE>
@@ -1926,7 +2031,10 @@ extern "C" int lcr_top1_matching_ex(const float* logS, int64_t B, int M, int N, 
   hipStream_t st = ST(stream);
   if (!out_bij) {
     const int slices = B >= 64 ? 1 : std::max(1, std::min(32, (M + 1 + 15) / 16));
-    hipLaunchKernelGGL(k_top1_stats, dim3(static_cast<int>(B), slices), dim3(256), 0, st, logS, M, N, rowarg, rowbeat, colarg, colbeat);
+    if (M + 1 <= T1S_MAX && N + 1 <= T1S_MAX)
+      hipLaunchKernelGGL(k_top1_stats_small, dim3(static_cast<int>(B)), dim3(256), 0, st, logS, M, N, rowarg, rowbeat, colarg, colbeat);
+    else
+      hipLaunchKernelGGL(k_top1_stats, dim3(static_cast<int>(B), slices), dim3(256), 0, st, logS, M, N, rowarg, rowbeat, colarg, colbeat);
     hipLaunchKernelGGL((k_top1_emit<0>), dim3(blocks_for(B * M)), dim3(256), 0, st, logS, B, M, N, rowarg, rowbeat, colarg, colbeat, row_mask, col_mask,
                        counts, offsets, out_bij, out_score, mutual);
     hipMemsetAsync(counts + B * M, 0, sizeof(int32_t), st);

@@ -326,13 +326,13 @@ def ctypes_topk(F, logs, rm, sm, mutual):
     return bij
 
 
-def test_top1_candidate_rule_equals_exp_of_everything():
+@pytest.mark.parametrize("K,B", [(128, 40), (250, 8), (191, 6), (192, 6)])
+def test_top1_candidate_rule_equals_exp_of_everything(K, B):
     """k_top1_stats evaluates exp only for the entries within a hair of a line's largest log; lcr_topk_matching (K = 1) still takes exp of
     every entry.  Same rows on inputs built to break a log-domain shortcut: logs one ulp apart (equal after exp), exact duplicates, lines whose
     largest entry underflows (-90 .. -104: coarse exp values), fully masked lines (-1e12) and ordinary transport outputs."""
     from lcrnet_amd import functional as F
-    g = torch.Generator().manual_seed(77)
-    B, K = 40, 128
+    g = torch.Generator().manual_seed(77 + K)                          # K + 1 <= 192: the one-pass small-matrix kernel; above: the generic one
     logs = torch.randn(B, K + 1, K + 1, generator=g) * 3 - 4
     for b in range(B):
         for _ in range(60):                                              # near-ties: a copy of the line's maximum one or two ulps away
@@ -360,4 +360,5 @@ def test_top1_candidate_rule_equals_exp_of_everything():
     for mutual in (False, True):
         a, sa = F.top1_matching(logs.cuda(), rm.cuda(), cm.cuda(), mutual=mutual)
         nb = ctypes_topk(F, logs.cuda(), rm.cuda(), cm.cuda(), mutual)
-        assert a.shape[0] > 1000 and torch.equal(a, nb)
+        assert a.shape[0] > 100, a.shape
+        assert torch.equal(a, nb)
