@@ -556,7 +556,8 @@ class PairPipeline:
     and by launch latency, not by the GPU; a second pair in flight fills the gaps (80 -> 100-120 pairs/s on the demo pair).  At ONE pair
     per call more than two workers lose to interpreter-lock contention (59 pairs/s with three, round 2); with pairs batched per call
     (pairs_per_call >= 8: most of a call is native launch sequences that release the lock) a third worker fills the latency-bound tail:
-    584 / 628 / 629 pairs/s with 2 / 3 / 4 workers at 16 pairs per call (round 5)."""
+    584 / 628 / 629 pairs/s with 2 / 3 / 4 workers at 16 pairs per call (round 5); round 6, with a third less kernel time per call: 643 / 675-690 /
+    695-721 with 2 / 3 / 4."""
 
     def __init__(self, model, voxel_size=0.3, radius=1.275, num_stages=4, neighbor_limits=(74, 68, 70, 67), workers=2, pairs_per_call=1,
                  upsampling="nearest"):
