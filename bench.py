@@ -556,6 +556,11 @@ def main():
                     iso["t_" + cls] += k_ if k_ is not None else b_
                     iso["n_" + cls] += 1
                     iso["fl_" + cls] += 2.0 * m_[0] * m_[1] * m_[2]
+                    # the launch's own roofline time: the slower of its fp32 MFMA time and its algorithmic HBM time (A + B + C once each)
+                    iso["t_roof_" + cls] = iso.get("t_roof_" + cls, 0.0) + max(2.0 * m_[0] * m_[1] * m_[2] / (FP32_PEAK_TFLOPS * 1e12),
+                                                                            4.0 * (m_[0] * m_[2] + m_[1] * m_[2] + m_[0] * m_[1]) / (HBM_PEAK_GBS * 1e9))
+                    iso["hbm_bound_" + cls] = iso.get("hbm_bound_" + cls, 0) + (4.0 * (m_[0] * m_[2] + m_[1] * m_[2] + m_[0] * m_[1]) / (HBM_PEAK_GBS * 1e9) >
+                                                                               2.0 * m_[0] * m_[1] * m_[2] / (FP32_PEAK_TFLOPS * 1e12))
             iso["flops"].append(sum(2.0 * m[0] * m[1] * m[2] for _, _, m in r["gemm"]))
             iso["flops_agg"].append(sum(2.0 * 15 * nnz.get((M, Ns), M * H) * C for _, _, (M, Ns, H, C, isz) in r["kpconv_aggregate"]))
     if rank == 0 and os.environ.get("LCR_BENCH_NO_KTIMER"):            # A/B run without per-launch events: the headline only
@@ -631,7 +636,12 @@ def main():
                     "fp32_mfma": {"kernel": "k_gemm_f32 / k_gemm_f32_deep (v_mfma_f32_32x32x2_f32)", "launches_per_step": round(iso["n_light"] / iso["passes"], 1),
                                   "kernel_ms_per_step": round(iso["t_light"] / iso["passes"] * 1e3, 4),
                                   "tflops": round(iso["fl_light"] / max(iso["t_light"], 1e-12) / 1e12, 2),
-                                  "frac_of_fp32_mfma_peak": round(iso["fl_light"] / max(iso["t_light"], 1e-12) / 1e12 / FP32_PEAK_TFLOPS, 4)}},
+                                  "frac_of_fp32_mfma_peak": round(iso["fl_light"] / max(iso["t_light"], 1e-12) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                                  "hbm_bound_launches_per_step": round(iso.get("hbm_bound_light", 0) / iso["passes"], 1),
+                                  "frac_of_two_sided_roofline": round(iso.get("t_roof_light", 0.0) / max(iso["t_light"], 1e-12), 4)},
+                    "two_sided": {"frac": round((iso.get("t_roof_light", 0.0) + iso.get("t_roof_split", 0.0)) / max(iso["t_gemm"], 1e-12), 4),
+                                  "what": "sum over the launches of max(2MNK / 157.3 TFLOP/s, 4 (MK + NK + MN) B / 8 TB/s) / sum of their own durations: "
+                                          "the wide stage-1/2 Linears (K <= 128) move more bytes than their flops take on the matrix cores"}},
                 "avg_launch_us": round(iso["t_gemm"] / max(iso["n_gemm"], 1) * 1e6, 2),
                 "kernel_ms_per_step": round(iso["t_gemm"] / iso["passes"] * 1e3, 4),
                 "gflop_per_launch": round(flops_step / gemm_per_step / 1e9, 3),
