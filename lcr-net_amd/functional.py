@@ -443,6 +443,9 @@ def attention(q, k, v, heads, q_lens=None, k_lens=None):
     return out
 
 
+ATTENTION_TOPK_MAX_KEYS = 4096     # ATK_MAXK of csrc/attention.hip: one row of scores per (query, head) in LDS
+
+
 def attention_topk(q, k, v, heads, q_lens, k_lens, kks):
     """dynamic_attention with k != None (rpetransformer.py:19-39): per problem p (rows stacked like `attention`), query and head, only the
     kks[p] largest scores are soft-maxed.  kks[p] = int(n_queries_p * fraction) is computed by the caller as the reference does."""

@@ -42,7 +42,14 @@ class _MultiHeadAttention(nn.Module):
         if topk_frac is not None:                                 # dynamic_attention(q, k, v, self.k[layer]): k = int(n * k), n = the cloud's queries
             ql = list(q_lens) if q_lens is not None else [q.shape[0]]
             kl = list(k_lens) if k_lens is not None else [k.shape[0]]
-            return F.attention_topk(q, k, v, self.num_heads, ql, kl, [int(n * topk_frac) for n in ql])
+            kks = [int(n * topk_frac) for n in ql]
+            for n_k, kk in zip(kl, kks):
+                if kk > n_k:                                      # torch.topk raises here too (rpetransformer.py:27-28); the kernel would clamp
+                    raise RuntimeError("top-k attention: k = %d exceeds the %d keys of the cloud (selected index k out of range)" % (kk, n_k))
+                if n_k > F.ATTENTION_TOPK_MAX_KEYS:               # before anything is launched (advisor r5): the scores of a row live in LDS
+                    raise RuntimeError("top-k attention (cfg.GAT.k) supports at most %d keys per cloud, got %d; the dense form (k = None) has "
+                                       "no such limit" % (F.ATTENTION_TOPK_MAX_KEYS, n_k))
+            return F.attention_topk(q, k, v, self.num_heads, ql, kl, kks)
         return F.attention(q, k, v, self.num_heads, q_lens, k_lens)
 
 
