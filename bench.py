@@ -520,9 +520,17 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_blocks
         torch.cuda.synchronize()
-        blocks_cfg = {"retrieval": bench_blocks.retrieval_block(dev),
-                      "sequence": bench_blocks.sequence_block(model, dev, scans, frames=int(os.environ.get("LCR_BENCH_SEQ_FRAMES", "2048"))),
-                      "pairs": bench_blocks.pairs_block(dev, repeats=int(os.environ.get("LCR_BENCH_PAIR_PASSES", "5")))}
+        def guarded(name, fn):                         # a secondary block must never cost the headline its line: failures are reported in place
+            try:
+                return fn()
+            except Exception as e:                     # noqa: BLE001
+                import traceback
+                traceback.print_exc(file=sys.stderr)
+                torch.cuda.synchronize()
+                return {"error": "%s block failed: %r" % (name, e)}
+        blocks_cfg = {"retrieval": guarded("retrieval", lambda: bench_blocks.retrieval_block(dev)),
+                      "sequence": guarded("sequence", lambda: bench_blocks.sequence_block(model, dev, scans, frames=int(os.environ.get("LCR_BENCH_SEQ_FRAMES", "2048")))),
+                      "pairs": guarded("pairs", lambda: bench_blocks.pairs_block(dev, repeats=int(os.environ.get("LCR_BENCH_PAIR_PASSES", "5"))))}
         torch.cuda.empty_cache()
     final_line = None
     iso = None

@@ -15,6 +15,7 @@ import torch
 
 from conftest import GOLDEN, LIMITS, NUM_STAGES, RADIUS, VOXEL, load_scan
 from oracle import ops as oracle_ops
+from oracle import torch_ref
 
 pytestmark = pytest.mark.gpu
 sys.path.insert(0, GOLDEN)
@@ -362,3 +363,32 @@ def test_top1_candidate_rule_equals_exp_of_everything(K, B):
         nb = ctypes_topk(F, logs.cuda(), rm.cuda(), cm.cuda(), mutual)
         assert a.shape[0] > 100, a.shape
         assert torch.equal(a, nb)
+
+
+def test_correspondence_limit_cuts_inside_a_tie_run_like_the_oracle(model):
+    """`correspondence_limit` with EQUAL scores at the cut (scores quantised to two decimals: runs of dozens of equal values): the kernel's
+    radix select admits the ties in row order, the oracle's stable sort does the same; torch.topk — the reference — leaves it open, so this
+    case is pinned against the oracle only.  The verification set is compared through what depends on it: the refined transform."""
+    from make_golden_pose_chain import synthetic_lgr_case
+    ref, src, rm, sm, logs, _ = synthetic_lgr_case(seed=5)
+    q = np.round(np.exp(logs.astype(np.float64)), 2)                    # 0.5 .. 0.9 in steps of 0.01; the 1e-4 background becomes 0
+    logs_q = np.log(np.maximum(q, 1e-30)).astype(np.float32)
+    names = ("topk", "mutual", "use_dustbin", "confidence_threshold", "use_global_score", "correspondence_limit")
+    was = {k: getattr(model, k) for k in names}
+    t = lambda x: torch.from_numpy(x)
+    try:
+        for limit in (137, 400, 901):
+            for k, v in zip(names, (1, False, True, 0.0, False, limit)):
+                setattr(model, k, v)
+            with torch.no_grad():
+                rp, sp, sc, T = model._local_global_registration(cu(ref), cu(src), cu(rm), cu(sm), cu(logs_q))
+                orp, osp, osc, oT = torch_ref.local_global_registration(t(ref), t(src), t(rm), t(sm), t(logs_q), correspondence_limit=limit)
+            s_sorted = np.sort(osc.numpy())[::-1]
+            assert len(osc) > limit and s_sorted[limit - 1] == s_sorted[limit], "the cut must fall inside a run of equal scores"
+            assert np.array_equal(rp.cpu().numpy(), orp.numpy()) and np.abs(sc.cpu().numpy() - osc.numpy()).max() < 1e-6
+            e_T = np.abs(T.cpu().numpy() - oT.numpy()).max()
+            print("limit %d of %d correspondences (cut inside a tie run): T within %.2e of the oracle's" % (limit, len(osc), e_T))
+            assert e_T < TOL
+    finally:
+        for k, v in was.items():
+            setattr(model, k, v)
