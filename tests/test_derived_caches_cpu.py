@@ -94,3 +94,57 @@ def test_native_table_key_and_module_copies():
     m.float()
     assert enc._native_table is None
     torch.save(m, io.BytesIO())
+
+
+def test_native_table_key_sees_structural_changes():
+    """The key keeps (container, name) slots instead of walking named_parameters() on every forward (round 6): a replaced sub-module, a
+    replaced / added / removed parameter and the GEMM-form switch must all still fail the check; an untouched module passes it repeatedly."""
+    import torch.nn as nn
+    from lcrnet_amd.modules.kpconv.modules import ResidualBlock
+    m = create_model().eval()
+    enc = m.encoder
+    key = native_encoder._Key(enc)
+    assert key.valid(enc) and key.valid(enc)
+    old = enc.encoder2_2
+    enc.encoder2_2 = ResidualBlock(old.in_channels, old.out_channels, 15, 1.0, 0.6, 32)      # a NEW sub-module of the same shape
+    assert not key.valid(enc)
+    enc.encoder2_2 = old
+    assert key.valid(enc)                                       # the very same objects again
+    lin = enc.encoder3_2.unary1.mlp
+    w = lin.weight
+    lin.weight = nn.Parameter(w.detach().clone())               # a new Parameter object at a new address
+    assert not key.valid(enc)
+    lin.weight = w
+    assert key.valid(enc)
+    lin.register_buffer("extra", torch.zeros(1))                # a tensor that was not there when the key was made
+    assert not key.valid(enc)
+    del lin._buffers["extra"]
+    assert key.valid(enc)
+    was = F.gemm_split_enabled()
+    F.set_gemm_split(not was)
+    try:
+        assert not key.valid(enc)                               # the table holds (or lacks) split planes: bound to the GEMM form
+    finally:
+        F.set_gemm_split(was)
+    assert key.valid(enc)
+
+
+def test_roformer_native_table_follows_the_weights():
+    from lcrnet_amd import native_roformer
+    from lcrnet_amd.modules.thdroformer import ThDRoFormer
+    tf = ThDRoFormer(1024, 256, 128, 4, 2).eval()
+    w = native_roformer._table(tf)
+    assert w.num_blocks == 4 and [w.block_is_self[i] for i in range(4)] == [1, 0, 1, 0] and (w.d_in, w.d_model, w.d_out, w.heads) == (1024, 128, 256, 4)
+    assert w.layers[1].q.w == tf.transformer.layers[1].attention.attention.proj_q.weight.data_ptr()
+    assert w.layers[3].ln2_b == tf.transformer.layers[3].output.norm.bias.data_ptr() and abs(w.layers[0].ln1_eps - 1e-5) < 1e-12
+    t1 = native_roformer.table_for(tf)
+    assert native_roformer.table_for(tf) is t1                  # cached
+    with torch.no_grad():
+        tf.out_proj.bias.add_(1.0)
+    assert native_roformer.table_for(tf) is not t1              # rebuilt after an in-place update
+    assert native_roformer.eligible(tf, torch.zeros(1, 1024)) is False      # CPU features: the module tree (which then refuses CPU tensors itself)
+    tf.double()
+    assert "_native_table" not in tf.__dict__                   # _apply drops the raw-pointer table
+    assert "_native_table" not in copy.deepcopy(tf).__dict__
+    tk = ThDRoFormer(1024, 256, 128, 4, 2, k=[0.5, 0.5])
+    assert not native_roformer.eligible(tk, torch.zeros(1, 1024))           # top-k attention runs through the module tree
