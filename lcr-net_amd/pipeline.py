@@ -548,6 +548,40 @@ class DescriptorPipeline:
             yield pending[0]
 
 
+def gpu_node_cpus(device_index):
+    """The host cores of the NUMA node GPU `device_index` hangs off (sysfs, via the device's PCI address), restricted to the cores this
+    process may use; None when the topology cannot be read (containers without sysfs, single-node hosts)."""
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        addr = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % addr).read())
+        if node < 0:
+            return None
+        cpus = []
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus += list(range(int(a), int(b or a) + 1))
+        allowed = set(os.sched_getaffinity(0))
+        cpus = [c for c in cpus if c in allowed]
+        return cpus or None
+    except Exception:                                  # noqa: BLE001
+        return None
+
+
+def compact_core_set(device_index, n):
+    """n neighbouring cores next to the GPU for a pipeline's host threads, or None (leave the threads where the scheduler puts them).
+    Why: the pair path is host-bound (a thread issues ~1 000 launches per pair and hands the interpreter lock to its peers at every
+    blocking call); with the threads free to roam a 256-core box, 16 pairs per call ran at 690 +- 40 pairs/s, pinned to 8 cores of the
+    GPU's node at 746 +- 10 (one pair per call 228 -> 257; profiles/r06_pair_core_binding.log).  The scans/s pipeline is GPU-bound and
+    does not care (2 878-2 915 scans/s bound or not)."""
+    if os.environ.get("LCR_PIPE_BIND", "1") == "0":
+        return None
+    cpus = gpu_node_cpus(device_index)
+    if cpus is None or len(cpus) <= n:
+        return None                                    # nothing to compact (already bound to a small share, e.g. one rank of eight)
+    return cpus[:n]
+
+
 class PairPipeline:
     """Registration pairs (BASELINE config 5, reference loop: experiments/inference/infer_registration.py) through the full pair
     model, `workers` pairs in flight: one host thread + one HIP stream per worker, results handed back in input order.
@@ -573,6 +607,8 @@ class PairPipeline:
         self.device = next(model.parameters()).device
         # worker streams: created and probed ONCE per pipeline (two busy streams on one hardware queue serialise each other)
         self._streams = distinct_queue_streams(self.device, self.workers) if self.workers > 1 else []
+        # the worker threads pin THEMSELVES to a few neighbouring cores next to the GPU (the caller's thread is left alone); LCR_PIPE_BIND=0: off
+        self._cores = compact_core_set(self.device.index if self.device.index is not None else torch.cuda.current_device(), 8)
         self._finalizer = weakref.finalize(self, release_streams, list(self._streams))
         self._finalizer.atexit = False               # nothing to hand back to at interpreter exit (and the runtime may be gone)
 
@@ -646,6 +682,11 @@ class PairPipeline:
         def worker():
             try:
                 torch.cuda.set_device(dev)
+                if self._cores:
+                    try:
+                        os.sched_setaffinity(0, self._cores)        # pid 0 = the calling THREAD on Linux
+                    except OSError:
+                        pass
                 with it_lock:
                     st = next(stream_it)
                 st.wait_stream(main)
