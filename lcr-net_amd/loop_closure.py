@@ -62,7 +62,7 @@ def register_pairs(pair_model, clouds, pairs, limits, pairs_per_call=16, workers
     dev = clouds[0].device
     work = [(torch.cat([clouds[p], clouds[a]]), torch.tensor([len(clouds[p]), len(clouds[a])], dtype=torch.int64, device=dev)) for p, a in pairs]
     P = max(1, min(pairs_per_call, len(work)))
-    with PairPipeline(pair_model, neighbor_limits=limits, workers=workers or (2 if P == 1 else 4), pairs_per_call=P) as pp:
+    with PairPipeline(pair_model, neighbor_limits=limits, workers=workers or (4 if P == 1 else 5), pairs_per_call=P) as pp:
         return list(pp.run(work))
 
 

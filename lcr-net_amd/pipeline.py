@@ -591,7 +591,9 @@ class PairPipeline:
     per call more than two workers lose to interpreter-lock contention (59 pairs/s with three, round 2); with pairs batched per call
     (pairs_per_call >= 8: most of a call is native launch sequences that release the lock) a third worker fills the latency-bound tail:
     584 / 628 / 629 pairs/s with 2 / 3 / 4 workers at 16 pairs per call (round 5); round 6, with a third less kernel time per call: 643 / 675-690 /
-    695-721 with 2 / 3 / 4."""
+    695-721 with 2 / 3 / 4.  With the worker threads pinned to 8 cores next to the GPU (`compact_core_set`, the default) more calls in flight
+    pay at every batching: one pair per call 260 / 344 / 400 / 425 pairs/s with 2 / 3 / 4 / 8 workers (10: collapse — more threads than cores),
+    16 per call 733 / 747 / 777 with 3 / 4 / 5."""
 
     def __init__(self, model, voxel_size=0.3, radius=1.275, num_stages=4, neighbor_limits=(74, 68, 70, 67), workers=2, pairs_per_call=1,
                  upsampling="nearest"):

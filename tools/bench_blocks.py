@@ -75,7 +75,9 @@ def pairs_block(dev, per_call=(1, 16), pairs=192, repeats=5, model=None):
         # a timed pass should last ~0.5 s or more: at 16 pairs per call 192 pairs are 12 calls = 0.28 s, a third of it pipeline fill and
         # drain of the three workers (round 3 met the same at 64 pairs per pass of 8-pair calls: +-10 % pass to pass) -> twice the pairs
         work = demo_pairs(dev, pairs if P == 1 else 2 * pairs)
-        workers = 2 if P == 1 else 4                            # batched calls: 675-690 pairs/s with three workers, 695-721 with four (same session)
+        # with the worker threads pinned next to the GPU more calls in flight pay (profiles/r06_pair_core_binding.log): one pair per call
+        # 260 / 344 / 400 / 413 / 425 pairs/s with 2 / 3 / 4 / 6 / 8 workers (10 collapse: more threads than the 8 cores); 16 per call 733 / 747 / 777 / 716 with 3 / 4 / 5 / 6
+        workers = 4 if P == 1 else 5
         with PairPipeline(m, neighbor_limits=PAIR_LIMITS, workers=workers, pairs_per_call=P) as pp:
             for _ in pp.run(work * max(2, workers)):           # as many FULL untimed passes as workers: the caching allocator then holds
                 pass                                           # blocks for every stack shape the timed passes will ask for
@@ -129,8 +131,8 @@ def pairs_block(dev, per_call=(1, 16), pairs=192, repeats=5, model=None):
             "unit": "pairs/s", "config": "configs[4] on one GPU: %d pairs per pass at one pair per call, %d when batched = the 15 combinations of the 6 KITTI demo "
                                          "scans cycled (~17k pts per cloud after 0.3 m voxels), limits %s, seeded random weights" % (pairs, 2 * pairs, PAIR_LIMITS),
             "by_pairs_per_call": out,
-            "what": "NOT the headline.  P = 1 is the reference's loop (one pair per forward, two calls in flight on two host threads / streams); "
-                    "P = 16 stacks 16 pairs per LCRNet.forward_pairs call, four calls in flight.  median / min / max of %d passes" % repeats}
+            "what": "NOT the headline.  P = 1 is the reference's loop (one pair per forward, four calls in flight on four host threads / streams); "
+                    "P = 16 stacks 16 pairs per LCRNet.forward_pairs call, five calls in flight.  median / min / max of %d passes" % repeats}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
