@@ -114,3 +114,38 @@ def test_nearest_only_upsampling_lists_are_column_zero_and_change_nothing():
     for oa, ob in zip(fa, fb):
         for k in ("pos_feats_f", "anc_feats_f", "pos_corr_points", "corr_scores", "estimated_transform", "pos_feature_global"):
             assert oa[k].shape == ob[k].shape and torch.allclose(oa[k], ob[k], atol=1e-6), k
+
+
+def test_many_workers_give_what_one_worker_gives():
+    """Four pinned worker threads (one pair per call) and five (four pairs per call) against one call at a time, 45 pairs: outputs arrive in
+    input order and every pair's descriptors / node counts / correspondence counts are those of the single-worker run (shared weight tables,
+    derived-tensor caches and the native sequencers are used from several host threads at once)."""
+    import itertools
+    from conftest import GOLDEN
+    import os
+    from lcrnet_amd.config import make_cfg
+    from lcrnet_amd.model_family import LCRNet
+    from lcrnet_amd.pipeline import PairPipeline
+    from lcrnet_amd.weights import seeded_state_dict
+    cfg = make_cfg()
+    cfg["neighbor_limits"] = LIMITS
+    m = LCRNet(cfg).eval()
+    m.load_state_dict(seeded_state_dict(m.state_dict(), 7351), strict=True)
+    m = m.cuda()
+    names = sorted(f[:-4] for f in os.listdir(os.path.join(GOLDEN, "scans")) if f.endswith(".npy"))
+    scans = {n: torch.from_numpy(load_scan(n)).cuda() for n in names}
+    combos = list(itertools.combinations(names, 2)) * 3
+    work = [(torch.cat([scans[a], scans[b]]), torch.tensor([len(scans[a]), len(scans[b])], dtype=torch.int64, device="cuda")) for a, b in combos]
+    keep = lambda o: {k: o[k].cpu() for k in ("pos_feature_global", "anc_feature_global", "length", "corr_scores", "estimated_transform", "pos_feats_c_enhanced")}
+    with PairPipeline(m, VOXEL, RADIUS, NUM_STAGES, LIMITS, workers=1, pairs_per_call=1) as one:
+        want = [keep(o) for o in one.run(work)]
+    for workers, P in ((4, 1), (5, 4)):
+        with PairPipeline(m, VOXEL, RADIUS, NUM_STAGES, LIMITS, workers=workers, pairs_per_call=P) as pp:
+            got = [keep(o) for o in pp.run(work)]
+        assert len(got) == len(want) == 45
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert (g["pos_feature_global"] - w["pos_feature_global"]).abs().max() < 1e-5 and (g["anc_feature_global"] - w["anc_feature_global"]).abs().max() < 1e-5, (workers, P, i)
+            assert g["pos_feats_c_enhanced"].shape == w["pos_feats_c_enhanced"].shape
+            assert float((g["pos_feats_c_enhanced"] - w["pos_feats_c_enhanced"]).abs().max()) < 1e-4 * max(1.0, float(w["pos_feats_c_enhanced"].abs().max())), (workers, P, i)
+            assert g["length"].tolist() == w["length"].tolist(), (workers, P, i)
+            assert abs(g["corr_scores"].shape[0] - w["corr_scores"].shape[0]) <= 0.05 * w["corr_scores"].shape[0], (workers, P, i)
