@@ -595,7 +595,7 @@ class PairPipeline:
     pay at every batching: one pair per call 260 / 344 / 400 / 425 pairs/s with 2 / 3 / 4 / 8 workers (10: collapse — more threads than cores),
     16 per call 733 / 747 / 777 with 3 / 4 / 5."""
 
-    def __init__(self, model, voxel_size=0.3, radius=1.275, num_stages=4, neighbor_limits=(74, 68, 70, 67), workers=2, pairs_per_call=1,
+    def __init__(self, model, voxel_size=0.3, radius=1.275, num_stages=4, neighbor_limits=(74, 68, 70, 67), workers=None, pairs_per_call=1,
                  upsampling="nearest"):
         """pairs_per_call > 1: consecutive pairs are stacked and go through `LCRNet.forward_pairs` together (one collate, one encoder /
         transformer / vote-encoder / decoder pass for all of them; only the matching + registration tail runs pair by pair).
@@ -603,8 +603,10 @@ class PairPipeline:
         (nearest_upsample, backbone4.py:355-367), a limit-1 search takes the arg-min path of the kernel and writes 1/70th of the rows; True
         builds the reference collate's full rows (identical model outputs: tests/test_pairs_batched_gpu.py)."""
         self.upsampling = upsampling
-        self.model, self.workers = model, max(1, int(workers))
         self.pairs_per_call = max(1, min(32, int(pairs_per_call)))
+        if workers is None:                                  # the measured best with pinned worker threads (profiles/r06_pair_core_binding.log)
+            workers = 4 if self.pairs_per_call == 1 else 5
+        self.model, self.workers = model, max(1, int(workers))
         self.voxel_size, self.radius, self.num_stages, self.limits = voxel_size, radius, num_stages, list(neighbor_limits)
         self.device = next(model.parameters()).device
         # worker streams: created and probed ONCE per pipeline (two busy streams on one hardware queue serialise each other)

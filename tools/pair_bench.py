@@ -9,8 +9,8 @@ no collective on the data path; the slowest rank's time counts and the registrat
 (lcrnet_amd.evaluation.registration_partial / registration_reduce, the reference's utils/utils/torch.py:16-34).
 
 Pairs: the 15 combinations of the 6 committed KITTI demo scans (tests/golden/scans), cycled.  For every P the same pairs go
-through PairPipeline(pairs_per_call=P): P = 1 is the reference's loop (one pair per forward, model_family/LCRNet.py:274-321; two
-pairs in flight on two host threads), P > 1 stacks P pairs per `LCRNet.forward_pairs` call.  The attention kernel's rate is
+through PairPipeline(pairs_per_call=P): P = 1 is the reference's loop (one pair per forward, model_family/LCRNet.py:274-321; four
+pairs in flight on four pinned host threads), P > 1 stacks P pairs per `LCRNet.forward_pairs` call.  The attention kernel's rate is
 measured live with HIP events inside the library (KernelTimer): algorithmic flops 4 * Nq * Nk * 128 per attention problem (QK^T and
 PV over 4 heads x 32) / launch time, against the 157.3 TFLOP/s fp32 MFMA peak."""
 import argparse
